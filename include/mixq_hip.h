@@ -1,0 +1,147 @@
+/*
+ * mixq_hip.h — C ABI of libmixq_hip.so: MI355X (gfx950 / CDNA4) kernels for MixQ's mixed-precision
+ * quantized Linear (W8A8O16 / W4A4O16).
+ *
+ * This is the drop-in boundary.  In the reference the hot path sits behind the un-vendored
+ * Python extension module `mixlib` (call sites /root/reference/mixquant/modules/linear.py:22,189-193,205,221,
+ * 235-283,321-366 and mixquant/modules/fused/norm.py:21-33).  Each entry point below names the `mixlib`
+ * function / torch expression it replaces.  The Python shim mixq_amd/mixlib.py maps the reference's names and
+ * positional argument orders onto these functions; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers are DEVICE pointers unless the name ends in _host; no torch types cross this boundary.
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     returns immediately; 0 = success, otherwise a hipError_t (>0) or one of the MIXQ_E* codes (<0).
+ *   - outputs are caller-allocated.  Nothing here allocates or frees device memory or synchronises the device,
+ *     so every entry point is hipGraph-capturable.
+ *   - fp16 = IEEE binary16 (uint16_t storage).  "row-major [R,C] ld" = element (r,c) at base[r*ld + c].
+ *   - quantisation convention (fixed by decision because the reference cannot pin it):
+ *       x_scale[m] = fp16( max_k |x[m,k]| / qmax ),  qmax = 2^(bit-1)-1   (fp32 divide, RNE to fp16)
+ *       q[m,k]     = clamp( rint( x[m,k] / float(x_scale[m]) ), -qmax, qmax )  (fp32 IEEE divide, RNE);
+ *                    all-zero row -> scale 0, q = 0
+ *       int4 pairs are nibble-packed low-nibble = even column, two's complement (linear.py:12-18).
+ *       y[m,n]     = fp16( float(acc_i32) * float(x_scale[m]) * float(scale_col[n])
+ *                          + sum_j x_out[m,j]*w_out[n,j] (fp32 accumulate)  + addend[m,n] )  -> optional SiLU
+ *                          -> + bias[n]; ONE rounding to fp16 at the end.
+ */
+#ifndef MIXQ_HIP_H
+#define MIXQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIXQ_OK 0
+#define MIXQ_EINVAL (-1)     /* bad argument (null pointer, bit not in {4,8}, negative size ...) */
+#define MIXQ_ESHAPE (-2)     /* shape not supported by the kernels (see each function) */
+#define MIXQ_ENODEV (-3)     /* no gfx950 device / kernel image not loadable on the current device */
+
+#define MIXQ_ACT_NONE 0
+#define MIXQ_ACT_SILU 1      /* SiLU on (dequant + outlier + addend), bias added afterwards (linear.py:324-373) */
+
+typedef void* mixq_stream_t; /* hipStream_t */
+
+/* Library / device identification.  mixq_version: ABI version (major*1000 + minor). */
+int mixq_version(void);
+/* Writes up to `cap` bytes of a NUL-terminated description ("gfx950 cu=256 ...") ; returns MIXQ_ENODEV without GPU. */
+int mixq_device_info(char* buf_host, int cap);
+
+/* ---- (i) per-token absmax + quantise ------------------------------------------------------------------
+ * Replaces mixlib.FindRowScale(x, x_scale, M, K, bit) -> q_x   (linear.py:190-193, :221).
+ *   x        fp16 [M,K] row-major, ldx elements between rows (read only)
+ *   x_scale  fp16 [M]   written in place (the reference passes its cache.x_scale[inputdim,1] buffer)
+ *   q        bit=8: int8 [M,K];  bit=4: uint8 [M,K/2] nibble-packed.  K % 8 == 0 (bit 8) / K % 16 == 0 (bit 4).
+ */
+int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q,
+                        int M, int K, int ldx, int bit, mixq_stream_t stream);
+
+/* ---- outlier extraction -------------------------------------------------------------------------------
+ * Replaces mixlib.ExtractOutliersAndSetToZeros(ind, x) -> x_out   (linear.py:189, :205).
+ *   ind    int32 [n] column ids in [0,K) (distinct)
+ *   x      fp16 [M,K] ldx : columns `ind` are ZEROED IN PLACE (the reference mutates the caller's tensor)
+ *   x_out  fp16 [M,ldo]   : x_out[m,j] = x[m,ind[j]] for j < n; columns n..ldo-1 are written with zeros
+ */
+int mixq_extract_outliers_zero(uint16_t* x, const int32_t* ind, int n, uint16_t* x_out,
+                               int M, int K, int ldx, int ldo, mixq_stream_t stream);
+
+/* ---- (i)+(ii) fused: extract + zero + absmax + quantise + misprediction flag, one pass over X ---------
+ * Replaces the k2+k1 pair of linear.py:187-193 and the device-side part of the check linear.py:201.
+ *   n_dev    optional int32* device scalar holding the live outlier count (overrides n when non-NULL;
+ *            must be <= n, which then is the capacity of `ind`)
+ *   flag     optional int32* device scalar: set to 1 (atomic OR) when any x_scale[m] > fp16(sigma/qmax),
+ *            i.e. the reference's `cache.x_scale[0:M].max() > self.sigma / qmax` evaluated on device.
+ *   sigma    outlier threshold (reference: 6)
+ */
+int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev,
+                     uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
+                     int M, int K, int ldx, int ldo, int bit, float sigma, mixq_stream_t stream);
+
+/* ---- online outlier-column detection ------------------------------------------------------------------
+ * Replaces torch.unique(torch.where(abs(X) > sigma)[1]).int32  (linear.py:157-161, FindOutliers).
+ *   colflags  uint8 [K] scratch (overwritten)
+ *   ind_out   int32 [K] : ascending distinct column ids with any |x[m,k]| > fp16(sigma)
+ *   count     int32 [1] : number of ids written
+ */
+int mixq_detect_outlier_cols(const uint16_t* x, float sigma, uint8_t* colflags, int32_t* ind_out,
+                             int32_t* count, int M, int K, int ldx, mixq_stream_t stream);
+
+/* ---- weight-column dequantisation for newly found outliers --------------------------------------------
+ * Replaces `q_weight[:,ind].to(fp16) * scale_col.T` (linear.py:207,305) and, for bit=4,
+ * mixlib.unpack_int4_to_fp16(q_weight, ind) * scale_col.T (linear.py:20-22,209-210).
+ *   w          bit=8 int8 [N,K]; bit=4 uint8 [N,K/2]
+ *   scale_col  fp16 [N], or NULL to get the raw integer values as fp16 (= unpack_int4_to_fp16 alone)
+ *   out        fp16 [N,ldo], columns 0..n-1 written: out[r,j] = fp16( fp16(w[r,ind[j]]) * scale_col[r] )
+ */
+int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col, const int32_t* ind, int n,
+                             uint16_t* out, int N, int K, int ldo, int bit, mixq_stream_t stream);
+
+/* ---- (iii)+(iv) int8 MFMA GEMM with fused dequant / outlier / addend / act / bias epilogue ------------
+ * Replaces mixlib.int8FusedDequantize[Silu](q_x, q_w, x_scale, scale_col, addend, M, N, K) (linear.py:251-273,
+ * 337-351), the cuBLAS outlier GEMM torch.mm(X_out, weight_cache.T) feeding it (linear.py:248,334) and the
+ * separate `y1 += bias` (linear.py:284-285).
+ *   q_x [M,K] int8, q_w [N,K] int8 (both K-contiguous), x_scale fp16 [M], scale_col fp16 [N]
+ *   x_out fp16 [M,ldxo], w_out fp16 [N,ldwo]: outlier operands (NULL / n_out = 0 for none);
+ *         n_out_dev: optional device int32 overriding n_out (<= n_out); ldxo, ldwo >= roundup(n_out,16), % 8 == 0
+ *   addend fp16 [M,lda] or NULL;  bias fp16 [N] or NULL;  y fp16 [M,ldy]
+ *   K % 64 == 0, N % 4 == 0, ldy % 4 == 0.
+ */
+int mixq_gemm_i8_fused(const int8_t* q_x, const int8_t* q_w, const uint16_t* x_scale,
+                       const uint16_t* scale_col, const uint16_t* x_out, int ldxo,
+                       const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
+                       const uint16_t* addend, int lda, const uint16_t* bias,
+                       uint16_t* y, int ldy, int M, int N, int K, int act, mixq_stream_t stream);
+
+/* Same for nibble-packed operands: replaces mixlib.int4FusedDequantize[Silu](..., M, N, K/2)
+ * (linear.py:259-265, 278-283, 360-366).  q_x uint8 [M,K/2], q_w uint8 [N,K/2]; K is the LOGICAL depth
+ * (number of int4 columns), K % 128 == 0. */
+int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x_scale,
+                       const uint16_t* scale_col, const uint16_t* x_out, int ldxo,
+                       const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
+                       const uint16_t* addend, int lda, const uint16_t* bias,
+                       uint16_t* y, int ldy, int M, int N, int K, int act, mixq_stream_t stream);
+
+/* ---- unfused debug pair ---------------------------------------------------------------------------------
+ * mixq_gemm_i8 replaces mixlib.gemm(q_x, q_w, M, N, K) -> int32 [M,N]        (linear.py:235,321)
+ * mixq_dequant replaces mixlib.dequantizeInt8[Silu](y32, x_scale, scale_col, addend, bit, M, N) (linear.py:238,241,324,327)
+ */
+int mixq_gemm_i8(const int8_t* q_x, const int8_t* q_w, int32_t* y32, int ldy, int M, int N, int K,
+                 mixq_stream_t stream);
+int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_scale, const uint16_t* scale_col,
+                 const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy,
+                 int M, int N, int act, mixq_stream_t stream);
+
+/* ---- tuning / introspection (not part of the reference surface) ----------------------------------------
+ * Force a GEMM tile configuration id (>= 0) for subsequent mixq_gemm_* calls, -1 = automatic shape-aware
+ * choice.  Returns MIXQ_EINVAL for an unknown id.  mixq_gemm_config_name writes the config's description. */
+int mixq_gemm_set_config(int cfg);
+int mixq_gemm_num_configs(void);
+int mixq_gemm_config_name(int cfg, char* buf_host, int cap);
+/* The config the automatic choice picks for (M,N,K,bit). */
+int mixq_gemm_pick_config(int M, int N, int K, int bit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXQ_HIP_H */

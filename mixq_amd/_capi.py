@@ -1,0 +1,119 @@
+"""ctypes binding of libmixq_hip.so — the C-ABI boundary declared in include/mixq_hip.h.
+
+There is NO fallback: if the HIP library is missing or fails to load, importing anything that computes raises
+`MixqBuildError`.  (The oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmixq_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mixq_hip.h")
+
+MIXQ_OK = 0
+MIXQ_EINVAL = -1
+MIXQ_ESHAPE = -2
+MIXQ_ENODEV = -3
+ACT_NONE = 0
+ACT_SILU = 1
+
+
+class MixqBuildError(RuntimeError):
+    pass
+
+
+class MixqError(RuntimeError):
+    def __init__(self, fn: str, code: int):
+        names = {MIXQ_EINVAL: "MIXQ_EINVAL (bad argument)", MIXQ_ESHAPE: "MIXQ_ESHAPE (unsupported shape)",
+                 MIXQ_ENODEV: "MIXQ_ENODEV (no gfx950 device)"}
+        super().__init__(f"{fn} failed: {names.get(code, f'hipError_t {code}')}")
+        self.code = code
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+
+# name -> argtypes; mirrors include/mixq_hip.h one-to-one (tests/test_capi_symbols.py parses the header and checks)
+SIGNATURES = {
+    "mixq_version": [],
+    "mixq_device_info": [C.c_char_p, _I],
+    "mixq_find_row_scale": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "mixq_extract_outliers_zero": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "mixq_quant_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "mixq_detect_outlier_cols": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
+    "mixq_dequant_weight_cols": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "mixq_gemm_i8_fused": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mixq_gemm_i4_fused": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mixq_gemm_i8": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "mixq_dequant": [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "mixq_gemm_set_config": [_I],
+    "mixq_gemm_num_configs": [],
+    "mixq_gemm_config_name": [_I, C.c_char_p, _I],
+    "mixq_gemm_pick_config": [_I, _I, _I, _I],
+}
+
+_lib = None
+
+
+def header_symbols(path: str = HEADER_PATH):
+    """Function names declared in include/mixq_hip.h (used by the symbol-export test)."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(mixq_\w+)\s*\(", txt)))
+
+
+def load():
+    """Load the shared library once; raise MixqBuildError loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MixqBuildError(
+            f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  mixq_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (makes torch's libamdhip64.so.7 the HIP runtime this library binds to)
+    except Exception:  # pragma: no cover
+        pass
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise MixqBuildError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MixqBuildError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = _I
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    """Call an entry point and raise MixqError on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise MixqError(name, rc)
+
+
+def device_info() -> str:
+    buf = C.create_string_buffer(256)
+    rc = load().mixq_device_info(buf, 256)
+    if rc != 0:
+        raise MixqError("mixq_device_info", rc)
+    return buf.value.decode()
+
+
+def gemm_config_names():
+    lib = load()
+    out = []
+    for i in range(lib.mixq_gemm_num_configs()):
+        buf = C.create_string_buffer(64)
+        lib.mixq_gemm_config_name(i, buf, 64)
+        out.append(buf.value.decode())
+    return out

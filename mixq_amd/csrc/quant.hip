@@ -1,0 +1,324 @@
+// Memory-bound activation kernels of the MixQ path for gfx950:
+//   (i)  per-token absmax -> fp16 scale, misprediction flag, outlier-column detection + compaction
+//   (ii) fused outlier extraction (dense fp16 side matrix, in-place zeroing) + symmetric int8 / int4 quantise
+// plus the cold weight-column dequantisation used when new outlier columns are appended.
+//
+// These are HBM-bound byte kernels: one 256-thread workgroup per activation row, 16-byte coalesced loads,
+// the row kept in registers between the absmax pass and the quantise pass (one trip over HBM), wave-shuffle +
+// LDS reductions.  They follow the call sites /root/reference/mixquant/modules/linear.py:157-161,187-226 and
+// the conventions fixed in include/mixq_hip.h.
+#include "common.h"
+
+namespace {
+
+constexpr int QT = 256;                 // threads per row workgroup
+
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    return v;
+}
+
+// |x| of 8 packed halves with the outlier columns (bits of m8) forced to zero; returns the masked vector too.
+__device__ __forceinline__ float amax8_masked(uint4& v, uint32_t m8) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (m8 & (1u << (2 * i)))     w[i] &= 0xffff0000u;
+        if (m8 & (1u << (2 * i + 1))) w[i] &= 0x0000ffffu;
+        a = fmaxf(a, fabsf(h2f(static_cast<uint16_t>(w[i] & 0xffffu))));
+        a = fmaxf(a, fabsf(h2f(static_cast<uint16_t>(w[i] >> 16))));
+    }
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+    return a;
+}
+
+template <int BIT>
+__device__ __forceinline__ int quant1(float x, float s) {
+    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
+    float q = (s > 0.f) ? rintf(__fdiv_rn(x, s)) : 0.f;        // IEEE divide, round-half-even
+    q = fminf(fmaxf(q, -QMAX), QMAX);
+    return static_cast<int>(q);
+}
+
+template <int BIT>
+__device__ __forceinline__ void quant_store8(const uint4& v, float s, void* qrow, int chunk) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int qv[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        qv[2 * i]     = quant1<BIT>(h2f(static_cast<uint16_t>(w[i] & 0xffffu)), s);
+        qv[2 * i + 1] = quant1<BIT>(h2f(static_cast<uint16_t>(w[i] >> 16)), s);
+    }
+    if constexpr (BIT == 8) {
+        uint2 o;
+        o.x = (qv[0] & 0xff) | ((qv[1] & 0xff) << 8) | ((qv[2] & 0xff) << 16) | (static_cast<uint32_t>(qv[3] & 0xff) << 24);
+        o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
+        reinterpret_cast<uint2*>(qrow)[chunk] = o;
+    } else {   // nibble pack: low nibble = even column (linear.py:14-18)
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o |= static_cast<uint32_t>((qv[2 * i] & 0xf) | ((qv[2 * i + 1] & 0xf) << 4)) << (8 * i);
+        reinterpret_cast<uint32_t*>(qrow)[chunk] = o;
+    }
+}
+
+// One workgroup per row.  NCH = number of 16-byte chunks each thread keeps in registers (row <= NCH*256*8
+// elements stays on chip between the two passes); NCH == 0 re-reads the row (L2-resident) for any K.
+template <int BIT, int NCH>
+__global__ __launch_bounds__(QT) void quant_rows_kernel(
+    uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
+    uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int ldo,
+    int32_t* __restrict__ flag, int K, float thr_scale)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32 (+1)] column bitmask, then 4 floats
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int mask_words = (K + 31) >> 5;
+    float* red = reinterpret_cast<float*>(smem + mask_words);
+    uint16_t* xr = x + static_cast<size_t>(row) * ldx;
+
+    int n = n_cap;
+    if (n_dev) { int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
+    const bool have_out = (n > 0) && ind != nullptr;
+    if (have_out) {
+        for (int i = tid; i < mask_words; i += QT) smem[i] = 0u;
+        __syncthreads();
+        for (int j = tid; j < n; j += QT) {
+            const int c = ind[j];
+            const uint16_t v = xr[c];
+            if (x_out) x_out[static_cast<size_t>(row) * ldo + j] = v;
+            xr[c] = 0;                                             // reference zeroes the caller's tensor in place
+            atomicOr(&smem[c >> 5], 1u << (c & 31));
+        }
+    }
+    if (x_out) for (int j = (have_out ? n : 0) + tid; j < ldo; j += QT) x_out[static_cast<size_t>(row) * ldo + j] = 0;
+    if (have_out) __syncthreads();
+
+    const int nchunk = K >> 3;
+    const uint4* xv = reinterpret_cast<const uint4*>(xr);
+    uint4 keep[NCH > 0 ? NCH : 1];
+    float amax = 0.f;
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * QT;
+            if (c < nchunk) {
+                uint4 v = xv[c];
+                uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
+                amax = fmaxf(amax, amax8_masked(v, m8));
+                keep[i] = v;
+            }
+        }
+    } else {
+        for (int c = tid; c < nchunk; c += QT) {
+            uint4 v = xv[c];
+            uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
+            amax = fmaxf(amax, amax8_masked(v, m8));
+        }
+    }
+    amax = block_max_256(amax, red);
+    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
+    const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
+    const float s = h2f(sh);
+    if (tid == 0) {
+        x_scale[row] = sh;
+        if (flag && s > thr_scale) atomicOr(flag, 1);
+    }
+    void* qrow = static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1));
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * QT;
+            if (c < nchunk) quant_store8<BIT>(keep[i], s, qrow, c);
+        }
+    } else {
+        for (int c = tid; c < nchunk; c += QT) {
+            uint4 v = xv[c];
+            uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
+            (void)amax8_masked(v, m8);
+            quant_store8<BIT>(v, s, qrow, c);
+        }
+    }
+}
+
+__global__ __launch_bounds__(QT) void extract_kernel(uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind,
+                                                     int n, uint16_t* __restrict__ x_out, int ldo)
+{
+    const int row = blockIdx.x;
+    uint16_t* xr = x + static_cast<size_t>(row) * ldx;
+    uint16_t* orow = x_out + static_cast<size_t>(row) * ldo;
+    for (int j = threadIdx.x; j < ldo; j += QT) {
+        uint16_t v = 0;
+        if (j < n) { const int c = ind[j]; v = xr[c]; xr[c] = 0; }
+        orow[j] = v;
+    }
+}
+
+// Column-wise OR of |x| > thr over a slab of rows; 8 columns (16 bytes) per thread.
+constexpr int DET_ROWS = 16;
+__global__ __launch_bounds__(QT) void detect_cols_kernel(const uint16_t* __restrict__ x, int ldx, int M, int K,
+                                                         float thr, uint8_t* __restrict__ colflags)
+{
+    const int c8 = blockIdx.x * QT + threadIdx.x;
+    if (c8 * 8 >= K) return;
+    const int r0 = blockIdx.y * DET_ROWS;
+    const int r1 = (r0 + DET_ROWS < M) ? r0 + DET_ROWS : M;
+    uint32_t hit = 0;
+    for (int r = r0; r < r1; ++r) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + static_cast<size_t>(r) * ldx + c8 * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (fabsf(h2f(static_cast<uint16_t>(w[i] & 0xffffu))) > thr) hit |= 1u << (2 * i);
+            if (fabsf(h2f(static_cast<uint16_t>(w[i] >> 16))) > thr)     hit |= 1u << (2 * i + 1);
+        }
+    }
+    if (hit) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (hit & (1u << e)) colflags[c8 * 8 + e] = 1;
+    }
+}
+
+// Single workgroup: ascending compaction of the set flags (sorted unique ids, as torch.unique returns).
+constexpr int CT = 1024;
+__global__ __launch_bounds__(CT) void compact_cols_kernel(const uint8_t* __restrict__ colflags, int K,
+                                                          int32_t* __restrict__ ind_out, int32_t* __restrict__ count)
+{
+    __shared__ int part[CT];
+    const int tid = threadIdx.x;
+    const int per = (K + CT - 1) / CT;
+    const int c0 = tid * per, c1 = (c0 + per < K) ? c0 + per : K;
+    int cnt = 0;
+    for (int c = c0; c < c1; ++c) cnt += colflags[c] ? 1 : 0;
+    part[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < CT; off <<= 1) {          // Hillis-Steele inclusive scan
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - cnt;
+    for (int c = c0; c < c1; ++c) if (colflags[c]) ind_out[pos++] = c;
+    if (tid == CT - 1) *count = part[CT - 1];
+}
+
+template <int BIT>
+__global__ __launch_bounds__(QT) void dequant_cols_kernel(const uint8_t* __restrict__ w, const uint16_t* __restrict__ scale_col,
+                                                          const int32_t* __restrict__ ind, int n, uint16_t* __restrict__ out,
+                                                          int N, int K, int ldo)
+{
+    const long long t = static_cast<long long>(blockIdx.x) * QT + threadIdx.x;
+    if (t >= static_cast<long long>(N) * n) return;
+    const int r = static_cast<int>(t / n), j = static_cast<int>(t % n);
+    const int c = ind[j];
+    int v;
+    if constexpr (BIT == 8) {
+        v = static_cast<int8_t>(w[static_cast<size_t>(r) * K + c]);
+    } else {
+        const uint8_t b = w[static_cast<size_t>(r) * (K >> 1) + (c >> 1)];
+        const int nib = (c & 1) ? (b >> 4) : (b & 0xf);
+        v = nib >= 8 ? nib - 16 : nib;
+    }
+    float f = static_cast<float>(v);
+    if (scale_col) f = h2f(f2h(f)) * h2f(scale_col[r]);     // fp16 * fp16 -> one rounding, as torch's half multiply
+    out[static_cast<size_t>(r) * ldo + j] = f2h(f);
+}
+
+template <int BIT>
+int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
+                      uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, hipStream_t st)
+{
+    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + 4) * sizeof(uint32_t);
+    const int nchunk = K >> 3;
+    dim3 g(M), b(QT);
+#define MIXQ_QLAUNCH(NCH) hipLaunchKernelGGL((quant_rows_kernel<BIT, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, K, thr_scale)
+    if      (nchunk <= 2 * QT)  MIXQ_QLAUNCH(2);
+    else if (nchunk <= 4 * QT)  MIXQ_QLAUNCH(4);
+    else if (nchunk <= 8 * QT)  MIXQ_QLAUNCH(8);
+    else if (nchunk <= 16 * QT) MIXQ_QLAUNCH(16);
+    else                        MIXQ_QLAUNCH(0);
+#undef MIXQ_QLAUNCH
+    return mixq_launch_status();
+}
+
+inline float fp16_round(float v) {                    // host: value of fp16(v) as float (RNE), via the device-agnostic type
+    return static_cast<float>(static_cast<_Float16>(v));
+}
+
+}  // namespace
+
+extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q, int M, int K, int ldx, int bit,
+                                   mixq_stream_t stream)
+{
+    if (!x || !x_scale || !q || M < 0 || K <= 0) return MIXQ_EINVAL;
+    if (bit != 8 && bit != 4) return MIXQ_EINVAL;
+    if ((K & 7) || (ldx & 7) || ldx < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
+    if (M == 0) return MIXQ_OK;
+    uint16_t* xm = const_cast<uint16_t*>(x);           // not written: n = 0 and x_out = NULL
+    if (bit == 8) return launch_quant_rows<8>(xm, ldx, nullptr, 0, nullptr, x_scale, q, nullptr, 0, nullptr, M, K, 0.f, mixq_stream(stream));
+    return launch_quant_rows<4>(xm, ldx, nullptr, 0, nullptr, x_scale, q, nullptr, 0, nullptr, M, K, 0.f, mixq_stream(stream));
+}
+
+extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
+                                uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma,
+                                mixq_stream_t stream)
+{
+    if (!x || !x_scale || !q || M < 0 || K <= 0 || n < 0) return MIXQ_EINVAL;
+    if (bit != 8 && bit != 4) return MIXQ_EINVAL;
+    if (n > 0 && (!ind || !x_out || ldo < n)) return MIXQ_EINVAL;
+    if ((K & 7) || (ldx & 7) || ldx < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
+    if (M == 0) return MIXQ_OK;
+    const float qmax = static_cast<float>((1 << (bit - 1)) - 1);
+    // reference: `x_scale.max() > self.sigma / qmax` with sigma an fp16 [1,1] tensor -> fp16(fp16(sigma)/qmax)
+    const float thr = fp16_round(fp16_round(sigma) / qmax);
+    uint16_t* xo = (n > 0) ? x_out : nullptr;
+    if (bit == 8) return launch_quant_rows<8>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, mixq_stream(stream));
+    return launch_quant_rows<4>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, mixq_stream(stream));
+}
+
+extern "C" int mixq_extract_outliers_zero(uint16_t* x, const int32_t* ind, int n, uint16_t* x_out, int M, int K, int ldx,
+                                          int ldo, mixq_stream_t stream)
+{
+    if (!x || !x_out || M < 0 || K <= 0 || n < 0 || (n > 0 && !ind) || ldo < n || ldx < K) return MIXQ_EINVAL;
+    if (M == 0 || ldo == 0) return MIXQ_OK;
+    hipLaunchKernelGGL(extract_kernel, dim3(M), dim3(QT), 0, mixq_stream(stream), x, ldx, ind, n, x_out, ldo);
+    return mixq_launch_status();
+}
+
+extern "C" int mixq_detect_outlier_cols(const uint16_t* x, float sigma, uint8_t* colflags, int32_t* ind_out, int32_t* count,
+                                        int M, int K, int ldx, mixq_stream_t stream)
+{
+    if (!x || !colflags || !ind_out || !count || M < 0 || K <= 0) return MIXQ_EINVAL;
+    if ((K & 7) || (ldx & 7) || ldx < K) return MIXQ_ESHAPE;
+    hipStream_t st = mixq_stream(stream);
+    hipError_t e = hipMemsetAsync(colflags, 0, K, st);
+    if (e != hipSuccess) return static_cast<int>(e);
+    if (M > 0) {
+        dim3 g((K / 8 + QT - 1) / QT, (M + DET_ROWS - 1) / DET_ROWS);
+        hipLaunchKernelGGL(detect_cols_kernel, g, dim3(QT), 0, st, x, ldx, M, K, fp16_round(sigma), colflags);
+        int rc = mixq_launch_status();
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(compact_cols_kernel, dim3(1), dim3(CT), 0, st, colflags, K, ind_out, count);
+    return mixq_launch_status();
+}
+
+extern "C" int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col, const int32_t* ind, int n, uint16_t* out,
+                                        int N, int K, int ldo, int bit, mixq_stream_t stream)
+{
+    if (!w || !out || N < 0 || K <= 0 || n < 0 || (n > 0 && !ind) || ldo < n) return MIXQ_EINVAL;
+    if (bit != 8 && bit != 4) return MIXQ_EINVAL;
+    if (N == 0 || n == 0) return MIXQ_OK;
+    const long long total = static_cast<long long>(N) * n;
+    dim3 g(static_cast<unsigned>((total + QT - 1) / QT));
+    const uint8_t* wb = static_cast<const uint8_t*>(w);
+    if (bit == 8) hipLaunchKernelGGL(dequant_cols_kernel<8>, g, dim3(QT), 0, mixq_stream(stream), wb, scale_col, ind, n, out, N, K, ldo);
+    else          hipLaunchKernelGGL(dequant_cols_kernel<4>, g, dim3(QT), 0, mixq_stream(stream), wb, scale_col, ind, n, out, N, K, ldo);
+    return mixq_launch_status();
+}

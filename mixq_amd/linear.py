@@ -1,0 +1,287 @@
+"""MixLinear_GEMM — MixQ's mixed-precision quantized Linear (W8A8O16 / W4A4O16) for MI355X.
+
+API mirror of /root/reference/mixquant/modules/linear.py (constructor :27-28, from_linear :90-91, forward :165,
+forward_without_preconditionFusedSilu :292, FindOutliers :157, helpers two_compl/pack_to_i4/unpack_int8_to_int4 :12-22;
+buffer names/shapes/dtypes :39-65), so it drops into the reference's Llama modules (`W_pack(x)`, `o_proj(x, None, True)`,
+`up_proj_(x, cache)`, `gate_proj_.forward_without_preconditionFusedSilu(x, cache)`) unchanged.
+
+What is different underneath:
+  * the k2+k1 pre-pass (extract outliers, zero them, row scale, quantise) is ONE kernel that also evaluates the
+    misprediction predicate of linear.py:201 on device;
+  * the cuBLAS outlier GEMM + M x N addend round trip (linear.py:248-256) is fused into the int8 MFMA GEMM as fp16
+    MFMA tail iterations; bias is added in the same epilogue;
+  * outlier detection (torch.unique(torch.where(...)), linear.py:160) is a column-flag kernel + compaction;
+  * from_linear does NOT destroy the caller's `linear.weight` (the reference divides it in place when it is already
+    on the device, linear.py:116-117); the produced q_weight/scale_col are identical.
+All compute goes through `mixq_amd.mixlib` -> libmixq_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import mixlib as _hip_mixlib
+from ._capi import ACT_NONE, ACT_SILU
+
+# The kernel backend.  Always the HIP module in the product; tests that exercise the host-side state machine on a
+# machine without a GPU swap in an oracle-backed stand-in (tests/backend_oracle.py) via `set_backend`.
+_backend = _hip_mixlib
+
+
+def set_backend(mod):
+    global _backend
+    prev = _backend
+    _backend = mod
+    return prev
+
+
+def two_compl(x: Tensor, bits: int) -> Tensor:
+    """Signed -> unsigned two's-complement field of `bits` bits (linear.py:12-13)."""
+    return torch.where(x < 0, x + (1 << bits), x)
+
+
+def pack_to_i4(X: Tensor) -> Tensor:
+    """int8 values in [-8,7], shape [R,K] -> uint8 [R,K/2]; low nibble = even column (linear.py:14-18)."""
+    u = two_compl(X.to(torch.int8), 4).to(torch.uint8)
+    return u[:, 0::2] | (u[:, 1::2] << 4)
+
+
+def unpack_int8_to_int4(weight: Tensor, ind: Tensor) -> Tensor:
+    """Sign-extended int4 weight columns `ind` as fp16 [N,n] (linear.py:20-22)."""
+    assert weight.dim() == 2
+    return _backend.unpack_int4_to_fp16(weight, ind)
+
+
+def _pad16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+class _ColStore:
+    """Growable [rows, cap] fp16 storage whose first n columns are live; row stride stays a multiple of 16 elements
+    so the GEMM's fp16 MFMA tail can read 16-byte fragments (include/mixq_hip.h: ldxo/ldwo)."""
+
+    def __init__(self, rows, device, init: Tensor | None = None):
+        self.rows, self.device = rows, device
+        self.n = 0
+        self.buf = None
+        if init is not None and init.numel():
+            self.append(init)
+
+    def append(self, cols: Tensor):
+        k = cols.shape[1]
+        if k == 0:
+            return
+        need = _pad16(self.n + k)
+        if self.buf is None or self.buf.shape[1] < need:
+            nb = torch.zeros((self.rows, max(need, 32)), dtype=torch.float16, device=self.device)
+            if self.buf is not None and self.n:
+                nb[:, :self.n] = self.buf[:, :self.n]
+            self.buf = nb
+        self.buf[:, self.n:self.n + k] = cols
+        self.n += k
+
+    def view(self):
+        if self.buf is None:
+            return None
+        return self.buf[:, :self.n]
+
+
+def _gemm_ready(t: Tensor | None) -> Tensor | None:
+    """Return `t` (a [R,n] fp16 matrix) in a layout the GEMM tail accepts: row stride >= pad16(n), multiple of 8."""
+    if t is None or t.shape[1] == 0:
+        return None
+    n = t.shape[1]
+    if t.stride(1) == 1 and t.stride(0) >= _pad16(n) and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    buf = torch.zeros((t.shape[0], _pad16(n)), dtype=torch.float16, device=t.device)
+    buf[:, :n] = t
+    return buf[:, :n]
+
+
+class MixLinear_GEMM(nn.Module):
+    def __init__(self, in_features, out_features, bias, dev, bit, weight_only=False, cache=None, fp_features_num=128,
+                 name=None):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.bit = bit
+        if bit not in (4, 8):
+            raise ValueError("MixLinear_GEMM: bit must be 4 or 8")
+
+        if weight_only is False:
+            self.register_buffer("scale_col", torch.empty((1, out_features), dtype=torch.float16, device=dev))
+            if bit == 8:
+                self.ind = torch.zeros((0,), dtype=torch.int32, device=dev)
+                self.register_buffer("q_weight", torch.empty((out_features, in_features), dtype=torch.int8, device=dev))
+                self.weight_cache = None
+            else:
+                self.fp_features_num = fp_features_num
+                self.register_buffer("q_weight", torch.empty((out_features, in_features // 2), dtype=torch.uint8, device=dev))
+                self.register_buffer("weight_cache", torch.empty((out_features, fp_features_num), dtype=torch.float16, device=dev))
+                self.register_buffer("ind", torch.empty((fp_features_num,), dtype=torch.int32, device=dev))
+        else:
+            self.register_buffer("q_weight", torch.empty((in_features, out_features), dtype=torch.int8, device=dev))
+            self.register_buffer("scale_col", torch.empty((out_features,), dtype=torch.float16, device=dev))
+
+        if bias:
+            self.register_buffer("bias", torch.empty((out_features,), dtype=torch.float16, device=dev))
+        else:
+            self.bias = None
+        self.cnt = 0
+        self.forward_without_precondition_len = -1
+        if bit == 4:
+            self.forward_without_precondition_len = fp_features_num
+
+        self.cache = cache
+        self.weight_only = weight_only
+        self.add_outliers = True
+        if cache is not None:
+            self.sigma = torch.ones((1, 1), dtype=torch.float16, device=dev)
+            self.sigma[0] = cache.sigma
+            self._sigma_f = float(cache.sigma.float().cpu().item())
+        self.arch = "gfx950"
+        self.name = name
+        self._wstore = None          # _ColStore behind weight_cache once outliers were appended online
+
+    # ------------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_linear(cls, linear, bit, weight_only=False, init_only=False, cache=None, layer_scales=None, dev="cuda",
+                    name=None, fp_features_num=128):
+        q = cls(linear.in_features, linear.out_features, linear.bias is not None, dev, bit=bit, weight_only=weight_only,
+                cache=cache, name=name, fp_features_num=fp_features_num)
+        if init_only is True:
+            return q
+        if weight_only is True:
+            raise NotImplementedError("weight-only W8A16 (EETQ) layers are outside the hot path (SURVEY.md §8f row 4)")
+
+        W = linear.weight.data.to(dev)                      # a copy when it moves; cloned below before any in-place op
+        N = linear.out_features
+        if bit == 8:
+            # linear.py:113-119: scale = fp16(rowabsmax/127); q = round(W / scale) in W's dtype, cast to int8
+            scale = (torch.max(torch.abs(W), dim=1)[0].unsqueeze(1) / 127).to(torch.float16).reshape((1, N))
+            q.scale_col.copy_(scale)
+            tmp = W.clone()
+            tmp /= q.scale_col.T
+            q.q_weight.copy_(tmp.round().to(torch.int8))
+        else:
+            # linear.py:123-143: keep the `fp_features_num` input channels with the largest activation scale in fp16,
+            # zero them in W, scale = rowabsmax/10, clamp to [-8,7], nibble-pack.
+            assert layer_scales is not None
+            ind = torch.sort(layer_scales)[1][-q.fp_features_num:]
+            linear.ind = ind
+            ind_d = ind.to(dev)
+            q.weight_cache.copy_(W[:, ind_d].to(W.dtype))
+            tmp = W.clone()
+            tmp[:, ind_d] = 0
+            scale = (torch.max(torch.abs(tmp), dim=1)[0].unsqueeze(1) / 10).to(torch.float16).reshape((1, N))
+            q.scale_col.copy_(scale)
+            tmp /= q.scale_col.T
+            tmp = torch.clamp(tmp.round(), -8, 7)
+            q.q_weight.copy_(pack_to_i4(tmp.to(torch.int8).cpu()).to(dev))
+            q.ind.copy_(ind_d.to(torch.int32))
+        if linear.bias is not None:
+            q.bias.copy_(linear.bias.half())
+        return q
+
+    # ------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def FindOutliers(self, Activation):
+        """Sorted distinct column ids with any |x| > sigma, int32 (linear.py:157-161).  One host read of the count."""
+        cache = self.cache
+        scratch = cache.scratch(Activation.shape[1]) if hasattr(cache, "scratch") else None
+        ind_buf, count = _backend.DetectOutlierCols(Activation, self._sigma_f, scratch)
+        n = int(count.item())
+        return ind_buf[:n].clone()
+
+    def _append_outliers(self, cache, inputs, ind):
+        """linear.py:205-221: pull the new columns out of x, dequantise the matching weight columns, append both."""
+        activation_outliers = _backend.ExtractOutliersAndSetToZeros(ind, inputs)
+        weight_cache = _backend.DequantWeightCols(self.q_weight, self.scale_col, ind, self.bit)
+        if self._wstore is None:
+            self._wstore = _ColStore(self.out_features, self.q_weight.device,
+                                     self.weight_cache if (self.weight_cache is not None and self.ind.shape[0]) else None)
+        xs = _ColStore(inputs.shape[0], inputs.device,
+                       cache.activation_outliers if (self.ind.shape[0] and cache.activation_outliers is not None) else None)
+        xs.append(activation_outliers)
+        self._wstore.append(weight_cache)
+        cache.activation_outliers = xs.view() if xs.n else activation_outliers
+        self.weight_cache = self._wstore.view() if self._wstore.n else weight_cache
+        self.ind = torch.hstack((self.ind, ind))
+        cache.ind = self.ind
+
+    def _gemm(self, cache, M, act):
+        n = int(self.ind.shape[0])
+        xo = _gemm_ready(cache.activation_outliers) if n else None
+        wo = _gemm_ready(self.weight_cache) if n else None
+        if n and (xo is None or wo is None or xo.shape[1] != n or wo.shape[1] != n):
+            raise RuntimeError("MixLinear_GEMM: outlier operands do not match `ind`")
+        return _backend.FusedLinear(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, xo, wo, n, self.bias, M,
+                                    self.out_features, self.in_features, bit=self.bit, act=act)
+
+    # ------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, cache=None, unfused=False):
+        if cache is None:
+            cache = self.cache
+        cache.shape = x.shape[:-1] + (self.out_features,)
+        inputs = x.reshape(-1, x.shape[-1])
+        M = inputs.shape[0]
+        if self.weight_only is True:
+            raise NotImplementedError("weight-only W8A16 (EETQ) layers are outside the hot path (SURVEY.md §8f row 4)")
+        qmax = 2 ** (self.bit - 1) - 1
+
+        if unfused:
+            # k2 + k1 of linear.py:187-193 as one pass; the flag is the predicate of linear.py:201
+            n = int(self.ind.shape[0])
+            flag = None
+            if self.add_outliers:
+                flag = cache.flag
+                flag.zero_()
+            cache.q_xcache, xo = _backend.QuantFused(inputs, self.ind if n else None, cache.x_scale, self.bit, self._sigma_f,
+                                                     flag=flag)
+            if n:
+                cache.activation_outliers = xo
+        cache.ind = self.ind
+
+        if self.add_outliers:
+            if unfused:
+                mispredicted = bool(int(cache.flag.item()))
+            else:
+                mispredicted = bool(cache.x_scale[0:M].max() > self.sigma / qmax)
+            if mispredicted:
+                ind = self.FindOutliers(inputs)
+                cache.new_ind = ind
+                self._append_outliers(cache, inputs, ind)
+                cache.q_xcache = _backend.FindRowScale(inputs, cache.x_scale, M, self.in_features, self.bit)
+            self.cnt += 1
+            if self.cnt >= self.cache.stop or self.ind.shape[0] > 128:
+                self.add_outliers = False
+
+        y1 = self._gemm(cache, M, ACT_NONE)
+        return y1.reshape(cache.shape)
+
+    @torch.no_grad()
+    def forward_without_preconditionFusedSilu(self, x, cache):
+        """gate_proj path (linear.py:292-376): reuse the activation quantised for up_proj, SiLU in the epilogue."""
+        inputs = x.reshape(-1, x.shape[-1])
+        M = inputs.shape[0]
+        if not self.forward_without_precondition_len == cache.ind.shape[0]:
+            if cache.ind.shape[0]:
+                ind = cache.new_ind
+                weight_cache = _backend.DequantWeightCols(self.q_weight, self.scale_col, ind, self.bit)
+                if self._wstore is None:
+                    self._wstore = _ColStore(self.out_features, self.q_weight.device,
+                                             self.weight_cache if (self.weight_cache is not None and self.ind.shape[0]) else None)
+                self._wstore.append(weight_cache)
+                self.weight_cache = self._wstore.view() if self._wstore.n else weight_cache
+                self.ind = cache.ind
+                self.forward_without_precondition_len = self.ind.shape[0]
+        if self.bit == 4 and not self.ind.shape[0]:
+            raise RuntimeError("int4 mod should have outliers !")
+        y1 = self._gemm(cache, M, ACT_SILU)
+        return y1.reshape(cache.shape)
+
+
+# north_star name for the same operator
+MixQLinear = MixLinear_GEMM

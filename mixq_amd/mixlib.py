@@ -1,0 +1,236 @@
+"""`mixlib`-compatible operator module backed by the gfx950 HIP kernels.
+
+The reference's hot path calls an un-vendored CUDA extension named `mixlib` (call sites
+/root/reference/mixquant/modules/linear.py:22,189-193,205,221,235-283,321-366).  This module exposes the SAME
+function names with the SAME positional argument orders, so reference-style operator code runs unchanged on an
+MI355X when `sys.modules['mixlib'] = mixq_amd.mixlib`.  Every function allocates its result
+with torch (device memory / stream plumbing only) and forwards raw device pointers to the C ABI of
+libmixq_hip.so (include/mixq_hip.h).  There is no CPU path: CPU tensors raise.
+
+On top of the reference surface it offers the fused entry points the MI355X design adds (QuantFused,
+DetectOutlierCols, DequantWeightCols, FusedLinear), used by mixq_amd.linear.MixLinear_GEMM.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _capi
+from ._capi import ACT_NONE, ACT_SILU
+
+
+def _dev_check(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("mixq_amd.mixlib: expected a GPU (HIP) tensor; there is no CPU fallback")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows(t, what):
+    """(ptr, row stride in elements) of a 2-D tensor whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"mixq_amd.mixlib: {what} must be 2-D with a contiguous last dimension")
+    return t.data_ptr(), t.stride(0)
+
+
+def _is_zero_addend(addend):
+    """The reference passes MixLibCache.zeros (all zero, row stride 36864 != N) when there are no outliers."""
+    return addend is None or getattr(addend, "_mixq_all_zero", False) or (addend.dim() == 2 and addend.stride(0) == 0)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# reference surface
+# ------------------------------------------------------------------------------------------------------------
+def FindRowScale(x, x_scale, M, K, bit=8):
+    """mixlib.FindRowScale(x, x_scale, M, K, bit) -> q_x  (linear.py:190-193).  Writes x_scale[0:M] in place."""
+    _dev_check(x, x_scale)
+    if x.dtype != torch.float16 or x_scale.dtype != torch.float16:
+        raise RuntimeError("FindRowScale: x and x_scale must be float16")
+    x2 = x.reshape(-1, x.shape[-1])
+    xp, ldx = _rows(x2, "x")
+    if x2.shape[0] < M or x2.shape[1] != K or x_scale.numel() < M:
+        raise RuntimeError("FindRowScale: shape mismatch")
+    if bit == 8:
+        q = torch.empty((M, K), dtype=torch.int8, device=x.device)
+    elif bit == 4:
+        q = torch.empty((M, K // 2), dtype=torch.uint8, device=x.device)
+    else:
+        raise RuntimeError("FindRowScale: bit must be 4 or 8")
+    _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, _stream())
+    return q
+
+
+def ExtractOutliersAndSetToZeros(ind, x):
+    """mixlib.ExtractOutliersAndSetToZeros(ind, x) -> x_out [M,n]; zeroes columns `ind` of x IN PLACE (linear.py:189,205)."""
+    _dev_check(ind, x)
+    if x.dtype != torch.float16 or ind.dtype != torch.int32:
+        raise RuntimeError("ExtractOutliersAndSetToZeros: x must be float16 and ind int32")
+    xp, ldx = _rows(x, "x")
+    M, K = x.shape
+    n = ind.numel()
+    out = torch.empty((M, n), dtype=torch.float16, device=x.device)
+    if n:
+        _capi.call("mixq_extract_outliers_zero", xp, ind.contiguous().data_ptr(), n, out.data_ptr(), M, K, ldx, n, _stream())
+    return out
+
+
+def _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, bit, act):
+    _dev_check(q_x, q_w, x_scale, scale_col)
+    y = torch.empty((M, N), dtype=torch.float16, device=q_x.device)
+    if _is_zero_addend(addend):
+        ap, lda = None, 0
+    else:
+        _dev_check(addend)
+        ap, lda = _rows(addend, "addend")
+    fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"
+    _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(),
+               None, 0, None, 0, 0, None, ap, lda, None, y.data_ptr(), N, M, N, K, act, _stream())
+    return y
+
+
+def int8FusedDequantize(q_x, q_w, x_scale, scale_col, addend, M, N, K):
+    """mixlib.int8FusedDequantize (linear.py:251-256, 268-273)."""
+    return _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, 8, ACT_NONE)
+
+
+def int8FusedDequantizeSilu(q_x, q_w, x_scale, scale_col, addend, M, N, K):
+    """mixlib.int8FusedDequantizeSilu (linear.py:337-351)."""
+    return _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, 8, ACT_SILU)
+
+
+def int4FusedDequantize(q_x, q_w, x_scale, scale_col, addend, M, N, K_half):
+    """mixlib.int4FusedDequantize: the last argument is K/2 (linear.py:259-265)."""
+    return _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, 2 * K_half, 4, ACT_NONE)
+
+
+def int4FusedDequantizeSilu(q_x, q_w, x_scale, scale_col, addend, M, N, K_half):
+    """mixlib.int4FusedDequantizeSilu (linear.py:360-366)."""
+    return _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, 2 * K_half, 4, ACT_SILU)
+
+
+def gemm(q_x, q_w, M, N, K):
+    """mixlib.gemm(q_x, q_w, M, N, K) -> int32 [M,N] (linear.py:235)."""
+    _dev_check(q_x, q_w)
+    y = torch.empty((M, N), dtype=torch.int32, device=q_x.device)
+    _capi.call("mixq_gemm_i8", q_x.data_ptr(), q_w.data_ptr(), y.data_ptr(), N, M, N, K, _stream())
+    return y
+
+
+def _dequant(y32, x_scale, scale_col, addend, bit, M, N, act):
+    _dev_check(y32, x_scale, scale_col)
+    y = torch.empty((M, N), dtype=torch.float16, device=y32.device)
+    if _is_zero_addend(addend):
+        ap, lda = None, 0
+    else:
+        ap, lda = _rows(addend, "addend")
+    yp, ldy32 = _rows(y32, "y32")
+    _capi.call("mixq_dequant", yp, ldy32, x_scale.data_ptr(), scale_col.data_ptr(), ap, lda, None, y.data_ptr(), N, M, N,
+               act, _stream())
+    return y
+
+
+def dequantizeInt8(y32, x_scale, scale_col, addend, bit, M, N):
+    """mixlib.dequantizeInt8 (linear.py:238,241)."""
+    return _dequant(y32, x_scale, scale_col, addend, bit, M, N, ACT_NONE)
+
+
+def dequantizeInt8Silu(y32, x_scale, scale_col, addend, bit, M, N):
+    """mixlib.dequantizeInt8Silu (linear.py:324,327)."""
+    return _dequant(y32, x_scale, scale_col, addend, bit, M, N, ACT_SILU)
+
+
+def unpack_int4_to_fp16(q_w, ind):
+    """mixlib.unpack_int4_to_fp16(q_w, ind) -> fp16 [N,n] sign-extended int4 weight columns (linear.py:20-22)."""
+    _dev_check(q_w, ind)
+    N, Kh = q_w.shape
+    n = ind.numel()
+    out = torch.empty((N, n), dtype=torch.float16, device=q_w.device)
+    if n:
+        _capi.call("mixq_dequant_weight_cols", q_w.data_ptr(), None, ind.contiguous().data_ptr(), n, out.data_ptr(), N,
+                   2 * Kh, n, 4, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# MI355X additions (fused forms)
+# ------------------------------------------------------------------------------------------------------------
+def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None):
+    """(i)+(ii) in one pass over X: extract/zero the known outlier columns `ind`, per-row scale into x_scale[0:M],
+    quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n])."""
+    _dev_check(x, x_scale, ind)
+    xp, ldx = _rows(x, "x")
+    M, K = x.shape
+    n = 0 if ind is None else ind.numel()
+    q = torch.empty((M, K if bit == 8 else K // 2), dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
+    if n:
+        if x_out is None:
+            ldo = (n + 15) // 16 * 16
+            x_out = torch.empty((M, ldo), dtype=torch.float16, device=x.device)
+        op, ldo = _rows(x_out, "x_out")
+        ip = ind.data_ptr()
+    else:
+        op, ldo, ip = None, 0, None
+    _capi.call("mixq_quant_fused", xp, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K, ldx,
+               ldo, bit, float(sigma), _stream())
+    return q, (x_out[:, :n] if n else None)
+
+
+def DetectOutlierCols(x, sigma, scratch=None):
+    """Device-side FindOutliers (linear.py:157-161): returns (ind_buf int32 [K], count int32 [1]) on device; the
+    caller reads `count` (a host sync, warm-up only) and slices."""
+    _dev_check(x)
+    xp, ldx = _rows(x, "x")
+    M, K = x.shape
+    if scratch is None:
+        scratch = (torch.empty(K, dtype=torch.uint8, device=x.device),
+                   torch.empty(K, dtype=torch.int32, device=x.device),
+                   torch.zeros(1, dtype=torch.int32, device=x.device))
+    flags, ind_buf, count = scratch
+    _capi.call("mixq_detect_outlier_cols", xp, float(sigma), flags.data_ptr(), ind_buf.data_ptr(), count.data_ptr(), M, K,
+               ldx, _stream())
+    return ind_buf, count
+
+
+def DequantWeightCols(q_w, scale_col, ind, bit, out=None):
+    """`q_weight[:,ind].to(fp16) * scale_col.T` (linear.py:207) / the int4 twin (linear.py:209-210) as one kernel."""
+    _dev_check(q_w, scale_col, ind)
+    N = q_w.shape[0]
+    K = q_w.shape[1] * (1 if bit == 8 else 2)
+    n = ind.numel()
+    if out is None:
+        out = torch.empty((N, n), dtype=torch.float16, device=q_w.device)
+    op, ldo = _rows(out, "out")
+    if n:
+        _capi.call("mixq_dequant_weight_cols", q_w.data_ptr(), scale_col.data_ptr(), ind.contiguous().data_ptr(), n, op, N, K,
+                   ldo, bit, _stream())
+    return out
+
+
+def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K, bit=8, act=ACT_NONE, n_out_dev=None,
+                addend=None, out=None):
+    """(iii)+(iv): int8/int4 MFMA GEMM + dequant + fp16 outlier correction + addend + act + bias -> fp16 [M,N]."""
+    _dev_check(q_x, q_w, x_scale, scale_col)
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=q_x.device)
+    if n_out and x_out is not None and w_out is not None:
+        xop, ldxo = _rows(x_out, "x_out")
+        wop, ldwo = _rows(w_out, "w_out")
+    else:
+        xop = wop = None
+        ldxo = ldwo = 0
+        n_out = 0
+    if _is_zero_addend(addend):
+        ap, lda = None, 0
+    else:
+        ap, lda = _rows(addend, "addend")
+    fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"
+    _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(), xop, ldxo, wop, ldwo, n_out,
+               _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act, _stream())
+    return y

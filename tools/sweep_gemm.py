@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""GPU-side development sweep: every GEMM tile config x a few shapes, checked against a torch fp64 matmul on the
+same GPU (exact for int8 operands) and timed with events on the launch stream.  Not a parity test (those are in
+tests/ against the CPU oracle); this is the tuning loop's measuring stick.  Writes gpurun_out/sweep_gemm.json.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mixq_amd import _capi, mixlib  # noqa: E402
+
+PEAK_TOPS = 5033.0
+
+
+def time_fn(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters  # us
+
+
+def time_graph(fn, iters=50, unroll=10):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(unroll):
+                fn()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters // unroll):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / (iters // unroll * unroll)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="512x11008x4096")
+    ap.add_argument("--cfgs", default="all")
+    ap.add_argument("--bit", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--out", default="gpurun_out/sweep_gemm.json")
+    args = ap.parse_args()
+    dev = "cuda"
+    lib = _capi.load()
+    print(_capi.device_info(), flush=True)
+    names = _capi.gemm_config_names()
+    cfgs = list(range(len(names))) if args.cfgs == "all" else [int(c) for c in args.cfgs.split(",")]
+    results = []
+    for shp in args.shapes.split(","):
+        M, N, K = (int(v) for v in shp.split("x"))
+        g = torch.Generator(device="cpu").manual_seed(0)
+        if args.bit == 8:
+            qx = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(dev)
+            qw = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(dev)
+            ref32 = (qx.double() @ qw.double().T)
+        else:
+            vx = torch.randint(-7, 8, (M, K), generator=g, dtype=torch.int8)
+            vw = torch.randint(-8, 8, (N, K), generator=g, dtype=torch.int8)
+            from mixq_amd.linear import pack_to_i4
+            qx, qw = pack_to_i4(vx).to(dev), pack_to_i4(vw).to(dev)
+            ref32 = (vx.to(dev).double() @ vw.to(dev).double().T)
+        sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
+        sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
+        ref = (ref32 * sx.double() * sw.double())
+        flops = 2.0 * M * N * K
+        for c in cfgs:
+            rc = lib.mixq_gemm_set_config(c)
+            assert rc == 0
+            try:
+                y = mixlib.FusedLinear(qx, qw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit)
+                torch.cuda.synchronize()
+            except Exception as ex:  # config incompatible with the shape
+                print(f"{shp} cfg{c} {names[c]}: {ex}", flush=True)
+                continue
+            err = (y.double() - ref).abs().max().item()
+            rel = err / ref.abs().max().item()
+            out = torch.empty_like(y)
+            us = time_fn(lambda: mixlib.FusedLinear(qx, qw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out), args.iters)
+            usg = time_graph(lambda: mixlib.FusedLinear(qx, qw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out), args.iters)
+            tops = flops / usg / 1e6
+            r = dict(shape=shp, cfg=c, name=names[c], bit=args.bit, max_abs_err=err, rel_err=rel, us_eager=us, us_graph=usg,
+                     tops=tops, frac=tops / PEAK_TOPS)
+            results.append(r)
+            print(f"{shp} cfg{c:2d} {names[c]:24s} err={err:.3e} rel={rel:.2e} eager={us:8.2f}us graph={usg:8.2f}us "
+                  f"{tops:7.1f} TOPS ({100 * tops / PEAK_TOPS:4.1f}%)", flush=True)
+        lib.mixq_gemm_set_config(-1)
+        auto = lib.mixq_gemm_pick_config(M, N, K, args.bit)
+        print(f"{shp}: auto pick = cfg{auto} {names[auto]}", flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(results, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
