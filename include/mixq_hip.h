@@ -41,6 +41,19 @@ extern "C" {
 #define MIXQ_ACT_NONE 0
 #define MIXQ_ACT_SILU 1      /* SiLU on (dequant + outlier + addend), bias added afterwards (linear.py:324-373) */
 
+/* Quantised-operand storage formats.
+ * MIXQ_FMT_PLAIN  : row-major [R, KB] bytes (KB = K for int8, K/2 for nibble-packed int4) - the reference's layout.
+ * MIXQ_FMT_P16X64 : tile-major "P16x64": [KB/64][rows16/16] blocks of 16 rows x 64 bytes (1 KiB each), rows16 =
+ *                   roundup(R,16); inside a block row r (0..15) stores its four 16-byte chunks c at position
+ *                   c ^ ((r>>2)&3).  A block is byte-for-byte the LDS image the GEMM's fragment reads expect, so one
+ *                   LDS-DMA instruction moves one contiguous KiB and a k-step of a tile is one contiguous run
+ *                   (1.7x the operand-feed rate of 64-byte row segments on MI355X).  KB % 64 == 0. */
+#define MIXQ_FMT_PLAIN  0
+#define MIXQ_FMT_P16X64 1
+/* `layout` bits of the GEMM entry points */
+#define MIXQ_X_PACKED 1      /* q_x is MIXQ_FMT_P16X64 */
+#define MIXQ_W_PACKED 2      /* q_w is MIXQ_FMT_P16X64 */
+
 typedef void* mixq_stream_t; /* hipStream_t */
 
 /* Library / device identification.  mixq_version: ABI version (major*1000 + minor). */
@@ -53,9 +66,11 @@ int mixq_device_info(char* buf_host, int cap);
  *   x        fp16 [M,K] row-major, ldx elements between rows (read only)
  *   x_scale  fp16 [M]   written in place (the reference passes its cache.x_scale[inputdim,1] buffer)
  *   q        bit=8: int8 [M,K];  bit=4: uint8 [M,K/2] nibble-packed.  K % 8 == 0 (bit 8) / K % 16 == 0 (bit 4).
+ *   qfmt     MIXQ_FMT_PLAIN, or MIXQ_FMT_P16X64 to emit q directly in the tile-major layout (buffer of
+ *            roundup(M,16) * KB bytes; rows >= M are left untouched).
  */
 int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q,
-                        int M, int K, int ldx, int bit, mixq_stream_t stream);
+                        int M, int K, int ldx, int bit, int qfmt, mixq_stream_t stream);
 
 /* ---- outlier extraction -------------------------------------------------------------------------------
  * Replaces mixlib.ExtractOutliersAndSetToZeros(ind, x) -> x_out   (linear.py:189, :205).
@@ -76,7 +91,7 @@ int mixq_extract_outliers_zero(uint16_t* x, const int32_t* ind, int n, uint16_t*
  */
 int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev,
                      uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
-                     int M, int K, int ldx, int ldo, int bit, float sigma, mixq_stream_t stream);
+                     int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
 
 /* ---- online outlier-column detection ------------------------------------------------------------------
  * Replaces torch.unique(torch.where(abs(X) > sigma)[1]).int32  (linear.py:157-161, FindOutliers).
@@ -105,13 +120,14 @@ int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col, const int
  *   x_out fp16 [M,ldxo], w_out fp16 [N,ldwo]: outlier operands (NULL / n_out = 0 for none);
  *         n_out_dev: optional device int32 overriding n_out (<= n_out); ldxo, ldwo >= roundup(n_out,16), % 8 == 0
  *   addend fp16 [M,lda] or NULL;  bias fp16 [N] or NULL;  y fp16 [M,ldy]
+ *   layout  MIXQ_X_PACKED | MIXQ_W_PACKED bits (0 = both operands plain row-major as in the reference)
  *   K % 64 == 0, N % 4 == 0, ldy % 4 == 0.
  */
 int mixq_gemm_i8_fused(const int8_t* q_x, const int8_t* q_w, const uint16_t* x_scale,
                        const uint16_t* scale_col, const uint16_t* x_out, int ldxo,
                        const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                        const uint16_t* addend, int lda, const uint16_t* bias,
-                       uint16_t* y, int ldy, int M, int N, int K, int act, mixq_stream_t stream);
+                       uint16_t* y, int ldy, int M, int N, int K, int act, int layout, mixq_stream_t stream);
 
 /* Same for nibble-packed operands: replaces mixlib.int4FusedDequantize[Silu](..., M, N, K/2)
  * (linear.py:259-265, 278-283, 360-366).  q_x uint8 [M,K/2], q_w uint8 [N,K/2]; K is the LOGICAL depth
@@ -120,7 +136,12 @@ int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x
                        const uint16_t* scale_col, const uint16_t* x_out, int ldxo,
                        const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                        const uint16_t* addend, int lda, const uint16_t* bias,
-                       uint16_t* y, int ldy, int M, int N, int K, int act, mixq_stream_t stream);
+                       uint16_t* y, int ldy, int M, int N, int K, int act, int layout, mixq_stream_t stream);
+
+/* ---- operand re-tiling ------------------------------------------------------------------------------------
+ * Copy a plain [R,KB] byte matrix (int8 weights, or nibble-packed int4) into MIXQ_FMT_P16X64.
+ * dst holds roundup(R,16) * KB bytes; rows >= R are zero-filled.  KB % 64 == 0.  Done once per weight at load. */
+int mixq_pack_p16x64(const void* src, void* dst, int R, int KB, mixq_stream_t stream);
 
 /* ---- unfused debug pair ---------------------------------------------------------------------------------
  * mixq_gemm_i8 replaces mixlib.gemm(q_x, q_w, M, N, K) -> int32 [M,N]        (linear.py:235,321)

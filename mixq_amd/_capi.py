@@ -19,6 +19,10 @@ MIXQ_ESHAPE = -2
 MIXQ_ENODEV = -3
 ACT_NONE = 0
 ACT_SILU = 1
+FMT_PLAIN = 0
+FMT_P16X64 = 1
+X_PACKED = 1
+W_PACKED = 2
 
 
 class MixqBuildError(RuntimeError):
@@ -41,17 +45,18 @@ _F = C.c_float
 SIGNATURES = {
     "mixq_version": [],
     "mixq_device_info": [C.c_char_p, _I],
-    "mixq_find_row_scale": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "mixq_find_row_scale": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mixq_extract_outliers_zero": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
-    "mixq_quant_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "mixq_quant_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "mixq_detect_outlier_cols": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
     "mixq_dequant_weight_cols": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
-    "mixq_gemm_i8_fused": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
-    "mixq_gemm_i4_fused": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mixq_gemm_i8_fused": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mixq_gemm_i4_fused": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mixq_gemm_i8": [_P, _P, _P, _I, _I, _I, _I, _P],
     "mixq_dequant": [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "mixq_gemm_set_config": [_I],
     "mixq_gemm_num_configs": [],
+    "mixq_pack_p16x64": [_P, _P, _I, _I, _P],
     "mixq_gemm_config_name": [_I, C.c_char_p, _I],
     "mixq_gemm_pick_config": [_I, _I, _I, _I],
 }

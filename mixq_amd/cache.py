@@ -29,6 +29,7 @@ class MixLibCache:
         self.shape = None
         self.activation_outliers = None
         self.q_xcache = None
+        self.q_xcache_packed = False         # q_xcache is in the P16x64 layout (set by whoever fills it)
         self.is_prefill = False
         self.bit = bit
         self.max_outliers = 256

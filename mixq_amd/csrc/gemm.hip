@@ -1,27 +1,38 @@
 // (iii)+(iv): int8 x int8 -> int32 MFMA GEMM for gfx950 with the MixQ epilogue fused in.
 //
-//   Y[m,n] = fp16( (sum_k Xq[m,k] Wq[n,k]) * sx[m] * sw[n]  +  sum_j Xo[m,j] Wo[n,j]  + addend[m,n] ) -> act -> + bias[n]
+//   Y[m,n] = fp16( act( (sum_k Xq[m,k] Wq[n,k]) * sx[m] * sw[n]  +  sum_j Xo[m,j] Wo[n,j]  + addend[m,n] ) + bias[n] )
 //
-// Design (MI355X-first):
-//  * both operands are K-contiguous ("TN"); tiles are streamed HBM/L2 -> LDS with 16-byte LDS-DMA
-//    (global_load_lds_dwordx4, no VGPR round trip) into an NSTAGE-deep ring; ONE raw s_barrier per k-step and a
-//    counted s_waitcnt vmcnt(N) keep NSTAGE-2 k-steps of loads in flight across the barrier.
-//  * LDS rows are BKB bytes; the 16-byte chunk index is XOR-swizzled with row bits so the ds_read_b128 fragment
-//    reads of a 16-lane group hit 16 distinct 16-byte bank slots (swizzle applied on the DMA *source* address and
-//    on the read address, the LDS image itself is lane-linear as LDS-DMA requires).
+// Design (MI355X-first; every choice below was measured on an MI355X, numbers in DESIGN.md §6):
+//  * Operands are K-contiguous.  A k-step moves a (BN + BM) x 64-byte slab HBM/L2 -> LDS with 16-byte LDS-DMA
+//    (global_load_lds_dwordx4, no VGPR round trip) into an NSTAGE-deep ring.  The per-CU feed rate, not HBM, is
+//    what limits this shape: 64-byte row segments of a plain [N,K] matrix stream at ~54 GB/s per CU, contiguous
+//    KiB pieces at ~90-104 GB/s.  So the fast path takes operands in the tile-major "P16x64" layout
+//    (include/mixq_hip.h) whose 16-row x 64-byte blocks ARE the LDS image; plain row-major operands (the
+//    reference's layout) are still accepted, with the XOR swizzle applied on the DMA source address instead.
+//  * LDS rows are 64 bytes; the 16-byte chunk index is XOR-ed with ((row>>2)&3) so the ds_read_b128 fragment reads
+//    of every 16-lane group hit 16 distinct bank slots (SQ_LDS_BANK_CONFLICT = 0 measured).
+//  * Wave specialisation: LOADERS dedicated wave(s) do nothing but issue the DMA and publish stages
+//    (counted s_waitcnt vmcnt + the k-step's single s_barrier); the WAVES_M x WAVES_N consumer waves only read
+//    fragments and issue MFMAs.  With the DMA issued from the MFMA waves the two costs ADD (an LDS-DMA issue
+//    blocks its wave while the texture addresser is busy, and the MFMAs queued behind it wait): 418 ns per k-step
+//    against 247 ns MFMA-only and 230 ns DMA-only.  LOADERS = 0 keeps that self-issuing form for comparison.
 //  * v_mfma_i32_32x32x32_i8 with the WEIGHT rows as the A operand and the ACTIVATION rows as the B operand, so a
-//    lane ends up holding 4 consecutive output columns n of one token m: the epilogue needs one x_scale per lane,
-//    and stores 8-byte (4 x fp16) pieces of a Y row.
-//  * the outlier correction runs as fp16 MFMA tail iterations (v_mfma_f32_32x32x16_f16) on the SAME accumulator
+//    lane ends up holding 4 consecutive output columns n of one token m (one x_scale per lane).  Fragment sets
+//    are double-buffered in registers: the reads of sub-step s+1 are issued between the MFMAs of sub-step s.
+//  * The outlier correction runs as fp16 MFMA tail iterations (v_mfma_f32_32x32x16_f16) on the SAME accumulator
 //    registers after they were dequantised to fp32 in place - no M x N side matrix is ever materialised
 //    (the reference writes and re-reads one: linear.py:248-256).  The outlier count may live in device memory.
+//  * Epilogue through LDS: the fp16 tile is staged in the (now idle) ring and written as whole 16-byte-per-lane
+//    row segments; the direct per-lane 8-byte stores touched 32 rows per instruction and cost 5 us of a 30 us
+//    kernel.
 //  * W4A4: CDNA4 has no int4 MFMA; nibbles are expanded in registers to int8 values 16*v (a shift and a mask per
 //    dword), the factor 256 is removed exactly in the fp32 epilogue.
-//  * the grid is 1-D over output tiles with an XCD-aware remap: the tiles that share a weight panel run on the
+//  * The grid is 1-D over output tiles with an XCD-aware remap: the tiles that share a weight panel run on the
 //    same XCD (same L2).  The tile shape is picked per problem so the tile count fills the 256 CUs.
 #include "common.h"
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -36,7 +47,11 @@ struct GemmArgs {
     int ldxo, ldwo, n_out, lda, ldy;
     int act;
     int tiles_m, tiles_n;
+    int x_packed, w_packed;                           // operand stored in the P16x64 tile-major layout
+    int xrows16, wrows16;                             // rows rounded up to 16 (packed operands)
 };
+
+constexpr int BKB = 64;                               // bytes of K per stage and row
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
@@ -47,33 +62,36 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// physical 16-byte chunk of logical chunk c in row r (involution in c for fixed r)
-template <int BKB> __device__ __forceinline__ int swz(int r, int c) {
-    if constexpr (BKB == 64) return c ^ ((r >> 2) & 3);
-    else                     return c ^ ((r >> 1) & 7);      // BKB == 128
-}
+// physical 16-byte chunk of logical chunk c in row r (an involution in c for fixed r)
+__device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 2) & 3); }
 
 __device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
 
-// BM: activation rows per tile, BN: weight rows per tile, BKB: bytes of K per stage and row, WAVES_M x WAVES_N waves,
-// NSTAGE ring depth.  MODE 0: int8 fused epilogue, 1: int4 fused epilogue, 2: int8 raw int32 output.
-template <int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int NSTAGE, int MODE>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const GemmArgs a)
+// BM: activation rows per tile, BN: weight rows per tile, WAVES_M x WAVES_N consumer waves, NSTAGE ring depth,
+// MODE 0: int8 fused epilogue, 1: int4 fused epilogue, 2: int8 raw int32 output.  LOADERS: dedicated DMA waves
+// (0 = the consumer waves issue the DMA themselves).  ABL (tuning only): 0 normal, 1 DMA only, 2 no DMA,
+// 3 MFMA only, 5 no epilogue stores.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, int LOADERS, int ABL>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kernel(const GemmArgs a)
 {
-    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int CW = WAVES_M * WAVES_N;              // consumer waves
+    constexpr int NT = (CW + LOADERS) * 64;
     constexpr int CH = BKB / 16;                       // 16-byte chunks per row
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int TI = (BM + BN) * CH / 64;              // 1-KiB wave-instructions per stage (weight rows, then activation rows)
-    constexpr int LOADS_LO = TI / NW, EXTRA = TI % NW;   // waves < EXTRA issue one more
-    constexpr int LOADS_HI = LOADS_LO + (EXTRA ? 1 : 0);
+    constexpr int TI = (BM + BN) * CH / 64;            // 1-KiB DMA pieces per stage (weight rows, then activation rows)
+    constexpr int IW = LOADERS ? LOADERS : CW;         // waves that issue DMA
+    constexpr int LOADS = (TI + IW - 1) / IW;          // pieces per issuing wave and stage (a short wave repeats a piece)
     constexpr int STAGE_BYTES = (BM + BN) * BKB;
-    static_assert((BM + BN) * CH % 64 == 0, "stage must be a whole number of 1-KiB DMA pieces");
-    static_assert(BM % 16 == 0 && BN % 16 == 0, "swizzle phase must agree between the two operand regions");
-    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
-    static_assert(LOADS_HI * (NSTAGE - 2) < 64, "vmcnt range");
+    constexpr int LOOK = NSTAGE - 2;                   // stages in flight ahead of the one being computed
+    constexpr int NEWER = LOOK - 1;                    // stages younger than the one a wait retires
     constexpr bool I4 = (MODE == 1);
+    constexpr int OPITCH = BN * 2 + 16;                // bytes per row of the fp16 output staging tile
+    static_assert((BM + BN) * CH % 64 == 0, "stage must be a whole number of 1-KiB DMA pieces");
+    static_assert(BM % 16 == 0 && BN % 16 == 0, "tiles are made of 16-row blocks");
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+    static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
+    static_assert(MODE == 2 || BM * OPITCH <= NSTAGE * STAGE_BYTES, "output staging tile must fit in the ring");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
@@ -89,36 +107,87 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
-    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
-
-    // ---- per-thread DMA source pointers (row clamped so ragged tiles never read out of bounds) -------------
-    const uint8_t* src[LOADS_HI];
-#pragma unroll
-    for (int i = 0; i < LOADS_HI; ++i) {
-        int qd = (i * NW + wave) * 64 + lane;
-        if (qd >= (BM + BN) * CH) qd = (BM + BN) * CH - 1;             // only for waves >= EXTRA in the last slot (never issued)
-        const int rr = qd / CH, pc = qd % CH;
-        if (rr < BN) {
-            int gr = n0 + rr; gr = gr < a.N ? gr : a.N - 1;
-            src[i] = a.qw + static_cast<size_t>(gr) * a.KB + swz<BKB>(rr, pc) * 16;
-        } else {
-            const int r = rr - BN;
-            int gr = m0 + r; gr = gr < a.M ? gr : a.M - 1;
-            src[i] = a.qx + static_cast<size_t>(gr) * a.KB + swz<BKB>(r, pc) * 16;
-        }
-    }
-    const bool extra_wave = (EXTRA > 0) && (wave < EXTRA);
     const int nk = a.KB / BKB;
 
-    auto stage = [&](int buf, int kt) {
-        uint8_t* base = lds + buf * STAGE_BYTES + wave * 1024;
-        const int koff = kt * BKB;
+    // ---- DMA piece table of an issuing wave ------------------------------------------------------------------
+    // Plain [R,KB] operands: a 1-KiB piece is 16 rows x 64 B with the XOR swizzle on the SOURCE chunk.
+    // Packed P16x64 operands: the memory image of a 16-row block IS the (swizzled) LDS image: a piece is one
+    // contiguous KiB, a stage is one contiguous run per operand, and the k-step stride is rows16 * 64.
+    const uint8_t* nsrc[LOADS];                          // source of the NEXT stage to issue, advanced per stage
+    int kstr[LOADS];
+    int piece[LOADS];
+    auto dma_setup = [&](int iw) {                       // iw: index of this wave among the issuing waves
 #pragma unroll
-        for (int i = 0; i < LOADS_LO; ++i) glds16(src[i] + koff, base + i * NW * 1024);
-        if constexpr (EXTRA > 0) {
-            if (extra_wave) glds16(src[LOADS_LO] + koff, base + LOADS_LO * NW * 1024);
+        for (int i = 0; i < LOADS; ++i) {
+            int pw = i * IW + iw;
+            if (pw >= TI) pw = iw;                       // benign duplicate of this wave's first piece
+            piece[i] = pw;
+            const int qd = pw * 64 + lane;
+            const int rr = qd / CH, pc = qd % CH;
+            const bool is_w = rr < BN;
+            const int r = is_w ? rr : rr - BN;
+            const int row0 = is_w ? n0 : m0, rows = is_w ? a.N : a.M, rows16 = is_w ? a.wrows16 : a.xrows16;
+            const uint8_t* base = is_w ? a.qw : a.qx;
+            const bool packed = is_w ? a.w_packed : a.x_packed;
+            if (packed) {
+                int rb = (row0 + r) >> 4; rb = rb < (rows16 >> 4) ? rb : (rows16 >> 4) - 1;
+                nsrc[i] = base + static_cast<size_t>(rb) * 1024 + (r & 15) * 64 + pc * 16;
+                kstr[i] = rows16 * 64;
+            } else {
+                int gr = row0 + r; gr = gr < rows ? gr : rows - 1;
+                nsrc[i] = base + static_cast<size_t>(gr) * a.KB + swz(r, pc) * 16;
+                kstr[i] = BKB;
+            }
         }
     };
+    auto stage = [&](int buf) {                          // issue the next stage into ring slot `buf`
+        uint8_t* base = lds + buf * STAGE_BYTES;
+        if constexpr (ABL != 2 && ABL != 3) {
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) { glds16(nsrc[i], base + piece[i] * 1024); nsrc[i] += kstr[i]; }
+        }
+    };
+
+    // =================================================================================================================
+    // loader wave(s): issue stage kt+LOOK, retire stage kt+1, meet the consumers at the k-step's barrier
+    // =================================================================================================================
+    if constexpr (LOADERS > 0) {
+        if (wave >= CW) {
+            __builtin_amdgcn_s_setprio(2);               // the DMA issue must never queue behind MFMA waves
+            dma_setup(wave - CW);
+#pragma unroll
+            for (int s = 0; s < LOOK; ++s)
+                if (s < nk) stage(s);
+            if (NEWER < nk) wait_vmcnt<LOADS * NEWER>(); else wait_vmcnt<0>();       // stage 0 landed
+            __builtin_amdgcn_s_barrier();
+            int nxt = LOOK % NSTAGE, kt = 0;
+            for (; kt + LOOK < nk; ++kt) {               // steady state: branch-free body
+                stage(nxt);
+                wait_vmcnt<LOADS * NEWER>();             // stage kt+1 landed, NEWER younger stages still in flight
+                __builtin_amdgcn_s_barrier();
+                nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+            }
+            for (; kt + 1 < nk; ++kt) {                  // drain
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (MODE != 2) {                   // take part in the epilogue's two barriers and its stores
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+
+    // =================================================================================================================
+    // consumer waves
+    // =================================================================================================================
+    const int wn = wave % WAVES_N, wm = (wave / WAVES_N) % WAVES_M;
+    const int lr = lane & 31, lh = lane >> 5;
+    int wrow[NI], xrow[MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wrow[i] = wn * WN + i * 32 + lr;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) xrow[j] = wm * WM + j * 32 + lr;
 
     i32x16 acc[NI][MI];
 #pragma unroll
@@ -128,41 +197,48 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-    // fragment row offsets inside a stage (bytes), constant over k
-    const int lr = lane & 31, lh = lane >> 5;
-    int wrow[NI], xrow[MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) wrow[i] = wn * WN + i * 32 + lr;
-#pragma unroll
-    for (int j = 0; j < MI; ++j) xrow[j] = wm * WM + j * 32 + lr;
+    if (LOADERS == 0 || wave < CW) {
+        if constexpr (LOADERS == 0) dma_setup(wave);
 
-    auto compute = [&](int buf) {
-        const uint8_t* wb = lds + buf * STAGE_BYTES;
-        const uint8_t* xb = wb + BN * BKB;
+        // Fragment sets are double-buffered in registers: set p holds the operands of one 32-byte sub-step.
+        i32x4 wf[2][NI], xf[2][MI];
+        if constexpr (ABL != 0 && ABL != 5) {           // ablation builds: give never-loaded sets defined, opaque values
 #pragma unroll
-        for (int s = 0; s < BKB / 32; ++s) {
-            i32x4 wf[NI], xf[MI];
+            for (int p = 0; p < 2; ++p) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-                wf[i] = *reinterpret_cast<const i32x4*>(wb + wrow[i] * BKB + swz<BKB>(wrow[i], s * 2 + lh) * 16);
+                for (int i = 0; i < NI; ++i) { wf[p][i] = i32x4{lane, lane, lane, lane}; asm volatile("" : "+v"(wf[p][i])); }
 #pragma unroll
-            for (int j = 0; j < MI; ++j)
-                xf[j] = *reinterpret_cast<const i32x4*>(xb + xrow[j] * BKB + swz<BKB>(xrow[j], s * 2 + lh) * 16);
-            if constexpr (!I4) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < MI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < MI; ++j) { xf[p][j] = i32x4{lane, 1, lane, 1}; asm volatile("" : "+v"(xf[p][j])); }
+            }
+        }
+        // One fragment read, in the order the MFMAs of a sub-step consume them: w0, x0..x(MI-1), w1..w(NI-1).
+        auto load_one = [&](int p, int buf, int sb, int idx) {
+            const uint8_t* wb = lds + buf * STAGE_BYTES;
+            const uint8_t* xb = wb + BN * BKB;
+            if (idx == 0 || idx > MI) {
+                const int i = idx == 0 ? 0 : idx - MI;
+                wf[p][i] = *reinterpret_cast<const i32x4*>(wb + wrow[i] * BKB + swz(wrow[i], sb * 2 + lh) * 16);
             } else {
-                // 16 packed bytes = 32 int4: even columns (low nibbles) and odd columns (high nibbles) become two
-                // int8 fragments holding 16*v; A and B use the same split so the k pairing is preserved.
-                i32x4 wl[NI], wh[NI], xl[MI], xh[MI];
+                const int j = idx - 1;
+                xf[p][j] = *reinterpret_cast<const i32x4*>(xb + xrow[j] * BKB + swz(xrow[j], sb * 2 + lh) * 16);
+            }
+        };
+        // One region = the MFMAs of fragment set P with (a) ND_ reads of the other set and (b) NG_ DMA pieces issued
+        // in the gaps behind the MFMAs, in exactly this program order (sched_barrier(0) pins it): an MFMA keeps the
+        // matrix pipe busy for 32 cycles while the wave issues the next LDS reads (and DMA pieces when LOADERS = 0).
+        auto region = [&](auto p_c, auto nd_c, auto ng_c, int rbuf, int rsub, int dma_buf) {
+            constexpr int P = decltype(p_c)::value, ND_ = decltype(nd_c)::value, NG_ = decltype(ng_c)::value;
+            constexpr int NM = NI * MI, SL = NM > 1 ? NM - 1 : 1;
+            uint8_t* dbase = lds + dma_buf * STAGE_BYTES;
+            i32x4 wl[NI], wh[NI], xl[MI], xh[MI];
+            if constexpr (I4) {
+                // 16 packed bytes = 32 int4: even columns (low nibbles) and odd columns (high nibbles) become two int8
+                // fragments holding 16*v; A and B use the same split so the k pairing is preserved.
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const uint32_t v = static_cast<uint32_t>(wf[i][d]);
+                        const uint32_t v = static_cast<uint32_t>(wf[P][i][d]);
                         wl[i][d] = static_cast<int>((v << 4) & 0xf0f0f0f0u);
                         wh[i][d] = static_cast<int>(v & 0xf0f0f0f0u);
                     }
@@ -170,44 +246,88 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
                 for (int j = 0; j < MI; ++j)
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const uint32_t v = static_cast<uint32_t>(xf[j][d]);
+                        const uint32_t v = static_cast<uint32_t>(xf[P][j][d]);
                         xl[j][d] = static_cast<int>((v << 4) & 0xf0f0f0f0u);
                         xh[j][d] = static_cast<int>(v & 0xf0f0f0f0u);
                     }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) {
+            for (int m = 0; m < NM; ++m) {
+                const int i = m / MI, j = m % MI;
+                if constexpr (ABL != 1) {
+                    if constexpr (!I4) {
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[P][i], xf[P][j], acc[i][j], 0, 0, 0);
+                    } else {
                         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wl[i], xl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh[i], xh[j], acc[i][j], 0, 0, 0);
                     }
-            }
-        }
-    };
-
-    // ---- main loop: NSTAGE-1 stages in flight, one barrier per k-step --------------------------------------
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < SL) {
+                    if constexpr (ABL != 2 && ABL != 3 && NG_ > 0) {
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) stage(s, s);
-    for (int kt = 0; kt < nk; ++kt) {
-        // loads issued after stage kt: min(NSTAGE-2, nk-1-kt) stages
-        if (kt + NSTAGE - 2 < nk) {
-            if constexpr (EXTRA > 0) {
-                if (extra_wave) wait_vmcnt<LOADS_HI * (NSTAGE - 2)>();
-                else            wait_vmcnt<LOADS_LO * (NSTAGE - 2)>();
-            } else {
-                wait_vmcnt<LOADS_LO * (NSTAGE - 2)>();
+                        for (int g = (NG_ * m) / SL; g < (NG_ * (m + 1)) / SL; ++g) { glds16(nsrc[g], dbase + piece[g] * 1024); nsrc[g] += kstr[g]; }
+                    }
+                    if constexpr (ABL != 1 && ABL != 3) {
+#pragma unroll
+                        for (int d = (ND_ * m) / SL; d < (ND_ * (m + 1)) / SL; ++d) load_one(1 - P, rbuf, rsub, d);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        } else {
-            wait_vmcnt<0>();
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using IND = std::integral_constant<int, NI + MI>;
+        using ING = std::integral_constant<int, LOADERS ? 0 : LOADS>;
+
+        // ---- software-pipelined k loop -------------------------------------------------------------------------
+        // LOOK stages in flight.  The DMA of stage kt+LOOK goes into the ring slot last read in iteration kt-2 (every
+        // wave finished those reads before the barrier of iteration kt-1), so it needs no barrier of its own.  The
+        // single barrier of a k-step sits in front of the first fragment read of the NEXT stage, between two MFMA groups.
+        if constexpr (LOADERS == 0) {
+#pragma unroll
+            for (int s = 0; s < LOOK; ++s)
+                if (s < nk) stage(s);
+            if (NEWER < nk) wait_vmcnt<LOADS * NEWER>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
-        compute(kt % NSTAGE);
+        if constexpr (ABL != 1 && ABL != 3) {
+#pragma unroll
+            for (int d = 0; d < NI + MI; ++d) load_one(0, 0, 0, d);
+        }
+        int cur = 0, nxt = LOOK % NSTAGE;                // ring slots of stage kt and stage kt+LOOK
+        // one k-step; ISSUE: DMA stage kt+LOOK from this wave, NEXT: a stage kt+1 exists.
+        auto body = [&](auto issue_c, auto next_c) {
+            constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value;
+            const int cur1 = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+            if constexpr (ISSUE) region(I0{}, IND{}, ING{}, cur, 1, nxt);     // MFMA(set 0), read set 1, DMA
+            else                 region(I0{}, IND{}, I0{}, cur, 1, nxt);
+            if constexpr (NEXT) {
+                if constexpr (LOADERS == 0) {
+                    if constexpr (ISSUE) wait_vmcnt<LOADS * NEWER>();
+                    else                 wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                region(I1{}, IND{}, I0{}, cur1, 0, nxt);                       // MFMA(set 1), first reads of stage kt+1
+            } else {
+                region(I1{}, I0{}, I0{}, cur1, 0, nxt);
+            }
+            cur = cur1;
+            nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+        };
+        int kt = 0;
+        if constexpr (LOADERS == 0) {
+            for (; kt + LOOK < nk; ++kt) body(std::true_type{}, std::true_type{});
+        }
+        for (; kt + 1 < nk; ++kt) body(std::false_type{}, std::true_type{});
+        body(std::false_type{}, std::false_type{});
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------
     if constexpr (MODE == 2) {
+        if (wave >= CW) return;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -230,97 +350,117 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_kernel(const Gemm
             }
         return;
     } else {
-        int n_out = a.n_out;
-        if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out = nd < n_out ? nd : n_out; }
-        if (!a.xo || !a.wo) n_out = 0;
-        const int ksteps = (n_out + 15) >> 4;
-        constexpr float PRE = I4 ? (1.f / 256.f) : 1.f;
+        // Rows of Y are written from an fp16 staging tile in LDS when whole 16-byte chunks are addressable.
+        const bool staged = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+        if (LOADERS == 0 || wave < CW) {
+            int n_out = a.n_out;
+            if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out = nd < n_out ? nd : n_out; }
+            if (!a.xo || !a.wo) n_out = 0;
+            const int ksteps = (n_out + 15) >> 4;
+            constexpr float PRE = I4 ? (1.f / 256.f) : 1.f;
 
-        float sxv[MI];
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const int m = m0 + xrow[j];
-            sxv[j] = (m < a.M) ? h2f(a.sx[m]) * PRE : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int nb = n0 + wn * WN + i * 32 + 4 * lh;
-            // 16 weight scales this lane needs: n = nb + 8g + e
-            float swv[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nb + 8 * g;
-                if (n + 3 < a.N) {
-                    const u32x2 p = *reinterpret_cast<const u32x2*>(a.sw + n);
-                    swv[4 * g]     = h2f(static_cast<uint16_t>(p.x & 0xffffu));
-                    swv[4 * g + 1] = h2f(static_cast<uint16_t>(p.x >> 16));
-                    swv[4 * g + 2] = h2f(static_cast<uint16_t>(p.y & 0xffffu));
-                    swv[4 * g + 3] = h2f(static_cast<uint16_t>(p.y >> 16));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) swv[4 * g + e] = (n + e < a.N) ? h2f(a.sw[n + e]) : 0.f;
-                }
-            }
+            float sxv[MI];
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                f32x16 f;
+                const int m = m0 + xrow[j];
+                sxv[j] = (m < a.M) ? h2f(a.sx[m]) * PRE : 0.f;
+            }
+            if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // every wave is done reading the ring
 #pragma unroll
-                for (int r = 0; r < 16; ++r) f[r] = static_cast<float>(acc[i][j][r]) * sxv[j] * swv[r];
-
-                // fp16 outlier tail on the same accumulator registers
-                if (ksteps > 0) {
-                    int wr = n0 + wrow[i]; wr = wr < a.N ? wr : a.N - 1;
-                    int xr = m0 + xrow[j]; xr = xr < a.M ? xr : a.M - 1;
-                    const uint16_t* wp = a.wo + static_cast<size_t>(wr) * a.ldwo + lh * 8;
-                    const uint16_t* xp = a.xo + static_cast<size_t>(xr) * a.ldxo + lh * 8;
-                    for (int kk = 0; kk < ksteps; ++kk) {
-                        u32x4 wq = *reinterpret_cast<const u32x4*>(wp + kk * 16);
-                        u32x4 xq = *reinterpret_cast<const u32x4*>(xp + kk * 16);
-                        const int kb = kk * 16 + lh * 8;               // mask columns >= n_out (pad may hold anything)
-                        if (kb + 8 > n_out) {
+            for (int i = 0; i < NI; ++i) {
+                const int nloc = wn * WN + i * 32 + 4 * lh;
+                const int nb = n0 + nloc;
+                float swv[16];                                                  // the 16 weight scales of this lane
 #pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                uint32_t keep = 0;
-                                if (kb + 2 * d < n_out)     keep |= 0x0000ffffu;
-                                if (kb + 2 * d + 1 < n_out) keep |= 0xffff0000u;
-                                wq[d] &= keep; xq[d] &= keep;
-                            }
-                        }
-                        f = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq), __builtin_bit_cast(f16x8, xq), f, 0, 0, 0);
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nb + 8 * g;
+                    if (n + 3 < a.N) {
+                        const u32x2 p = *reinterpret_cast<const u32x2*>(a.sw + n);
+                        swv[4 * g]     = h2f(static_cast<uint16_t>(p.x & 0xffffu));
+                        swv[4 * g + 1] = h2f(static_cast<uint16_t>(p.x >> 16));
+                        swv[4 * g + 2] = h2f(static_cast<uint16_t>(p.y & 0xffffu));
+                        swv[4 * g + 3] = h2f(static_cast<uint16_t>(p.y >> 16));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) swv[4 * g + e] = (n + e < a.N) ? h2f(a.sw[n + e]) : 0.f;
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < MI; ++j) {
+                    f32x16 f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) f[r] = static_cast<float>(acc[i][j][r]) * sxv[j] * swv[r];
 
-                const int m = m0 + xrow[j];
-                if (m < a.M) {
+                    if (ksteps > 0) {                    // fp16 outlier tail on the same accumulator registers
+                        int wr = n0 + wrow[i]; wr = wr < a.N ? wr : a.N - 1;
+                        int xr = m0 + xrow[j]; xr = xr < a.M ? xr : a.M - 1;
+                        const uint16_t* wp = a.wo + static_cast<size_t>(wr) * a.ldwo + lh * 8;
+                        const uint16_t* xp = a.xo + static_cast<size_t>(xr) * a.ldxo + lh * 8;
+                        for (int kk = 0; kk < ksteps; ++kk) {
+                            u32x4 wq = *reinterpret_cast<const u32x4*>(wp + kk * 16);
+                            u32x4 xq = *reinterpret_cast<const u32x4*>(xp + kk * 16);
+                            const int kb = kk * 16 + lh * 8;           // mask columns >= n_out (pad may hold anything)
+                            if (kb + 8 > n_out) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = nb + 8 * g;
-                        float v[4] = {f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]};
-                        const bool full = (n + 3 < a.N);
-                        if (a.addend) {
-                            const uint16_t* ap = a.addend + static_cast<size_t>(m) * a.lda + n;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (full || n + e < a.N) v[e] += h2f(ap[e]);
+                                for (int d = 0; d < 4; ++d) {
+                                    uint32_t keep = 0;
+                                    if (kb + 2 * d < n_out)     keep |= 0x0000ffffu;
+                                    if (kb + 2 * d + 1 < n_out) keep |= 0xffff0000u;
+                                    wq[d] &= keep; xq[d] &= keep;
+                                }
+                            }
+                            f = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq), __builtin_bit_cast(f16x8, xq), f, 0, 0, 0);
                         }
-                        if (a.act == MIXQ_ACT_SILU) {
+                    }
+
+                    const int m = m0 + xrow[j];
+                    if (m < a.M && (ABL != 5 || a.act == 77)) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
-                        }
-                        if (a.bias) {
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = nb + 8 * g;
+                            float v[4] = {f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]};
+                            const bool full = (n + 3 < a.N);
+                            if (a.addend) {
+                                const uint16_t* ap = a.addend + static_cast<size_t>(m) * a.lda + n;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) if (full || n + e < a.N) v[e] += h2f(a.bias[n + e]);
-                        }
-                        uint16_t* yp = a.y + static_cast<size_t>(m) * a.ldy + n;
-                        if (full) {
+                                for (int e = 0; e < 4; ++e) if (full || n + e < a.N) v[e] += h2f(ap[e]);
+                            }
+                            if (a.act == MIXQ_ACT_SILU) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+                            }
+                            if (a.bias) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) if (full || n + e < a.N) v[e] += h2f(a.bias[n + e]);
+                            }
                             u32x2 o;
                             o.x = static_cast<uint32_t>(f2h(v[0])) | (static_cast<uint32_t>(f2h(v[1])) << 16);
                             o.y = static_cast<uint32_t>(f2h(v[2])) | (static_cast<uint32_t>(f2h(v[3])) << 16);
-                            *reinterpret_cast<u32x2*>(yp) = o;
-                        } else {
+                            if (staged) {
+                                *reinterpret_cast<u32x2*>(lds + xrow[j] * OPITCH + (nloc + 8 * g) * 2) = o;
+                            } else {
+                                uint16_t* yp = a.y + static_cast<size_t>(m) * a.ldy + n;
+                                if (full) *reinterpret_cast<u32x2*>(yp) = o;
+                                else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) if (n + e < a.N) yp[e] = f2h(v[e]);
+                                    for (int e = 0; e < 4; ++e) if (n + e < a.N) yp[e] = f2h(v[e]);
+                                }
+                            }
                         }
                     }
+                }
+            }
+            if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // staging tile complete
+        }
+        if (staged) {
+            // all waves (loader included): 16 bytes per lane, 16 consecutive lanes cover a 256-byte row segment
+            constexpr int CPR = BN * 2 / 16;                                   // 16-byte chunks per tile row
+            for (int q = tid; q < BM * CPR; q += NT) {
+                const int r = q / CPR, c = q - r * CPR;
+                const int m = m0 + r, n = n0 + c * 8;
+                if (m < a.M && n < a.N && (ABL != 5 || a.act == 77)) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * OPITCH + c * 16);
+                    *reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n) = v;
                 }
             }
         }
@@ -346,72 +486,77 @@ __global__ __launch_bounds__(256) void dequant_kernel(const int32_t* __restrict_
 // ---- configuration table ---------------------------------------------------------------------------------------
 struct GemmConfig {
     const char* name;
-    int bm, bn, bkb, waves, nstage;
+    int bm, bn, waves, nstage;
     void (*k8)(const GemmArgs);
     void (*k4)(const GemmArgs);
     void (*k32)(const GemmArgs);
 };
 
-#define MIXQ_CFG(BM, BN, BKB, WMv, WNv, NS)                                                                   \
-    { #BM "x" #BN "x" #BKB "_w" #WMv "x" #WNv "_s" #NS, BM, BN, BKB, (WMv) * (WNv), NS,                     \
-      gemm_kernel<BM, BN, BKB, WMv, WNv, NS, 0>, gemm_kernel<BM, BN, BKB, WMv, WNv, NS, 1>,                 \
-      gemm_kernel<BM, BN, BKB, WMv, WNv, NS, 2> }
+#define MIXQ_CFG(BM, BN, WMv, WNv, NS, LD)                                                                    \
+    { #BM "x" #BN "_w" #WMv "x" #WNv "_s" #NS "_l" #LD, BM, BN, (WMv) * (WNv) + (LD), NS,                   \
+      gemm_kernel<BM, BN, WMv, WNv, NS, 0, LD, 0>, gemm_kernel<BM, BN, WMv, WNv, NS, 1, LD, 0>,             \
+      gemm_kernel<BM, BN, WMv, WNv, NS, 2, LD, 0> }
+#define MIXQ_ABL(BM, BN, WMv, WNv, NS, LD, ABL)                                                               \
+    { #BM "x" #BN "_w" #WMv "x" #WNv "_s" #NS "_l" #LD "_abl" #ABL, BM, BN, (WMv) * (WNv) + (LD), NS,       \
+      gemm_kernel<BM, BN, WMv, WNv, NS, 0, LD, ABL>, gemm_kernel<BM, BN, WMv, WNv, NS, 0, LD, ABL>,         \
+      gemm_kernel<BM, BN, WMv, WNv, NS, 2, LD, ABL> }
 
 const GemmConfig g_cfgs[] = {
-    MIXQ_CFG(256, 128, 64, 4, 2, 3),     // 0: 8 waves, 64x64 wave tile
-    MIXQ_CFG(256, 128, 64, 2, 2, 3),     // 1: 4 waves, 128x64 wave tile
-    MIXQ_CFG(256, 128, 128, 4, 2, 3),    // 2
-    MIXQ_CFG(128, 128, 64, 2, 2, 3),     // 3
-    MIXQ_CFG(128, 128, 64, 2, 2, 4),     // 4
-    MIXQ_CFG(128, 128, 128, 2, 2, 3),    // 5
-    MIXQ_CFG(256, 96, 64, 4, 1, 3),      // 6: 4 waves 64(M) x 96(N)
-    MIXQ_CFG(256, 96, 64, 8, 1, 3),      // 7: 8 waves 32 x 96
-    MIXQ_CFG(128, 192, 64, 2, 2, 3),     // 8: 4 waves 64 x 96
-    MIXQ_CFG(128, 192, 64, 4, 2, 3),     // 9: 8 waves 32 x 96
-    MIXQ_CFG(128, 64, 64, 2, 2, 4),      // 10
-    MIXQ_CFG(64, 64, 64, 2, 2, 4),       // 11
-    MIXQ_CFG(32, 128, 64, 1, 4, 4),      // 12: small-M
-    MIXQ_CFG(256, 256, 64, 4, 2, 3),     // 13: 8 waves 64(M) x 128(N)
-    MIXQ_CFG(256, 128, 64, 4, 2, 4),     // 14
-    MIXQ_CFG(256, 128, 128, 2, 2, 3),    // 15
+    MIXQ_CFG(256, 128, 4, 2, 5, 1),     // 0: 8 consumer waves (64x64) + 1 loader
+    MIXQ_CFG(256, 128, 4, 2, 5, 0),     // 1: same tile, consumers issue the DMA themselves
+    MIXQ_CFG(256, 128, 2, 2, 5, 1),     // 2: 4 consumer waves (128x64) + 1 loader
+    MIXQ_CFG(256, 128, 2, 2, 5, 4),     // 3: 4 consumers (128x64) + 4 loaders
+    MIXQ_CFG(256, 128, 4, 2, 5, 2),     // 4: 8 consumers + 2 loaders
+    MIXQ_CFG(256, 128, 2, 2, 5, 2),     // 5: 4 consumers + 2 loaders
+    MIXQ_CFG(256, 128, 4, 2, 5, 4),     // 6: 8 consumers + 4 loaders
+    MIXQ_CFG(256, 128, 2, 2, 5, 0),     // 7: 4 consumers self-issuing
+    MIXQ_CFG(128, 192, 2, 2, 5, 2),     // 8: 4 consumers 64 x 96 + 2 loaders
+    MIXQ_CFG(128, 192, 2, 2, 5, 4),     // 9
+    MIXQ_CFG(128, 128, 2, 2, 5, 2),     // 10
+    MIXQ_CFG(64, 64, 2, 2, 5, 1),       // 11
+    MIXQ_CFG(32, 128, 1, 4, 5, 1),      // 12: small-M
+    MIXQ_CFG(256, 256, 4, 2, 5, 0),     // 13: 8 consumers 64(M) x 128(N) self-issuing
+    MIXQ_CFG(128, 256, 2, 2, 5, 2),     // 14: 4 consumers 64 x 128 + 2 loaders
+    MIXQ_CFG(128, 256, 2, 2, 5, 4),     // 15
+    MIXQ_ABL(256, 128, 2, 2, 5, 4, 1),  // 16: cfg 3, DMA only
+    MIXQ_ABL(256, 128, 2, 2, 5, 4, 2),  // 17: cfg 3, no DMA
+    MIXQ_ABL(256, 128, 2, 2, 5, 4, 3),  // 18: cfg 3, MFMA only
+    MIXQ_ABL(256, 128, 2, 2, 5, 4, 5),  // 19: cfg 3, no epilogue stores
 };
 constexpr int NUM_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
+constexpr int NUM_PICK = 16;                       // configs the automatic choice may use (the rest are ablations)
 
 int g_forced_cfg = -1;
 bool g_attr_done[NUM_CFGS][3];
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Shape-aware choice: estimated time ~ rounds over 256 CUs x per-tile work (MFMA-bound) with a small penalty for
-// narrow tiles (less operand reuse -> more L2 traffic) and for padding waste.
-int pick_config(int M, int N, int KB) {
+// Shape-aware choice: estimated time ~ rounds over 256 CUs x max(MFMA time, feed time) per k-step of a tile.
+//   MFMA: BM*BN*64*2 ops at 8192 ops/clk/CU;  feed: (BM+BN)*64 bytes at ~48 B/clk/CU (packed) / 25 (plain rows).
+int pick_config(int M, int N, int KB, bool packed) {
+    (void)KB;
     double best = 1e30; int bi = 0;
-    for (int c = 0; c < NUM_CFGS; ++c) {
+    for (int c = 0; c < NUM_PICK; ++c) {
         const GemmConfig& g = g_cfgs[c];
-        if (KB % g.bkb) continue;
+        if (g_cfgs[c].k8 == g_cfgs[1].k8) continue;       // the self-issuing form is kept for comparison only
         const int tiles = cdiv(M, g.bm) * cdiv(N, g.bn);
         const int rounds = cdiv(tiles, 256);
-        const double tile_work = static_cast<double>(g.bm) * g.bn;                 // MFMA time per k-step
-        const double feed = 4096.0 * (1.0 / g.bm + 1.0 / g.bn);                    // L2->LDS bytes/clk at peak
-        const double eff = feed > 40.0 ? 40.0 / feed : 1.0;
-        const double t = rounds * tile_work / eff;
+        const double mfma = static_cast<double>(g.bm) * g.bn * 128.0 / 8192.0;
+        const double feed = static_cast<double>(g.bm + g.bn) * 64.0 / (packed ? 48.0 : 25.0);
+        const double t = rounds * ((mfma > feed ? mfma : feed) + 60.0);
         if (t < best * 0.999) { best = t; bi = c; }
     }
     return bi;
 }
 
 int launch_gemm(GemmArgs& a, int mode, hipStream_t st) {
-    int c = g_forced_cfg >= 0 ? g_forced_cfg : pick_config(a.M, a.N, a.KB);
+    const bool packed = a.x_packed && a.w_packed;
+    const int c = g_forced_cfg >= 0 ? g_forced_cfg : pick_config(a.M, a.N, a.KB, packed);
     const GemmConfig* g = &g_cfgs[c];
-    if (a.KB % g->bkb) {                                     // forced config incompatible with K: fall back to auto
-        c = pick_config(a.M, a.N, a.KB);
-        g = &g_cfgs[c];
-        if (a.KB % g->bkb) return MIXQ_ESHAPE;
-    }
     a.tiles_m = cdiv(a.M, g->bm);
     a.tiles_n = cdiv(a.N, g->bn);
     void (*k)(const GemmArgs) = mode == 0 ? g->k8 : (mode == 1 ? g->k4 : g->k32);
-    const size_t shm = static_cast<size_t>(g->bm + g->bn) * g->bkb * g->nstage;
+    const size_t shm = static_cast<size_t>(g->bm + g->bn) * BKB * g->nstage;
     if (!g_attr_done[c][mode]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            static_cast<int>(shm));
@@ -425,8 +570,9 @@ int launch_gemm(GemmArgs& a, int mode, hipStream_t st) {
 int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                       const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                       const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int K,
-                      int act, int bit, mixq_stream_t stream)
+                      int act, int layout, int bit, mixq_stream_t stream)
 {
+    if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED)) return MIXQ_EINVAL;
     if (!q_x || !q_w || !x_scale || !scale_col || !y || M < 0 || N < 0 || K <= 0 || n_out < 0) return MIXQ_EINVAL;
     if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU) return MIXQ_EINVAL;
     const int KB = bit == 8 ? K : K / 2;
@@ -443,6 +589,8 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     a.sx = x_scale; a.sw = scale_col; a.xo = x_out; a.wo = w_out; a.n_out_dev = n_out_dev;
     a.addend = addend; a.bias = bias; a.y = y;
     a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
+    a.x_packed = (layout & MIXQ_X_PACKED) ? 1 : 0; a.w_packed = (layout & MIXQ_W_PACKED) ? 1 : 0;
+    a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
     return launch_gemm(a, bit == 8 ? 0 : 1, mixq_stream(stream));
 }
 
@@ -451,19 +599,19 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
 extern "C" int mixq_gemm_i8_fused(const int8_t* q_x, const int8_t* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                                   const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out,
                                   const int32_t* n_out_dev, const uint16_t* addend, int lda, const uint16_t* bias,
-                                  uint16_t* y, int ldy, int M, int N, int K, int act, mixq_stream_t stream)
+                                  uint16_t* y, int ldy, int M, int N, int K, int act, int layout, mixq_stream_t stream)
 {
     return gemm_fused_common(q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
-                             ldy, M, N, K, act, 8, stream);
+                             ldy, M, N, K, act, layout, 8, stream);
 }
 
 extern "C" int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                                   const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out,
                                   const int32_t* n_out_dev, const uint16_t* addend, int lda, const uint16_t* bias,
-                                  uint16_t* y, int ldy, int M, int N, int K, int act, mixq_stream_t stream)
+                                  uint16_t* y, int ldy, int M, int N, int K, int act, int layout, mixq_stream_t stream)
 {
     return gemm_fused_common(q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
-                             ldy, M, N, K, act, 4, stream);
+                             ldy, M, N, K, act, layout, 4, stream);
 }
 
 extern "C" int mixq_gemm_i8(const int8_t* q_x, const int8_t* q_w, int32_t* y32, int ldy, int M, int N, int K,
@@ -476,6 +624,7 @@ extern "C" int mixq_gemm_i8(const int8_t* q_x, const int8_t* q_w, int32_t* y32, 
     memset(&a, 0, sizeof(a));
     a.qx = reinterpret_cast<const uint8_t*>(q_x); a.qw = reinterpret_cast<const uint8_t*>(q_w);
     a.y32 = y32; a.M = M; a.N = N; a.KB = K; a.ldy = ldy;
+    a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
     return launch_gemm(a, 2, mixq_stream(stream));
 }
 
@@ -505,7 +654,7 @@ extern "C" int mixq_gemm_config_name(int cfg, char* buf, int cap) {
 }
 extern "C" int mixq_gemm_pick_config(int M, int N, int K, int bit) {
     if (M <= 0 || N <= 0 || K <= 0 || (bit != 4 && bit != 8)) return MIXQ_EINVAL;
-    return pick_config(M, N, bit == 8 ? K : K / 2);
+    return pick_config(M, N, bit == 8 ? K : K / 2, true);
 }
 
 extern "C" int mixq_version(void) { return 1000; }

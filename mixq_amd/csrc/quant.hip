@@ -45,8 +45,16 @@ __device__ __forceinline__ int quant1(float x, float s) {
     return static_cast<int>(q);
 }
 
+// Byte address of byte `kb` of row `row` in the P16x64 tile-major layout (pack.hip): [KB/64][rows16/16] blocks of
+// 16 rows x 64 bytes whose 16-byte chunks are XOR-swizzled exactly like the GEMM's LDS image.
+__device__ __forceinline__ size_t p16x64_offset(int row, int kb, int rows16) {
+    const int r = row & 15, c = (kb & 63) >> 4;
+    return (static_cast<size_t>(kb >> 6) * (rows16 >> 4) + (row >> 4)) * 1024 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + (kb & 15);
+}
+
+// q: plain -> row base pointer, packed -> matrix base pointer
 template <int BIT>
-__device__ __forceinline__ void quant_store8(const uint4& v, float s, void* qrow, int chunk) {
+__device__ __forceinline__ void quant_store8(const uint4& v, float s, void* q, int chunk, int row, int rows16) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     int qv[8];
 #pragma unroll
@@ -58,13 +66,15 @@ __device__ __forceinline__ void quant_store8(const uint4& v, float s, void* qrow
         uint2 o;
         o.x = (qv[0] & 0xff) | ((qv[1] & 0xff) << 8) | ((qv[2] & 0xff) << 16) | (static_cast<uint32_t>(qv[3] & 0xff) << 24);
         o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
-        reinterpret_cast<uint2*>(qrow)[chunk] = o;
+        if (rows16) *reinterpret_cast<uint2*>(static_cast<char*>(q) + p16x64_offset(row, chunk * 8, rows16)) = o;
+        else        reinterpret_cast<uint2*>(q)[chunk] = o;
     } else {   // nibble pack: low nibble = even column (linear.py:14-18)
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             o |= static_cast<uint32_t>((qv[2 * i] & 0xf) | ((qv[2 * i + 1] & 0xf) << 4)) << (8 * i);
-        reinterpret_cast<uint32_t*>(qrow)[chunk] = o;
+        if (rows16) *reinterpret_cast<uint32_t*>(static_cast<char*>(q) + p16x64_offset(row, chunk * 4, rows16)) = o;
+        else        reinterpret_cast<uint32_t*>(q)[chunk] = o;
     }
 }
 
@@ -74,7 +84,7 @@ template <int BIT, int NCH>
 __global__ __launch_bounds__(QT) void quant_rows_kernel(
     uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
     uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int ldo,
-    int32_t* __restrict__ flag, int K, float thr_scale)
+    int32_t* __restrict__ flag, int K, float thr_scale, int rows16)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32 (+1)] column bitmask, then 4 floats
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -129,19 +139,19 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
     }
-    void* qrow = static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1));
+    void* qrow = rows16 ? q : static_cast<void*>(static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1)));
     if constexpr (NCH > 0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * QT;
-            if (c < nchunk) quant_store8<BIT>(keep[i], s, qrow, c);
+            if (c < nchunk) quant_store8<BIT>(keep[i], s, qrow, c, row, rows16);
         }
     } else {
         for (int c = tid; c < nchunk; c += QT) {
             uint4 v = xv[c];
             uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
             (void)amax8_masked(v, m8);
-            quant_store8<BIT>(v, s, qrow, c);
+            quant_store8<BIT>(v, s, qrow, c, row, rows16);
         }
     }
 }
@@ -230,14 +240,31 @@ __global__ __launch_bounds__(QT) void dequant_cols_kernel(const uint8_t* __restr
     out[static_cast<size_t>(r) * ldo + j] = f2h(f);
 }
 
+// Re-tile a plain [R,KB] byte matrix into P16x64; one 16-byte chunk per thread, rows >= R are zero-filled.
+__global__ __launch_bounds__(QT) void pack_p16x64_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R,
+                                                         int KB, int rows16)
+{
+    const long long t = static_cast<long long>(blockIdx.x) * QT + threadIdx.x;
+    const long long total = static_cast<long long>(rows16) * (KB >> 4);
+    if (t >= total) return;
+    const int per_kb = rows16 * 4;
+    const int kb = static_cast<int>(t / per_kb), rem = static_cast<int>(t % per_kb);
+    const int rb = rem >> 6, r = (rem >> 2) & 15, pc = rem & 3;
+    const int row = rb * 16 + r, c = pc ^ ((r >> 2) & 3);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < R) v = *reinterpret_cast<const uint4*>(src + static_cast<size_t>(row) * KB + kb * 64 + c * 16);
+    reinterpret_cast<uint4*>(dst)[t] = v;
+}
+
 template <int BIT>
 int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
-                      uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, hipStream_t st)
+                      uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st)
 {
     const size_t shm = (static_cast<size_t>((K + 31) >> 5) + 4) * sizeof(uint32_t);
     const int nchunk = K >> 3;
+    const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g(M), b(QT);
-#define MIXQ_QLAUNCH(NCH) hipLaunchKernelGGL((quant_rows_kernel<BIT, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, K, thr_scale)
+#define MIXQ_QLAUNCH(NCH) hipLaunchKernelGGL((quant_rows_kernel<BIT, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, K, thr_scale, rows16)
     if      (nchunk <= 2 * QT)  MIXQ_QLAUNCH(2);
     else if (nchunk <= 4 * QT)  MIXQ_QLAUNCH(4);
     else if (nchunk <= 8 * QT)  MIXQ_QLAUNCH(8);
@@ -253,22 +280,26 @@ inline float fp16_round(float v) {                    // host: value of fp16(v) 
 
 }  // namespace
 
-extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q, int M, int K, int ldx, int bit,
+extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q, int M, int K, int ldx, int bit, int qfmt,
                                    mixq_stream_t stream)
 {
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64) return MIXQ_EINVAL;
+    if (qfmt == MIXQ_FMT_P16X64 && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (!x || !x_scale || !q || M < 0 || K <= 0) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
     if ((K & 7) || (ldx & 7) || ldx < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
     if (M == 0) return MIXQ_OK;
     uint16_t* xm = const_cast<uint16_t*>(x);           // not written: n = 0 and x_out = NULL
-    if (bit == 8) return launch_quant_rows<8>(xm, ldx, nullptr, 0, nullptr, x_scale, q, nullptr, 0, nullptr, M, K, 0.f, mixq_stream(stream));
-    return launch_quant_rows<4>(xm, ldx, nullptr, 0, nullptr, x_scale, q, nullptr, 0, nullptr, M, K, 0.f, mixq_stream(stream));
+    if (bit == 8) return launch_quant_rows<8>(xm, ldx, nullptr, 0, nullptr, x_scale, q, nullptr, 0, nullptr, M, K, 0.f, qfmt, mixq_stream(stream));
+    return launch_quant_rows<4>(xm, ldx, nullptr, 0, nullptr, x_scale, q, nullptr, 0, nullptr, M, K, 0.f, qfmt, mixq_stream(stream));
 }
 
 extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
-                                uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma,
+                                uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt,
                                 mixq_stream_t stream)
 {
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64) return MIXQ_EINVAL;
+    if (qfmt == MIXQ_FMT_P16X64 && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (!x || !x_scale || !q || M < 0 || K <= 0 || n < 0) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
     if (n > 0 && (!ind || !x_out || ldo < n)) return MIXQ_EINVAL;
@@ -278,8 +309,8 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
     // reference: `x_scale.max() > self.sigma / qmax` with sigma an fp16 [1,1] tensor -> fp16(fp16(sigma)/qmax)
     const float thr = fp16_round(fp16_round(sigma) / qmax);
     uint16_t* xo = (n > 0) ? x_out : nullptr;
-    if (bit == 8) return launch_quant_rows<8>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, mixq_stream(stream));
-    return launch_quant_rows<4>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, mixq_stream(stream));
+    if (bit == 8) return launch_quant_rows<8>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream));
+    return launch_quant_rows<4>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream));
 }
 
 extern "C" int mixq_extract_outliers_zero(uint16_t* x, const int32_t* ind, int n, uint16_t* x_out, int M, int K, int ldx,
@@ -320,5 +351,17 @@ extern "C" int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col
     const uint8_t* wb = static_cast<const uint8_t*>(w);
     if (bit == 8) hipLaunchKernelGGL(dequant_cols_kernel<8>, g, dim3(QT), 0, mixq_stream(stream), wb, scale_col, ind, n, out, N, K, ldo);
     else          hipLaunchKernelGGL(dequant_cols_kernel<4>, g, dim3(QT), 0, mixq_stream(stream), wb, scale_col, ind, n, out, N, K, ldo);
+    return mixq_launch_status();
+}
+
+extern "C" int mixq_pack_p16x64(const void* src, void* dst, int R, int KB, mixq_stream_t stream)
+{
+    if (!src || !dst || R < 0 || KB <= 0) return MIXQ_EINVAL;
+    if (KB % 64) return MIXQ_ESHAPE;
+    if (R == 0) return MIXQ_OK;
+    const int rows16 = (R + 15) & ~15;
+    const long long total = static_cast<long long>(rows16) * (KB >> 4);
+    hipLaunchKernelGGL(pack_p16x64_kernel, dim3(static_cast<unsigned>((total + QT - 1) / QT)), dim3(QT), 0, mixq_stream(stream),
+                       static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), R, KB, rows16);
     return mixq_launch_status();
 }

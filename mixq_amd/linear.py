@@ -143,6 +143,8 @@ class MixLinear_GEMM(nn.Module):
         self.arch = "gfx950"
         self.name = name
         self._wstore = None          # _ColStore behind weight_cache once outliers were appended online
+        self._wpk = None             # q_weight re-tiled to P16x64 (built once, on the first forward)
+        self._wpk_key = None
 
     # ------------------------------------------------------------------------------------------------------
     @classmethod
@@ -210,14 +212,28 @@ class MixLinear_GEMM(nn.Module):
         self.ind = torch.hstack((self.ind, ind))
         cache.ind = self.ind
 
+    def _packed_weight(self):
+        """q_weight in the tile-major P16x64 layout the GEMM's DMA streams fastest (include/mixq_hip.h); rebuilt
+        when the buffer is replaced or rewritten (checkpoint load)."""
+        qw = self.q_weight
+        if qw.shape[1] % 64:
+            return None
+        key = (qw.data_ptr(), qw._version)
+        if self._wpk is None or self._wpk_key != key:
+            self._wpk = _backend.PackP16x64(qw) if hasattr(_backend, "PackP16x64") else None
+            self._wpk_key = key
+        return self._wpk
+
     def _gemm(self, cache, M, act):
         n = int(self.ind.shape[0])
         xo = _gemm_ready(cache.activation_outliers) if n else None
         wo = _gemm_ready(self.weight_cache) if n else None
         if n and (xo is None or wo is None or xo.shape[1] != n or wo.shape[1] != n):
             raise RuntimeError("MixLinear_GEMM: outlier operands do not match `ind`")
-        return _backend.FusedLinear(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, xo, wo, n, self.bias, M,
-                                    self.out_features, self.in_features, bit=self.bit, act=act)
+        wpk = self._packed_weight()
+        return _backend.FusedLinear(cache.q_xcache, wpk if wpk is not None else self.q_weight, cache.x_scale, self.scale_col,
+                                    xo, wo, n, self.bias, M, self.out_features, self.in_features, bit=self.bit, act=act,
+                                    x_packed=bool(getattr(cache, "q_xcache_packed", False)), w_packed=wpk is not None)
 
     # ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -238,8 +254,10 @@ class MixLinear_GEMM(nn.Module):
             if self.add_outliers:
                 flag = cache.flag
                 flag.zero_()
+            packed = self._packed_weight() is not None
             cache.q_xcache, xo = _backend.QuantFused(inputs, self.ind if n else None, cache.x_scale, self.bit, self._sigma_f,
-                                                     flag=flag)
+                                                     flag=flag, packed=packed)
+            cache.q_xcache_packed = packed
             if n:
                 cache.activation_outliers = xo
         cache.ind = self.ind
@@ -253,7 +271,12 @@ class MixLinear_GEMM(nn.Module):
                 ind = self.FindOutliers(inputs)
                 cache.new_ind = ind
                 self._append_outliers(cache, inputs, ind)
-                cache.q_xcache = _backend.FindRowScale(inputs, cache.x_scale, M, self.in_features, self.bit)
+                if self._packed_weight() is not None:
+                    cache.q_xcache = _backend.FindRowScalePacked(inputs, cache.x_scale, M, self.in_features, self.bit)
+                    cache.q_xcache_packed = True
+                else:
+                    cache.q_xcache = _backend.FindRowScale(inputs, cache.x_scale, M, self.in_features, self.bit)
+                    cache.q_xcache_packed = False
             self.cnt += 1
             if self.cnt >= self.cache.stop or self.ind.shape[0] > 128:
                 self.add_outliers = False

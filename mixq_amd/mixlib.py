@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import _capi
-from ._capi import ACT_NONE, ACT_SILU
+from ._capi import ACT_NONE, ACT_SILU, FMT_PLAIN, FMT_P16X64, X_PACKED, W_PACKED
 
 
 def _dev_check(*ts):
@@ -64,7 +64,7 @@ def FindRowScale(x, x_scale, M, K, bit=8):
         q = torch.empty((M, K // 2), dtype=torch.uint8, device=x.device)
     else:
         raise RuntimeError("FindRowScale: bit must be 4 or 8")
-    _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, _stream())
+    _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, FMT_PLAIN, _stream())
     return q
 
 
@@ -92,7 +92,7 @@ def _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, bit, act):
         ap, lda = _rows(addend, "addend")
     fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"
     _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(),
-               None, 0, None, 0, 0, None, ap, lda, None, y.data_ptr(), N, M, N, K, act, _stream())
+               None, 0, None, 0, 0, None, ap, lda, None, y.data_ptr(), N, M, N, K, act, 0, _stream())
     return y
 
 
@@ -162,14 +162,32 @@ def unpack_int4_to_fp16(q_w, ind):
 # ------------------------------------------------------------------------------------------------------------
 # MI355X additions (fused forms)
 # ------------------------------------------------------------------------------------------------------------
-def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None):
+def packed_rows(rows):
+    return (rows + 15) // 16 * 16
+
+
+def PackP16x64(q):
+    """Re-tile a plain [R,KB] int8/uint8 operand into the P16x64 tile-major layout (include/mixq_hip.h).  Returns a
+    [roundup(R,16), KB] tensor of the same dtype holding the packed bytes (NOT addressable as a matrix)."""
+    _dev_check(q)
+    if q.dim() != 2 or not q.is_contiguous() or q.element_size() != 1:
+        raise RuntimeError("PackP16x64: expected a contiguous 2-D int8/uint8 tensor")
+    R, KB = q.shape
+    out = torch.empty((packed_rows(R), KB), dtype=q.dtype, device=q.device)
+    _capi.call("mixq_pack_p16x64", q.data_ptr(), out.data_ptr(), R, KB, _stream())
+    return out
+
+
+def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, packed=False):
     """(i)+(ii) in one pass over X: extract/zero the known outlier columns `ind`, per-row scale into x_scale[0:M],
-    quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n])."""
+    quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n]).  With packed=True q_x is
+    emitted directly in the P16x64 layout ([roundup(M,16), KB] bytes)."""
     _dev_check(x, x_scale, ind)
     xp, ldx = _rows(x, "x")
     M, K = x.shape
     n = 0 if ind is None else ind.numel()
-    q = torch.empty((M, K if bit == 8 else K // 2), dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
+    q = torch.empty((packed_rows(M) if packed else M, K if bit == 8 else K // 2),
+                    dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
     if n:
         if x_out is None:
             ldo = (n + 15) // 16 * 16
@@ -179,8 +197,17 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None):
     else:
         op, ldo, ip = None, 0, None
     _capi.call("mixq_quant_fused", xp, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K, ldx,
-               ldo, bit, float(sigma), _stream())
+               ldo, bit, float(sigma), FMT_P16X64 if packed else FMT_PLAIN, _stream())
     return q, (x_out[:, :n] if n else None)
+
+
+def FindRowScalePacked(x, x_scale, M, K, bit=8):
+    """FindRowScale emitting the P16x64 layout."""
+    _dev_check(x, x_scale)
+    xp, ldx = _rows(x, "x")
+    q = torch.empty((packed_rows(M), K if bit == 8 else K // 2), dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
+    _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, FMT_P16X64, _stream())
+    return q
 
 
 def DetectOutlierCols(x, sigma, scratch=None):
@@ -215,7 +242,7 @@ def DequantWeightCols(q_w, scale_col, ind, bit, out=None):
 
 
 def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K, bit=8, act=ACT_NONE, n_out_dev=None,
-                addend=None, out=None):
+                addend=None, out=None, x_packed=False, w_packed=False):
     """(iii)+(iv): int8/int4 MFMA GEMM + dequant + fp16 outlier correction + addend + act + bias -> fp16 [M,N]."""
     _dev_check(q_x, q_w, x_scale, scale_col)
     y = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=q_x.device)
@@ -232,5 +259,6 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
         ap, lda = _rows(addend, "addend")
     fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"
     _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(), xop, ldxo, wop, ldwo, n_out,
-               _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act, _stream())
+               _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act,
+               (X_PACKED if x_packed else 0) | (W_PACKED if w_packed else 0), _stream())
     return y

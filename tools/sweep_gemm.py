@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--cfgs", default="all")
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--packed", default="0,1")
     ap.add_argument("--out", default="gpurun_out/sweep_gemm.json")
     args = ap.parse_args()
     dev = "cuda"
@@ -83,11 +84,17 @@ def main():
         sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
         ref = (ref32 * sx.double() * sw.double())
         flops = 2.0 * M * N * K
-        for c in cfgs:
+        qxp = mixlib.PackP16x64(qx) if (K if args.bit == 8 else K // 2) % 64 == 0 else None
+        qwp = mixlib.PackP16x64(qw) if qxp is not None else None
+        for c, krot in [(c, int(kr)) for c in cfgs for kr in args.packed.split(",")]:
+            if krot and (qxp is None or "x128_" in names[c].split("_w")[0][-5:]):
+                continue
+            ax, aw = (qxp, qwp) if krot else (qx, qw)
+            pk = dict(x_packed=bool(krot), w_packed=bool(krot))
             rc = lib.mixq_gemm_set_config(c)
             assert rc == 0
             try:
-                y = mixlib.FusedLinear(qx, qw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit)
+                y = mixlib.FusedLinear(ax, aw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, **pk)
                 torch.cuda.synchronize()
             except Exception as ex:  # config incompatible with the shape
                 print(f"{shp} cfg{c} {names[c]}: {ex}", flush=True)
@@ -95,13 +102,13 @@ def main():
             err = (y.double() - ref).abs().max().item()
             rel = err / ref.abs().max().item()
             out = torch.empty_like(y)
-            us = time_fn(lambda: mixlib.FusedLinear(qx, qw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out), args.iters)
-            usg = time_graph(lambda: mixlib.FusedLinear(qx, qw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out), args.iters)
+            us = time_fn(lambda: mixlib.FusedLinear(ax, aw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out, **pk), args.iters)
+            usg = time_graph(lambda: mixlib.FusedLinear(ax, aw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out, **pk), args.iters)
             tops = flops / usg / 1e6
-            r = dict(shape=shp, cfg=c, name=names[c], bit=args.bit, max_abs_err=err, rel_err=rel, us_eager=us, us_graph=usg,
+            r = dict(shape=shp, cfg=c, krot=krot, name=names[c], bit=args.bit, max_abs_err=err, rel_err=rel, us_eager=us, us_graph=usg,
                      tops=tops, frac=tops / PEAK_TOPS)
             results.append(r)
-            print(f"{shp} cfg{c:2d} {names[c]:24s} err={err:.3e} rel={rel:.2e} eager={us:8.2f}us graph={usg:8.2f}us "
+            print(f"{shp} cfg{c:2d} packed={krot:1d} {names[c]:24s} err={err:.3e} rel={rel:.2e} eager={us:8.2f}us graph={usg:8.2f}us "
                   f"{tops:7.1f} TOPS ({100 * tops / PEAK_TOPS:4.1f}%)", flush=True)
         lib.mixq_gemm_set_config(-1)
         auto = lib.mixq_gemm_pick_config(M, N, K, args.bit)
