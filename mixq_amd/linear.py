@@ -183,7 +183,7 @@ class MixLinear_GEMM(nn.Module):
             q.q_weight.copy_(pack_to_i4(tmp.to(torch.int8).cpu()).to(dev))
             q.ind.copy_(ind_d.to(torch.int32))
         if linear.bias is not None:
-            q.bias.copy_(linear.bias.half())
+            q.bias.copy_(linear.bias.data.half())
         return q
 
     # ------------------------------------------------------------------------------------------------------

@@ -31,12 +31,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
-sys.path.insert(0, ROOT)
+sys.path[0] = ROOT
 from oracle import oracle as O  # noqa: E402
 
 
 def t2h(t):
-    return t.detach().cpu().contiguous().numpy()
+    return t.detach().cpu().contiguous().numpy().copy()      # copy: CPU tensors share memory with reused cache buffers
 
 
 def make_mixlib_standin():

@@ -1,0 +1,73 @@
+"""A `mixq_amd.mixlib`-shaped backend on top of the CPU oracle, for testing the operator's HOST logic (state machine,
+buffer management) on machines without a GPU.  Test infrastructure: installed with mixq_amd.linear.set_backend() by
+the tests only; the product never imports it."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+ACT_NONE, ACT_SILU = 0, 1
+calls = []
+
+
+def _np(t):
+    return t.detach().cpu().contiguous().numpy()
+
+
+def FindRowScale(x, x_scale, M, K, bit=8):
+    calls.append("FindRowScale")
+    q, s = O.find_row_scale(_np(x.reshape(-1, K)[:M]), bit)
+    x_scale.reshape(-1)[0:M] = torch.from_numpy(s)
+    return torch.from_numpy(q)
+
+
+def ExtractOutliersAndSetToZeros(ind, x):
+    calls.append("ExtractOutliersAndSetToZeros")
+    xn = _np(x).copy()
+    out = O.extract_outliers_zero(xn, _np(ind))
+    x.copy_(torch.from_numpy(xn))
+    return torch.from_numpy(out)
+
+
+def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, packed=False):
+    calls.append("QuantFused")
+    assert not packed
+    M, K = x.shape
+    xo = None
+    if ind is not None and ind.numel():
+        xo = ExtractOutliersAndSetToZeros(ind, x)
+        calls.pop()
+    q, s = O.find_row_scale(_np(x), bit)
+    x_scale.reshape(-1)[0:M] = torch.from_numpy(s)
+    if flag is not None and O.mispredicted(s, sigma, bit):
+        flag |= 1
+    return torch.from_numpy(q), xo
+
+
+def DetectOutlierCols(x, sigma, scratch=None):
+    calls.append("DetectOutlierCols")
+    ind = O.find_outliers(_np(x), sigma)
+    buf = torch.zeros(x.shape[1], dtype=torch.int32)
+    buf[: ind.size] = torch.from_numpy(ind)
+    return buf, torch.tensor([ind.size], dtype=torch.int32)
+
+
+def DequantWeightCols(q_w, scale_col, ind, bit, out=None):
+    calls.append("DequantWeightCols")
+    return torch.from_numpy(O.dequant_weight_cols(_np(q_w), _np(scale_col), _np(ind), bit))
+
+
+def unpack_int4_to_fp16(q_w, ind):
+    calls.append("unpack_int4_to_fp16")
+    return torch.from_numpy(O.unpack_i4_cols(_np(q_w), _np(ind)))
+
+
+def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K, bit=8, act=ACT_NONE, n_out_dev=None,
+                addend=None, out=None, x_packed=False, w_packed=False):
+    calls.append("FusedLinear")
+    assert not x_packed and not w_packed
+    xo = _np(x_out) if (n_out and x_out is not None) else None
+    wo = _np(w_out) if (n_out and w_out is not None) else None
+    y = O.linear_fused(_np(q_x), _np(q_w), _np(x_scale.reshape(-1)[0:M]), _np(scale_col), xo=xo, wo=wo,
+                       addend=None if addend is None else _np(addend), bias=None if bias is None else _np(bias), act=act, bit=bit)
+    return torch.from_numpy(y)

@@ -1,0 +1,79 @@
+"""The C-ABI shared library loads (no GPU needed) and exports every symbol include/mixq_hip.h declares; the ctypes
+signature table mirrors the header; argument validation is exercised where it needs no device."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from mixq_amd import _capi
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_capi.LIB_PATH), "run __graft_entry__.build() first"
+    assert os.path.dirname(_capi.LIB_PATH).endswith("mixq_amd")
+
+
+def test_every_header_symbol_is_exported_and_bound():
+    lib = _capi.load()
+    declared = _capi.header_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mixq_hip.h but not exported"
+    assert set(declared) == set(_capi.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_header_arity_matches_ctypes_table():
+    txt = open(_capi.HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    for m in re.finditer(r"\bint\s+(mixq_\w+)\s*\(([^)]*)\)\s*;", txt):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        assert n == len(_capi.SIGNATURES[name]), f"{name}: header has {n} parameters, ctypes table {len(_capi.SIGNATURES[name])}"
+
+
+def test_code_object_is_gfx950():
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    out = subprocess.run([objdump, "--offloading", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_version_and_config_table():
+    lib = _capi.load()
+    assert lib.mixq_version() >= 1000
+    names = _capi.gemm_config_names()
+    assert len(names) == lib.mixq_gemm_num_configs() and len(set(names)) == len(names)
+    assert lib.mixq_gemm_set_config(len(names)) == _capi.MIXQ_EINVAL
+    assert lib.mixq_gemm_set_config(-1) == 0
+    c = lib.mixq_gemm_pick_config(512, 11008, 4096, 8)
+    assert 0 <= c < len(names)
+    assert lib.mixq_gemm_pick_config(0, 1, 1, 8) == _capi.MIXQ_EINVAL
+
+
+def test_argument_validation_without_device():
+    """Bad arguments are rejected before anything touches the GPU."""
+    lib = _capi.load()
+    one = C.c_void_p(16)   # a non-null dummy pointer; never dereferenced on these paths
+    assert lib.mixq_find_row_scale(None, one, one, 4, 64, 64, 8, 0, None) == _capi.MIXQ_EINVAL
+    assert lib.mixq_find_row_scale(one, one, one, 4, 64, 64, 5, 0, None) == _capi.MIXQ_EINVAL      # bit
+    assert lib.mixq_find_row_scale(one, one, one, 4, 60, 64, 8, 0, None) == _capi.MIXQ_ESHAPE      # K % 8
+    assert lib.mixq_find_row_scale(one, one, one, 4, 72, 72, 8, 1, None) == _capi.MIXQ_ESHAPE      # packed needs K % 64
+    assert lib.mixq_find_row_scale(one, one, one, 0, 64, 64, 8, 0, None) == 0                      # empty input is fine
+    assert lib.mixq_gemm_i8_fused(one, one, one, one, None, 0, None, 0, 0, None, None, 0, None, one, 64, 4, 64, 100, 0, 0,
+                                  None) == _capi.MIXQ_ESHAPE                                        # K % 64
+    assert lib.mixq_gemm_i8_fused(one, one, one, one, None, 0, None, 0, 0, None, None, 0, None, one, 64, 4, 64, 128, 7, 0,
+                                  None) == _capi.MIXQ_EINVAL                                        # act
+    assert lib.mixq_gemm_i8_fused(one, one, one, one, None, 0, None, 0, 0, None, None, 0, None, one, 64, 0, 64, 128, 0, 0,
+                                  None) == 0                                                        # M = 0
+    assert lib.mixq_pack_p16x64(one, one, 4, 100, None) == _capi.MIXQ_ESHAPE
+    assert lib.mixq_extract_outliers_zero(one, None, 3, one, 4, 64, 64, 3, None) == _capi.MIXQ_EINVAL
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_capi.MixqBuildError):
+        _capi.load()

@@ -1,0 +1,414 @@
+"""Parity of the HIP path (through the C ABI of libmixq_hip.so) against the CPU oracle on seeded inputs.
+
+Bars (north_star): integer / byte / index results bit-exact; fp16 outputs within |d|inf <= 1e-2 of a CPU Linear over the
+SAME dequantised operands (oracle.linear_dequant_ref, fp64), and within 2 fp16 ulp of the oracle's restatement of the
+same fp32 formula.  Full BASELINE sizes are covered through size-independent exact properties (checksum of checksums,
+sampled rows) because the scalar oracle cannot finish 46 GFLOP in seconds."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mixq_amd import MixLibCache, MixLinear_GEMM, _capi, mixlib  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from test_pack_properties import p16x64_reference, p16x64_unpack  # noqa: E402
+
+DEV = "cuda"
+GATE = 1e-2          # north_star: |d|inf vs CPU Linear over the same dequantised operands
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint16)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def ulp_tol(ref):
+    """2 fp16 ulp of the reference magnitude, at least 1e-3."""
+    a = np.abs(ref.astype(np.float32))
+    ulp = np.where(a > 0, 2.0 ** (np.floor(np.log2(np.maximum(a, 6e-5))) - 10), 2.0 ** -24)
+    return np.maximum(2 * ulp, 1e-3)
+
+
+def make_x(M, K, seed, outlier_cols=(), scale=20.0, zero_rows=()):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    for c in outlier_cols:
+        x[:, c] *= scale
+    for r in zero_rows:
+        x[r] = 0
+    return x
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    info = _capi.device_info()          # raises unless a gfx950 device is visible and the native library is loaded
+    assert "gfx950" in info
+    _capi.load().mixq_gemm_set_config(-1)
+    yield
+    _capi.load().mixq_gemm_set_config(-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (i) per-token scale + quantise
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K", [(1, 64), (5, 64), (37, 1024), (64, 4096), (16, 11008), (3, 28672), (2, 40000)])
+@pytest.mark.parametrize("bit", [8, 4])
+def test_find_row_scale_bit_exact(M, K, bit):
+    if bit == 4 and K % 16:
+        pytest.skip("int4 needs K % 16 == 0")
+    x = make_x(M, K, seed=M * 7 + K, zero_rows=(0,) if M > 1 else ())
+    x[-1, -1] = 65504.0                                    # largest fp16
+    xs = torch.zeros((M + 3, 1), dtype=torch.float16, device=DEV)
+    q = mixlib.FindRowScale(t(x), xs, M, K, bit)
+    qo, so = O.find_row_scale(x, bit)
+    assert np.array_equal(n(q), qo)
+    assert np.array_equal(bits(n(xs)[:M, 0]), bits(so))
+    assert not n(xs)[M:].any(), "rows beyond M of the caller's x_scale buffer must not be touched"
+
+
+@pytest.mark.parametrize("M,K,bit", [(1, 64, 8), (17, 256, 8), (40, 1024, 8), (33, 512, 4)])
+def test_packed_quantise_equals_pack_of_plain(M, K, bit):
+    x = make_x(M, K, seed=3)
+    xs = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+    qp = mixlib.FindRowScalePacked(t(x), xs, M, K, bit)
+    qo, so = O.find_row_scale(x, bit)
+    KB = K if bit == 8 else K // 2
+    got = p16x64_unpack(n(qp).reshape(-1).view(np.uint8), M, KB)
+    assert np.array_equal(got, qo.view(np.uint8))
+    assert np.array_equal(bits(n(xs)[:, 0]), bits(so))
+    # the standalone re-tiling kernel produces the documented layout byte for byte (pad rows zero)
+    packed = mixlib.PackP16x64(t(qo))
+    assert np.array_equal(n(packed).reshape(-1).view(np.uint8), p16x64_reference(qo))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (ii) outlier extraction, fused quantise, detection
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,ncols", [(8, 64, 1), (32, 256, 3), (64, 4096, 41), (5, 1024, 130)])
+def test_extract_and_fused_quantise(M, K, ncols):
+    rng = np.random.default_rng(K + ncols)
+    ind = np.sort(rng.choice(K, ncols, replace=False)).astype(np.int32)
+    rng.shuffle(ind)                                       # `ind` is in discovery order, not sorted
+    x = make_x(M, K, seed=11, outlier_cols=ind)
+    # reference pair (k2, k1)
+    x1 = t(x)
+    xo1 = mixlib.ExtractOutliersAndSetToZeros(t(ind), x1)
+    xz = x.copy()
+    xo_ref = O.extract_outliers_zero(xz, ind)
+    assert np.array_equal(bits(n(xo1)), bits(xo_ref))
+    assert np.array_equal(bits(n(x1)), bits(xz)), "columns must be zeroed in the caller's tensor"
+    # fused form
+    for bit in (8, 4):
+        x2 = t(x)
+        xs = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        q, xo2 = mixlib.QuantFused(x2, t(ind), xs, bit, 6.0, flag=flag)
+        qo, so = O.find_row_scale(xz, bit)
+        assert np.array_equal(n(q), qo)
+        assert np.array_equal(bits(n(xs)[:, 0]), bits(so))
+        assert np.array_equal(bits(n(xo2)), bits(xo_ref))
+        assert np.array_equal(bits(n(x2)), bits(xz))
+        assert xo2.stride(0) % 16 == 0, "outlier matrix row stride must suit the GEMM tail"
+        assert bool(flag.item()) == O.mispredicted(so, 6.0, bit)
+
+
+def test_misprediction_flag_threshold():
+    """flag <=> max(x_scale) > fp16(sigma/127) (linear.py:201), probed on both sides of the threshold."""
+    for amax, expect in [(5.9, False), (6.0, False), (6.02, True), (100.0, True)]:
+        x = np.full((4, 64), 0.5, dtype=np.float16)
+        x[2, 5] = amax
+        xs = torch.zeros((4, 1), dtype=torch.float16, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        mixlib.QuantFused(t(x), None, xs, 8, 6.0, flag=flag)
+        so = O.find_row_scale(x, 8)[1]
+        assert bool(flag.item()) == O.mispredicted(so, 6.0, 8) == expect
+
+
+@pytest.mark.parametrize("M,K,cols", [(24, 256, [7, 100, 201]), (512, 4096, list(range(0, 4096, 100))), (3, 64, []),
+                                       (16, 128, list(range(128)))])
+def test_detect_outlier_columns(M, K, cols):
+    x = make_x(M, K, seed=5, outlier_cols=cols)
+    if not cols:
+        x = np.clip(x, -3, 3)
+    if K > 60:
+        x[1, 55] = 6.0          # exactly sigma: not an outlier
+    ind_buf, count = mixlib.DetectOutlierCols(t(x), 6.0)
+    cnt = int(count.item())
+    ref = O.find_outliers(x, 6.0)
+    assert cnt == ref.size
+    assert np.array_equal(n(ind_buf)[:cnt], ref)
+
+
+def test_detect_matches_golden_find_outliers(golden):
+    g = golden("g4_find_outliers.npz")
+    ind_buf, count = mixlib.DetectOutlierCols(t(g["x"]), float(g["sigma"]))
+    assert np.array_equal(n(ind_buf)[: int(count.item())], g["ind"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight columns
+# ---------------------------------------------------------------------------------------------------------------
+def test_weight_column_dequant_bit_exact(golden):
+    g8, g4 = golden("g2_from_linear_w8.npz"), golden("g3_from_linear_w4.npz")
+    ind = np.array([0, 5, 255, 17], dtype=np.int32)
+    got = mixlib.DequantWeightCols(t(g8["q_weight"]), t(g8["scale_col"]), t(ind), 8)
+    assert np.array_equal(bits(n(got)), bits(O.dequant_weight_cols(g8["q_weight"], g8["scale_col"], ind, 8)))
+    ind4 = np.array([511, 0, 33, 256], dtype=np.int32)
+    got4 = mixlib.DequantWeightCols(t(g4["q_weight"]), t(g4["scale_col"]), t(ind4), 4)
+    assert np.array_equal(bits(n(got4)), bits(O.dequant_weight_cols(g4["q_weight"], g4["scale_col"], ind4, 4)))
+    raw = mixlib.unpack_int4_to_fp16(t(g4["q_weight"]), t(ind4))
+    assert np.array_equal(bits(n(raw)), bits(O.unpack_i4_cols(g4["q_weight"], ind4)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (iii) integer GEMM: exact, every tile configuration, ragged shapes, both operand layouts
+# ---------------------------------------------------------------------------------------------------------------
+def _real_configs():
+    return [i for i, name in enumerate(_capi.gemm_config_names()) if "abl" not in name]
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (33, 100, 128), (512, 256, 512), (300, 1000, 1024)])
+def test_int32_gemm_exact_all_configs(M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    qx = rng.integers(-127, 128, (M, K), dtype=np.int8)
+    qw = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    ref = O.gemm_i8(qx, qw)
+    lib = _capi.load()
+    for c in _real_configs():
+        assert lib.mixq_gemm_set_config(c) == 0
+        y = mixlib.gemm(t(qx), t(qw), M, N, K)
+        assert np.array_equal(n(y), ref), f"config {c} {_capi.gemm_config_names()[c]}"
+    lib.mixq_gemm_set_config(-1)
+
+
+def _fused_case(M, N, K, bit, seed, n_out, bias, addend, act):
+    rng = np.random.default_rng(seed)
+    ind = np.sort(rng.choice(K, n_out, replace=False)).astype(np.int32) if n_out else np.zeros(0, np.int32)
+    x = make_x(M, K, seed=seed + 1, outlier_cols=ind)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    if bit == 8:
+        qw, sw = O.quant_weight_w8(w)
+        wo = O.dequant_weight_cols(qw, sw, ind, 8) if n_out else None
+    else:
+        qw, sw, wo = O.quant_weight_w4(w, ind)            # fp columns keep their exact fp16 weights (linear.py:129)
+        if not n_out:
+            wo = None
+    xz = x.copy()
+    xo = O.extract_outliers_zero(xz, ind) if n_out else None
+    qx, sx = O.find_row_scale(xz, bit)
+    b = rng.standard_normal(N).astype(np.float16) if bias else None
+    ad = rng.standard_normal((M, N)).astype(np.float16) if addend else None
+    return dict(qx=qx, qw=qw, sx=sx, sw=sw, xo=xo, wo=wo, ind=ind, bias=b, addend=ad, act=act, bit=bit, M=M, N=N, K=K)
+
+
+def _run_fused(c, packed):
+    M, N, K, bit = c["M"], c["N"], c["K"], c["bit"]
+    n_out = int(c["ind"].size)
+    pad = (n_out + 15) // 16 * 16
+    xo = wo = None
+    if n_out:
+        xo = torch.zeros((M, pad), dtype=torch.float16, device=DEV); xo[:, :n_out] = t(c["xo"])
+        wo = torch.full((N, pad), float("nan"), dtype=torch.float16, device=DEV); wo[:, :n_out] = t(c["wo"])   # pad is poison
+        xo, wo = xo[:, :n_out], wo[:, :n_out]
+    qx, qw = t(c["qx"]), t(c["qw"])
+    if packed:
+        qx, qw = mixlib.PackP16x64(qx), mixlib.PackP16x64(qw)
+    sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV); sx[:, 0] = t(c["sx"])
+    return mixlib.FusedLinear(qx, qw, sx, t(c["sw"]), xo, wo, n_out, None if c["bias"] is None else t(c["bias"]), M, N, K, bit=bit,
+                              act=c["act"], addend=None if c["addend"] is None else t(c["addend"]), x_packed=packed, w_packed=packed)
+
+
+@pytest.mark.parametrize("M,N,K,bit,n_out,bias,addend,act", [
+    (32, 96, 256, 8, 0, False, False, 0),
+    (32, 96, 256, 8, 3, True, False, 0),
+    (96, 320, 1024, 8, 41, False, False, 0),
+    (96, 320, 1024, 8, 17, True, True, 1),
+    (130, 200, 512, 8, 128, True, False, 0),
+    (7, 36, 128, 8, 5, False, True, 0),
+    (64, 128, 512, 4, 128, False, False, 0),
+    (40, 64, 1024, 4, 16, True, False, 1),
+])
+@pytest.mark.parametrize("packed", [False, True])
+def test_fused_linear_vs_oracle(M, N, K, bit, n_out, bias, addend, act, packed):
+    c = _fused_case(M, N, K, bit, seed=M + N + K + bit + n_out, n_out=n_out, bias=bias, addend=addend, act=act)
+    y = n(_run_fused(c, packed)).astype(np.float32)
+    ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], addend=c["addend"], bias=c["bias"], act=act,
+                         bit=bit).astype(np.float32)
+    assert np.isfinite(y).all()
+    assert (np.abs(y - ref) <= ulp_tol(ref)).all(), f"max |d| = {np.abs(y - ref).max()}"
+    if bit == 8 and not act and not addend:
+        gate = O.linear_dequant_ref(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], ind=c["ind"], bias=c["bias"])
+        assert np.abs(y - gate).max() <= GATE            # tolerance stated by north_star: 1e-2 fp16
+
+
+def test_reference_style_calls_through_the_mixlib_surface():
+    """The reference's own call sequence (linear.py:187-285): k2, k1, torch.mm, int8FusedDequantize(addend), += bias."""
+    c = _fused_case(64, 192, 512, 8, seed=9, n_out=9, bias=True, addend=False, act=0)
+    rng = np.random.default_rng(9)
+    x = make_x(64, 512, seed=10, outlier_cols=c["ind"])
+    xt = t(x)
+    cache = MixLibCache(64, device=DEV)
+    xo = mixlib.ExtractOutliersAndSetToZeros(t(c["ind"]), xt)
+    q = mixlib.FindRowScale(xt, cache.x_scale, 64, 512, 8)
+    wc = t(c["wo"])
+    outliers_fp16 = torch.mm(xo, wc.T)
+    y = mixlib.int8FusedDequantize(q, t(c["qw"]), cache.x_scale, t(c["sw"]), outliers_fp16, 64, 192, 512)
+    y += t(c["bias"])
+    gate = O.linear_dequant_ref(n(q), c["qw"], n(cache.x_scale)[:64, 0], c["sw"], xo=n(xo), ind=c["ind"], bias=c["bias"])
+    assert np.abs(n(y).astype(np.float64) - gate).max() <= GATE
+    # no-outlier form with the cache's zeros addend, unfused pair, SiLU twin
+    y0 = mixlib.int8FusedDequantize(q, t(c["qw"]), cache.x_scale, t(c["sw"]), cache.zeros, 64, 192, 512)
+    y32 = mixlib.gemm(q, t(c["qw"]), 64, 192, 512)
+    assert np.array_equal(n(y32), O.gemm_i8(n(q), c["qw"]))
+    y1 = mixlib.dequantizeInt8(y32, cache.x_scale, t(c["sw"]), cache.zeros, 8, 64, 192)
+    assert np.abs(n(y0).astype(np.float32) - n(y1).astype(np.float32)).max() <= 2e-3
+    ys = mixlib.int8FusedDequantizeSilu(q, t(c["qw"]), cache.x_scale, t(c["sw"]), cache.zeros, 64, 192, 512)
+    ref_s = O.linear_fused(n(q), c["qw"], n(cache.x_scale)[:64, 0], c["sw"], act=1).astype(np.float32)
+    assert (np.abs(n(ys).astype(np.float32) - ref_s) <= ulp_tol(ref_s)).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# operator: the reference's recorded forward traces, now on the HIP backend
+# ---------------------------------------------------------------------------------------------------------------
+def _unpacked_q(cache, M, KB):
+    q = n(cache.q_xcache)
+    if getattr(cache, "q_xcache_packed", False):
+        return p16x64_unpack(q.reshape(-1).view(np.uint8), M, KB)
+    return q.view(np.uint8)
+
+
+def test_operator_trace_w8_on_gpu(golden):
+    g, g2 = golden("g5a_forward_w8_unfused.npz"), golden("g2_from_linear_w8.npz")
+    lin = torch.nn.Linear(256, 96, bias=True).half()
+    lin.weight.data.copy_(torch.from_numpy(g2["weight"]))
+    lin.bias.data.copy_(torch.from_numpy(g2["bias_in"]))
+    cache = MixLibCache(64, device=DEV)
+    layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
+    assert np.array_equal(n(layer.q_weight), g2["q_weight"]) and np.array_equal(bits(n(layer.scale_col)), bits(g2["scale_col"]))
+    for i in range(int(g["ncalls"])):
+        x = t(g[f"c{i}_x_in"])
+        y = layer(x, None, True)
+        assert np.array_equal(n(layer.ind), g[f"c{i}_ind"])
+        assert layer.cnt == int(g[f"c{i}_cnt"]) and layer.add_outliers == bool(g[f"c{i}_add_outliers"])
+        assert np.array_equal(bits(n(cache.x_scale)[:32]), bits(g[f"c{i}_x_scale"]))
+        assert np.array_equal(_unpacked_q(cache, 32, 256), g[f"c{i}_q_xcache"].view(np.uint8))
+        assert np.array_equal(bits(n(x)), bits(g[f"c{i}_x_after"]))
+        if layer.ind.numel():
+            assert np.array_equal(bits(n(layer.weight_cache)), bits(g[f"c{i}_weight_cache"]))
+        assert np.abs(n(y).astype(np.float32) - g[f"c{i}_y"].astype(np.float32)).max() <= 4e-3
+
+
+def test_operator_trace_w4_and_silu_on_gpu(golden):
+    g = golden("g5d_forward_w4_silu.npz")
+    ls = torch.from_numpy(g["layer_scales"])
+    up, gate = torch.nn.Linear(512, 64, bias=False).half(), torch.nn.Linear(512, 64, bias=False).half()
+    up.weight.data.copy_(torch.from_numpy(g["up_weight"]))
+    gate.weight.data.copy_(torch.from_numpy(g["gate_weight"]))
+    cache = MixLibCache(64, bit=4, device=DEV)
+    up_q = MixLinear_GEMM.from_linear(up, 4, cache=cache, layer_scales=ls, dev=DEV)
+    gate_q = MixLinear_GEMM.from_linear(gate, 4, cache=cache, layer_scales=ls, dev=DEV)
+    for i in range(int(g["ncalls"])):
+        x = t(g[f"c{i}_x_in"])
+        y = up_q(x, cache, True)
+        assert np.array_equal(n(up_q.ind), g[f"c{i}_ind"])
+        assert np.array_equal(_unpacked_q(cache, 16, 256), g[f"c{i}_q_xcache"].view(np.uint8))
+        assert np.abs(n(y).astype(np.float32) - g[f"c{i}_y"].astype(np.float32)).max() <= 4e-3
+        ys = gate_q.forward_without_preconditionFusedSilu(t(g[f"c{i}_x_in"]), cache)
+        assert np.abs(n(ys).astype(np.float32) - g[f"c{i}_y_silu"].astype(np.float32)).max() <= 4e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE sizes through size-independent exact properties
+# ---------------------------------------------------------------------------------------------------------------
+LLAMA2_7B = [(4096, 4096), (4096, 11008), (4096, 12288), (11008, 4096)]
+LLAMA2_70B = [(8192, 8192), (8192, 28672), (8192, 10240), (28672, 8192)]
+LLAMA3_8B = [(4096, 4096), (4096, 6144), (4096, 14336), (14336, 4096)]
+
+
+@pytest.mark.parametrize("K,N", sorted(set(LLAMA2_7B + LLAMA2_70B + LLAMA3_8B)))
+def test_full_size_int32_checksum_and_rows(K, N):
+    """M = 512 at the BASELINE shapes: (a) checksum of checksums  sum_n Y32[m,n] == x[m,:] . colsum(W)  for EVERY row
+    (exact integers); (b) 4 sampled rows fully against the oracle; both operand layouts."""
+    M = 512
+    g = torch.Generator().manual_seed(K + N)
+    qx = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8)
+    qw = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    colsum = qw.to(torch.int64).sum(dim=0)
+    want_rowsum = (qx.to(torch.int64) * colsum).sum(dim=1).numpy()
+    rows = [0, 137, 300, 511]
+    ref_rows = O.gemm_i8(qx[rows].numpy(), qw.numpy())
+    y = mixlib.gemm(qx.to(DEV), qw.to(DEV), M, N, K)
+    assert np.array_equal(n(y.to(torch.int64).sum(dim=1)), want_rowsum)
+    assert np.array_equal(n(y[rows]), ref_rows)
+    # packed layout through the fused entry point with unit scales: fp16(acc * 2^-12) stays exact for |acc| < 2^11 * 2^12
+    sx = torch.full((M, 1), 2.0 ** -6, dtype=torch.float16, device=DEV)
+    sw = torch.full((1, N), 2.0 ** -6, dtype=torch.float16, device=DEV)
+    yp = mixlib.FusedLinear(mixlib.PackP16x64(qx.to(DEV)), mixlib.PackP16x64(qw.to(DEV)), sx, sw, None, None, 0, None, M, N, K,
+                            x_packed=True, w_packed=True)
+    want = (y.to(torch.float64) * 2.0 ** -12).to(torch.float16)
+    assert torch.equal(yp, want)
+
+
+@pytest.mark.parametrize("K,N,bit", [(4096, 11008, 8), (4096, 14336, 8), (4096, 11008, 4)])
+def test_full_size_operator_with_one_percent_outliers(K, N, bit):
+    """BASELINE config 4 protocol: 1 % synthetic outlier columns x20, two warm-up forwards freeze `ind`
+    (outlier-predict on), the third is checked on sampled rows against the CPU Linear over the dequantised operands."""
+    M = 512
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(K, N, bias=False).half()
+    cols = torch.randperm(K, generator=torch.Generator().manual_seed(1))[: round(0.01 * K)]
+    cache = MixLibCache(M, bit=bit, device=DEV)
+    if bit == 8:
+        layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
+    else:
+        scales = torch.ones(K); scales[cols] = 20.0 + torch.arange(cols.numel()) * 1e-3     # calibration marks the same columns
+        layer = MixLinear_GEMM.from_linear(lin, 4, cache=cache, layer_scales=scales, dev=DEV)
+    xs = []
+    for call in range(3):
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(10 + call)).half()
+        x[:, cols] *= 20
+        xs.append(x)
+        y = layer(x.to(DEV), None, True)
+    assert layer.add_outliers is False
+    found = set(n(layer.ind).tolist())
+    assert set(cols.tolist()) <= found
+    rows = [0, 255, 511]
+    x = xs[-1].numpy()[rows].copy()
+    ind = n(layer.ind).astype(np.int32)
+    xo = O.extract_outliers_zero(x, ind)
+    qx, sx = O.find_row_scale(x, bit)
+    if bit == 8:
+        gate = O.linear_dequant_ref(qx, n(layer.q_weight), sx, n(layer.scale_col), xo=xo, ind=ind)
+        assert np.abs(n(y)[rows].astype(np.float64) - gate).max() <= GATE
+    ref = O.linear_fused(qx, n(layer.q_weight), sx, n(layer.scale_col), xo=xo, wo=n(layer.weight_cache), bit=bit).astype(np.float32)
+    assert (np.abs(n(y)[rows].astype(np.float32) - ref) <= ulp_tol(ref)).all()
+
+
+def test_linearity_in_the_outlier_operand():
+    """Y(xo1 + xo2) - Y(0) == (Y(xo1) - Y(0)) + (Y(xo2) - Y(0)) up to fp16 rounding: the fp16 MFMA tail is additive."""
+    c = _fused_case(64, 128, 256, 8, seed=4, n_out=16, bias=False, addend=False, act=0)
+    base = dict(c); base["xo"] = np.zeros_like(c["xo"])
+    a = dict(c); a["xo"] = (c["xo"].astype(np.float32) * 0.5).astype(np.float16)
+    y0, ya, yfull = (n(_run_fused(k, True)).astype(np.float32) for k in (base, a, c))
+    assert np.abs((yfull - y0) - 2 * (ya - y0)).max() <= 8e-3
+
+
+def test_empty_and_tiny_inputs():
+    xs = torch.zeros((4, 1), dtype=torch.float16, device=DEV)
+    q = mixlib.FindRowScale(torch.zeros((0, 64), dtype=torch.float16, device=DEV), xs, 0, 64, 8)
+    assert tuple(q.shape) == (0, 64)
+    e = mixlib.ExtractOutliersAndSetToZeros(torch.zeros(0, dtype=torch.int32, device=DEV), torch.ones((3, 64), dtype=torch.float16, device=DEV))
+    assert tuple(e.shape) == (3, 0)
+    y = mixlib.gemm(torch.zeros((0, 64), dtype=torch.int8, device=DEV), torch.zeros((8, 64), dtype=torch.int8, device=DEV), 0, 8, 64)
+    assert tuple(y.shape) == (0, 8)
+    with pytest.raises(_capi.MixqError):
+        mixlib.gemm(torch.zeros((4, 100), dtype=torch.int8, device=DEV), torch.zeros((8, 100), dtype=torch.int8, device=DEV), 4, 8, 100)

@@ -1,0 +1,87 @@
+"""Property tests (hypothesis) for the bit-exact integer parts of the path: nibble packing, the P16x64 tile-major
+layout, and the quantisation invariants of the oracle."""
+import numpy as np
+import torch
+from hypothesis import given, settings, strategies as st
+
+from mixq_amd import pack_to_i4
+from oracle import oracle as O
+
+
+def p16x64_reference(q):
+    """Straight restatement of the P16x64 layout of include/mixq_hip.h: [KB/64][rows16/16] blocks of 16 rows x 64 B,
+    the four 16-byte chunks of row r stored at position c ^ ((r>>2)&3); rows >= R zero."""
+    R, KB = q.shape
+    rows16 = (R + 15) // 16 * 16
+    out = np.zeros(rows16 * KB, dtype=np.uint8)
+    src = q.view(np.uint8)
+    for row in range(R):
+        for kb in range(KB // 64):
+            base = (kb * (rows16 // 16) + row // 16) * 1024 + (row % 16) * 64
+            for c in range(4):
+                pc = c ^ (((row % 16) >> 2) & 3)
+                out[base + pc * 16: base + pc * 16 + 16] = src[row, kb * 64 + c * 16: kb * 64 + c * 16 + 16]
+    return out
+
+
+def p16x64_unpack(buf, R, KB):
+    rows16 = (R + 15) // 16 * 16
+    out = np.zeros((R, KB), dtype=np.uint8)
+    for row in range(R):
+        for kb in range(KB // 64):
+            base = (kb * (rows16 // 16) + row // 16) * 1024 + (row % 16) * 64
+            for c in range(4):
+                pc = c ^ (((row % 16) >> 2) & 3)
+                out[row, kb * 64 + c * 16: kb * 64 + c * 16 + 16] = buf[base + pc * 16: base + pc * 16 + 16]
+    return out
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.integers(1, 9), st.integers(1, 40), st.integers(0, 2 ** 31 - 1))
+def test_pack_unpack_i4_roundtrip(rows, half_cols, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(-8, 8, (rows, 2 * half_cols), dtype=np.int8)
+    p = O.pack_i4(x)
+    assert p.shape == (rows, half_cols) and p.dtype == np.uint8
+    assert np.array_equal(O.unpack_i4_all(p), x)
+    assert np.array_equal(pack_to_i4(torch.from_numpy(x)).numpy(), p)
+    # low nibble = even column, two's complement (linear.py:12-18)
+    assert np.array_equal(p & 0xF, np.where(x[:, 0::2] < 0, x[:, 0::2] + 16, x[:, 0::2]).astype(np.uint8))
+    assert np.array_equal(p >> 4, np.where(x[:, 1::2] < 0, x[:, 1::2] + 16, x[:, 1::2]).astype(np.uint8))
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(1, 40), st.integers(1, 3), st.integers(0, 2 ** 31 - 1))
+def test_p16x64_layout_is_a_bijection(rows, kblocks, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(-128, 128, (rows, 64 * kblocks), dtype=np.int8)
+    buf = p16x64_reference(q)
+    assert np.array_equal(p16x64_unpack(buf, rows, 64 * kblocks), q.view(np.uint8))
+    # every 16-lane group of the GEMM's fragment reads (rows r..r+15 step pattern of ds_read_b128, same logical chunk)
+    # lands on 16 distinct 16-byte bank slots of the 256-byte LDS bank row
+    for group in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+        for c in range(4):
+            slots = {((r * 64 + ((c ^ ((r >> 2) & 3)) * 16)) // 16) % 16 for r in group}
+            assert len(slots) == 16
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 6), st.sampled_from([16, 64, 200]), st.sampled_from([4, 8]), st.integers(0, 2 ** 31 - 1))
+def test_row_quantisation_invariants(rows, K, bit, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((rows, K)) * rng.choice([1e-3, 1.0, 50.0])).astype(np.float16)
+    x[0, :] = 0                                               # all-zero row -> scale 0, q 0
+    q, s = O.find_row_scale(x, bit)
+    qmax = 2 ** (bit - 1) - 1
+    qi = q if bit == 8 else O.unpack_i4_all(q)
+    assert qi.min() >= -qmax and qi.max() <= qmax
+    assert s[0] == 0 and not qi[0].any()
+    amax = np.abs(x.astype(np.float32)).max(axis=1)
+    assert np.array_equal(s.view(np.uint16), (amax / np.float32(qmax)).astype(np.float16).view(np.uint16))
+    sf = s.astype(np.float32)
+    nz = sf > 0
+    # dequantised value is within half a step (plus fp16 rounding of the scale) of the input
+    err = np.abs(qi[nz].astype(np.float32) * sf[nz, None] - x[nz].astype(np.float32))
+    assert (err <= 0.5 * sf[nz, None] * 1.01 + 1e-6).all()
+    # the element of largest magnitude maps to +-qmax
+    assert (np.abs(qi[nz]).max(axis=1) == qmax).all()
