@@ -573,7 +573,8 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
                       int act, int layout, int bit, mixq_stream_t stream)
 {
     if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED)) return MIXQ_EINVAL;
-    if (!q_x || !q_w || !x_scale || !scale_col || !y || M < 0 || N < 0 || K <= 0 || n_out < 0) return MIXQ_EINVAL;
+    if (M < 0 || N < 0 || K <= 0 || n_out < 0) return MIXQ_EINVAL;
+    if (M > 0 && N > 0 && (!q_x || !q_w || !x_scale || !scale_col || !y)) return MIXQ_EINVAL;
     if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU) return MIXQ_EINVAL;
     const int KB = bit == 8 ? K : K / 2;
     if ((KB % 64) || (bit == 4 && (K & 1)) || (N & 3) || (ldy & 3) || ldy < N) return MIXQ_ESHAPE;
@@ -617,7 +618,7 @@ extern "C" int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const 
 extern "C" int mixq_gemm_i8(const int8_t* q_x, const int8_t* q_w, int32_t* y32, int ldy, int M, int N, int K,
                             mixq_stream_t stream)
 {
-    if (!q_x || !q_w || !y32 || M < 0 || N < 0 || K <= 0) return MIXQ_EINVAL;
+    if (M < 0 || N < 0 || K <= 0 || (M > 0 && N > 0 && (!q_x || !q_w || !y32))) return MIXQ_EINVAL;
     if ((K % 64) || (N & 3) || (ldy & 3) || ldy < N) return MIXQ_ESHAPE;
     if (M == 0 || N == 0) return MIXQ_OK;
     GemmArgs a;

@@ -285,7 +285,7 @@ extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q
 {
     if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64) return MIXQ_EINVAL;
     if (qfmt == MIXQ_FMT_P16X64 && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
-    if (!x || !x_scale || !q || M < 0 || K <= 0) return MIXQ_EINVAL;
+    if (M < 0 || K <= 0 || (M > 0 && (!x || !x_scale || !q))) return MIXQ_EINVAL;   // empty inputs may carry null pointers
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
     if ((K & 7) || (ldx & 7) || ldx < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
     if (M == 0) return MIXQ_OK;
@@ -300,7 +300,7 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
 {
     if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64) return MIXQ_EINVAL;
     if (qfmt == MIXQ_FMT_P16X64 && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
-    if (!x || !x_scale || !q || M < 0 || K <= 0 || n < 0) return MIXQ_EINVAL;
+    if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !x_scale || !q))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
     if (n > 0 && (!ind || !x_out || ldo < n)) return MIXQ_EINVAL;
     if ((K & 7) || (ldx & 7) || ldx < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
@@ -316,7 +316,8 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
 extern "C" int mixq_extract_outliers_zero(uint16_t* x, const int32_t* ind, int n, uint16_t* x_out, int M, int K, int ldx,
                                           int ldo, mixq_stream_t stream)
 {
-    if (!x || !x_out || M < 0 || K <= 0 || n < 0 || (n > 0 && !ind) || ldo < n || ldx < K) return MIXQ_EINVAL;
+    if (M < 0 || K <= 0 || n < 0 || (n > 0 && !ind) || ldo < n || ldx < K) return MIXQ_EINVAL;
+    if (M > 0 && ldo > 0 && (!x || !x_out)) return MIXQ_EINVAL;
     if (M == 0 || ldo == 0) return MIXQ_OK;
     hipLaunchKernelGGL(extract_kernel, dim3(M), dim3(QT), 0, mixq_stream(stream), x, ldx, ind, n, x_out, ldo);
     return mixq_launch_status();

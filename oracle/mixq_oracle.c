@@ -267,19 +267,25 @@ void orc_linear_fused(const void* qx, const void* qw, const uint16_t* sx, const 
 }
 
 /* The north_star's parity reference: a CPU Linear over the SAME dequantised operands
- *   X^[m,k] = q[m,k]*sx[m] with the outlier columns restored exactly, W^[n,k] = qw[n,k]*sw[n]; fp64 accumulate.
+ *   X^[m,k] = q[m,k]*sx[m] with the outlier columns restored exactly, W^[n,k] = qw[n,k]*sw[n] - except on the outlier
+ *   columns, where the operand the reference multiplies is its fp16 `weight_cache` (linear.py:207/:129), passed as wo;
+ *   with wo == NULL those columns use qw*sw too.  fp64 accumulate.
  * Independent of the integer path above (no int32 accumulator, no factoring of the scales). */
 void orc_linear_dequant_ref(const int8_t* qx, const int8_t* qw, const uint16_t* sx, const uint16_t* sw, const uint16_t* xo,
-                            int ldxo, const int32_t* ind, int n_out, const uint16_t* bias, double* y, int M, int N, int K)
+                            int ldxo, const int32_t* ind, int n_out, const uint16_t* wo, int ldwo, const uint16_t* bias,
+                            double* y, int M, int N, int K)
 {
 #pragma omp parallel for schedule(static)
     for (int m = 0; m < M; ++m) {
         double* xr = (double*)malloc(sizeof(double) * (size_t)K);
         for (int k = 0; k < K; ++k) xr[k] = (double)qx[(size_t)m * K + k] * (double)h2f(sx[m]);
-        for (int j = 0; j < n_out; ++j) xr[ind[j]] = (double)h2f(xo[(size_t)m * ldxo + j]);
+        for (int j = 0; j < n_out; ++j) xr[ind[j]] = wo ? 0.0 : (double)h2f(xo[(size_t)m * ldxo + j]);
         for (int n = 0; n < N; ++n) {
             double acc = 0.0, s = (double)h2f(sw[n]);
             for (int k = 0; k < K; ++k) acc += xr[k] * ((double)qw[(size_t)n * K + k] * s);
+            if (wo)
+                for (int j = 0; j < n_out; ++j)
+                    acc += (double)h2f(xo[(size_t)m * ldxo + j]) * (double)h2f(wo[(size_t)n * ldwo + j]);
             if (bias) acc += (double)h2f(bias[n]);
             y[(size_t)m * N + n] = acc;
         }

@@ -172,8 +172,9 @@ def linear_fused(qx, qw, sx, sw, xo=None, wo=None, addend=None, bias=None, act=0
     return y
 
 
-def linear_dequant_ref(qx, qw, sx, sw, xo=None, ind=None, bias=None):
-    """north_star's gate: CPU Linear over the same dequantised operands, fp64 -> float64 [M,N] (int8 operands)."""
+def linear_dequant_ref(qx, qw, sx, sw, xo=None, ind=None, bias=None, wo=None):
+    """north_star's gate: CPU Linear over the same dequantised operands, fp64 -> float64 [M,N] (int8 operands).
+    wo: the fp16 weight_cache the reference multiplies the outlier columns with (linear.py:207); None -> qw*sw."""
     qx = np.ascontiguousarray(qx, dtype=np.int8)
     qw = np.ascontiguousarray(qw, dtype=np.int8)
     M, K = qx.shape
@@ -188,8 +189,14 @@ def linear_dequant_ref(qx, qw, sx, sw, xo=None, ind=None, bias=None):
     else:
         xo = ind = None
     b = None if bias is None else _h(bias).reshape(-1)
+    if wo is not None and n_out:
+        wo = _h(wo)
+        assert wo.shape == (N, n_out)
+    else:
+        wo = None
     y = np.empty((M, N), dtype=np.float64)
-    lib().orc_linear_dequant_ref(_p(qx), _p(qw), _p(sx), _p(sw), _p(xo), n_out, _p(ind), n_out, _p(b), _p(y), M, N, K)
+    lib().orc_linear_dequant_ref(_p(qx), _p(qw), _p(sx), _p(sw), _p(xo), n_out, _p(ind), n_out, _p(wo), n_out, _p(b), _p(y),
+                                 M, N, K)
     return y
 
 

@@ -116,5 +116,5 @@ def test_oracle_fused_vs_dequant_reference(oracle):
     wo = oracle.dequant_weight_cols(qw, sw, ind, 8)
     bias = rng.standard_normal(N).astype(np.float16)
     y = oracle.linear_fused(qx, qw, sx, sw, xo=xo, wo=wo, bias=bias).astype(np.float64)
-    ref = oracle.linear_dequant_ref(qx, qw, sx, sw, xo=xo, ind=ind, bias=bias)
+    ref = oracle.linear_dequant_ref(qx, qw, sx, sw, xo=xo, ind=ind, bias=bias, wo=wo)
     assert np.abs(y - ref).max() <= 1e-2
