@@ -197,6 +197,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
+    u32x2 swp[NI][4];                                    // epilogue scales, prefetched near the end of the k loop
+    uint16_t sxh[MI];
     if (LOADERS == 0 || wave < CW) {
         if constexpr (LOADERS == 0) dma_setup(wave);
 
@@ -320,6 +322,30 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
         int kt = 0;
         if constexpr (LOADERS == 0) {
             for (; kt + LOOK < nk; ++kt) body(std::true_type{}, std::true_type{});
+        } else {
+            for (; kt + 4 < nk; ++kt) body(std::false_type{}, std::true_type{});
+        }
+        // The epilogue's scales are requested a few k-steps before the loop ends, so their HBM latency hides under the
+        // remaining MFMAs instead of standing between the last MFMA and the first store.
+        if constexpr (MODE != 2) {
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const int m = m0 + xrow[j];
+                sxh[j] = (m < a.M) ? a.sx[m] : static_cast<uint16_t>(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * WN + i * 32 + 4 * lh + 8 * g;
+                    if (n + 3 < a.N) swp[i][g] = *reinterpret_cast<const u32x2*>(a.sw + n);
+                    else {
+                        uint32_t h[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (n + e < a.N) ? a.sw[n + e] : 0u;
+                        swp[i][g] = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+                    }
+                }
         }
         for (; kt + 1 < nk; ++kt) body(std::false_type{}, std::true_type{});
         body(std::false_type{}, std::false_type{});
@@ -361,10 +387,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
 
             float sxv[MI];
 #pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const int m = m0 + xrow[j];
-                sxv[j] = (m < a.M) ? h2f(a.sx[m]) * PRE : 0.f;
-            }
+            for (int j = 0; j < MI; ++j) sxv[j] = h2f(sxh[j]) * PRE;
             if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // every wave is done reading the ring
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -373,17 +396,10 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                 float swv[16];                                                  // the 16 weight scales of this lane
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = nb + 8 * g;
-                    if (n + 3 < a.N) {
-                        const u32x2 p = *reinterpret_cast<const u32x2*>(a.sw + n);
-                        swv[4 * g]     = h2f(static_cast<uint16_t>(p.x & 0xffffu));
-                        swv[4 * g + 1] = h2f(static_cast<uint16_t>(p.x >> 16));
-                        swv[4 * g + 2] = h2f(static_cast<uint16_t>(p.y & 0xffffu));
-                        swv[4 * g + 3] = h2f(static_cast<uint16_t>(p.y >> 16));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) swv[4 * g + e] = (n + e < a.N) ? h2f(a.sw[n + e]) : 0.f;
-                    }
+                    swv[4 * g]     = h2f(static_cast<uint16_t>(swp[i][g].x & 0xffffu));
+                    swv[4 * g + 1] = h2f(static_cast<uint16_t>(swp[i][g].x >> 16));
+                    swv[4 * g + 2] = h2f(static_cast<uint16_t>(swp[i][g].y & 0xffffu));
+                    swv[4 * g + 3] = h2f(static_cast<uint16_t>(swp[i][g].y >> 16));
                 }
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
@@ -460,7 +476,9 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                 const int m = m0 + r, n = n0 + c * 8;
                 if (m < a.M && n < a.N && (ABL != 5 || a.act == 77)) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * OPITCH + c * 16);
-                    *reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n) = v;
+                    // streaming (nt) store: Y is written once and not re-read by this kernel; keeping 11 MB of dirty
+                    // lines in the L2s only postpones their write-back to the kernel boundary
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n));
                 }
             }
         }
@@ -510,8 +528,8 @@ const GemmConfig g_cfgs[] = {
     MIXQ_CFG(256, 128, 2, 2, 5, 2),     // 5: 4 consumers + 2 loaders
     MIXQ_CFG(256, 128, 4, 2, 5, 4),     // 6: 8 consumers + 4 loaders
     MIXQ_CFG(256, 128, 2, 2, 5, 0),     // 7: 4 consumers self-issuing
-    MIXQ_CFG(128, 192, 2, 2, 5, 2),     // 8: 4 consumers 64 x 96 + 2 loaders
-    MIXQ_CFG(128, 192, 2, 2, 5, 4),     // 9
+    MIXQ_CFG(128, 192, 2, 2, 5, 4),     // 8: 4 consumers 64 x 96 + 4 loaders
+    MIXQ_CFG(128, 192, 2, 2, 5, 2),     // 9: ... + 2 loaders
     MIXQ_CFG(128, 128, 2, 2, 5, 2),     // 10
     MIXQ_CFG(64, 64, 2, 2, 5, 1),       // 11
     MIXQ_CFG(32, 128, 1, 4, 5, 1),      // 12: small-M

@@ -92,6 +92,19 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
     float* red = reinterpret_cast<float*>(smem + mask_words);
     uint16_t* xr = x + static_cast<size_t>(row) * ldx;
 
+    // The row is requested FIRST (16 bytes per lane, all chunks in flight) so the outlier bookkeeping below - index load,
+    // gather, in-place zeroing, LDS bitmask - overlaps the one HBM round trip instead of adding a second one.
+    const int nchunk = K >> 3;
+    const uint4* xv = reinterpret_cast<const uint4*>(xr);
+    uint4 keep[NCH > 0 ? NCH : 1];
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * QT;
+            if (c < nchunk) keep[i] = xv[c];
+        }
+    }
+
     int n = n_cap;
     if (n_dev) { int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
     const bool have_out = (n > 0) && ind != nullptr;
@@ -109,19 +122,14 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
     if (x_out) for (int j = (have_out ? n : 0) + tid; j < ldo; j += QT) x_out[static_cast<size_t>(row) * ldo + j] = 0;
     if (have_out) __syncthreads();
 
-    const int nchunk = K >> 3;
-    const uint4* xv = reinterpret_cast<const uint4*>(xr);
-    uint4 keep[NCH > 0 ? NCH : 1];
     float amax = 0.f;
     if constexpr (NCH > 0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * QT;
             if (c < nchunk) {
-                uint4 v = xv[c];
                 uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
-                amax = fmaxf(amax, amax8_masked(v, m8));
-                keep[i] = v;
+                amax = fmaxf(amax, amax8_masked(keep[i], m8));     // whatever the load saw in a zeroed column is masked
             }
         }
     } else {

@@ -26,7 +26,7 @@ struct Args {
 };
 
 // BM activation rows + BN weight rows, SEG bytes per row and step, NW waves, LOOK stages in flight
-template <int BM, int BN, int SEG, int NW, int LOOK, int LAYOUT, int PATH>
+template <int BM, int BN, int SEG, int NW, int LOOK, int LAYOUT, int PATH, int READS = 0>
 __global__ __launch_bounds__(NW * 64) void feed_kernel(const Args a)
 {
     constexpr int CH = SEG / 16;
@@ -64,13 +64,22 @@ __global__ __launch_bounds__(NW * 64) void feed_kernel(const Args a)
 #pragma unroll
         for (int s = 0; s < LOOK; ++s) stage(s, s);
         int nxt = LOOK % NS;
+        int cur = 0;
         for (int kt = 0; kt < a.nk; ++kt) {
             if (kt + LOOK < a.nk) { stage(nxt, kt + LOOK); wait_vmcnt<LOADS * LOOK>(); }
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
+            if constexpr (READS > 0) {       // concurrent fragment-read traffic: READS x ds_read_b128 per wave and stage
+#pragma unroll
+                for (int r = 0; r < READS; ++r) {
+                    const u32x4 v = *(const u32x4*)(lds + cur * STAGE + ((r * 64 + lane) * 16 + wave * 1024) % STAGE);
+                    acc ^= v[0] ^ v[3];
+                }
+            }
             nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
         }
-        acc = *(uint32_t*)(lds + tid * 4);
+        acc ^= *(uint32_t*)(lds + tid * 4);
     } else {
         u32x4 r[LOOK][LOADS];
 #pragma unroll
@@ -103,12 +112,12 @@ __global__ __launch_bounds__(NW * 64) void feed_kernel(const Args a)
     if (acc == 0x12345678u) a.sink[0] = acc;
 }
 
-template <int BM, int BN, int SEG, int NW, int LOOK, int LAYOUT, int PATH>
+template <int BM, int BN, int SEG, int NW, int LOOK, int LAYOUT, int PATH, int READS = 0>
 void run(const char* name, Args a, int ntiles, int M, int N, int K)
 {
     constexpr int NS = LOOK + 2;
     const size_t shm = (size_t)(BM + BN) * SEG * (PATH == 0 ? NS : 2);
-    auto k = feed_kernel<BM, BN, SEG, NW, LOOK, LAYOUT, PATH>;
+    auto k = feed_kernel<BM, BN, SEG, NW, LOOK, LAYOUT, PATH, READS>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     a.nk = K / SEG;
     a.tiles_m = M / BM;
@@ -135,6 +144,12 @@ int main()
     CHECK(hipMemset(w, 1, (size_t)(N + 256) * K)); CHECK(hipMemset(x, 2, (size_t)M * K));
     Args a{w, x, sink, K, 0, 0};
 #define RUN(BM, BN, SEG, NW, LOOK, LAYOUT, PATH) run<BM, BN, SEG, NW, LOOK, LAYOUT, PATH>(#BM "x" #BN " seg" #SEG " w" #NW " look" #LOOK " layout" #LAYOUT " path" #PATH, a, (M / BM) * (N / BN), M, N, K)
+#define RUNR(BM, BN, SEG, NW, LOOK, LAYOUT, PATH, RD) run<BM, BN, SEG, NW, LOOK, LAYOUT, PATH, RD>(#BM "x" #BN " seg" #SEG " w" #NW " look" #LOOK " layout" #LAYOUT " path" #PATH " reads" #RD, a, (M / BM) * (N / BN), M, N, K)
+    RUNR(256, 128, 64, 8, 3, 1, 0, 0);
+    RUNR(256, 128, 64, 8, 3, 1, 0, 4);
+    RUNR(256, 128, 64, 8, 3, 1, 0, 8);
+    RUNR(256, 128, 64, 8, 3, 1, 0, 16);
+    RUNR(256, 128, 64, 8, 3, 1, 0, 32);
     RUN(256, 128, 64, 8, 3, 0, 0);
     RUN(256, 128, 64, 8, 3, 1, 0);
     RUN(256, 128, 128, 8, 1, 2, 0);
