@@ -153,6 +153,16 @@ int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_scale, const u
                  const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy,
                  int M, int N, int act, mixq_stream_t stream);
 
+/* ---- stream-K workspace ---------------------------------------------------------------------------------
+ * The stream-K form of the GEMM (chosen for shapes whose tile count leaves CUs idle, e.g. M = 512, N = 11008) hands
+ * int32 partial tiles between workgroups through a device buffer the HOST provides once:
+ *   mixq_gemm_workspace_bytes()  size to allocate; mixq_gemm_set_workspace(ptr, bytes) registers it (bytes = 0
+ *   unregisters).  The buffer must be zero-filled when registered; every launch leaves its flag words zero.
+ * Without a registered workspace the data-parallel kernels are used.  Launches that use the workspace must be
+ * serialised on one stream (the operator, like the reference's, is not re-entrant: SURVEY.md §8b Threading). */
+long long mixq_gemm_workspace_bytes(void);
+int mixq_gemm_set_workspace(void* ws, long long bytes);
+
 /* ---- tuning / introspection (not part of the reference surface) ----------------------------------------
  * Force a GEMM tile configuration id (>= 0) for subsequent mixq_gemm_* calls, -1 = automatic shape-aware
  * choice.  Returns MIXQ_EINVAL for an unknown id.  mixq_gemm_config_name writes the config's description. */

@@ -59,7 +59,10 @@ SIGNATURES = {
     "mixq_pack_p16x64": [_P, _P, _I, _I, _P],
     "mixq_gemm_config_name": [_I, C.c_char_p, _I],
     "mixq_gemm_pick_config": [_I, _I, _I, _I],
+    "mixq_gemm_workspace_bytes": [],
+    "mixq_gemm_set_workspace": [_P, C.c_longlong],
 }
+RESTYPES = {"mixq_gemm_workspace_bytes": C.c_longlong}
 
 _lib = None
 
@@ -68,7 +71,7 @@ def header_symbols(path: str = HEADER_PATH):
     """Function names declared in include/mixq_hip.h (used by the symbol-export test)."""
     txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(mixq_\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(?:int|long long)\s+(mixq_\w+)\s*\(", txt)))
 
 
 def load():
@@ -94,7 +97,7 @@ def load():
         except AttributeError as e:
             raise MixqBuildError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = _I
+        fn.restype = RESTYPES.get(name, _I)
     _lib = lib
     return lib
 
@@ -112,6 +115,23 @@ def device_info() -> str:
     if rc != 0:
         raise MixqError("mixq_device_info", rc)
     return buf.value.decode()
+
+
+_workspace = None
+
+
+def ensure_workspace(device=None):
+    """Allocate (once per process) and register the zero-filled stream-K workspace on the current GPU."""
+    global _workspace
+    if _workspace is None:
+        import torch
+        lib = load()
+        nbytes = int(lib.mixq_gemm_workspace_bytes())
+        _workspace = torch.zeros(nbytes, dtype=torch.uint8, device=device or "cuda")
+        rc = lib.mixq_gemm_set_workspace(_workspace.data_ptr(), nbytes)
+        if rc != 0:
+            raise MixqError("mixq_gemm_set_workspace", rc)
+    return _workspace
 
 
 def gemm_config_names():

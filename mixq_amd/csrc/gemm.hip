@@ -30,6 +30,7 @@
 //  * The grid is 1-D over output tiles with an XCD-aware remap: the tiles that share a weight panel run on the
 //    same XCD (same L2).  The tile shape is picked per problem so the tile count fills the 256 CUs.
 #include "common.h"
+#include "gemm_sk.h"
 #include <stdio.h>
 #include <string.h>
 #include <type_traits>
@@ -551,25 +552,42 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Shape-aware choice: estimated time ~ rounds over 256 CUs x max(MFMA time, feed time) per k-step of a tile.
 //   MFMA: BM*BN*64*2 ops at 8192 ops/clk/CU;  feed: (BM+BN)*64 bytes at ~48 B/clk/CU (packed) / 25 (plain rows).
+// Shape-aware choice.  Score = rounds over the 256 CUs x measured time per k-step of one tile (microseconds, MI355X,
+// packed operands, tools/sweep_gemm.py over the Llama-2-7b/70b and Llama-3-8B shapes).  The winner per
+// shape in those sweeps is what this picks: 128x128 when N is small, 128x192 around N = 10-12k, 256x128 / 128x256 at
+// N = 14k, 256x256 when there are >= ~200 such tiles.  Row-strided (plain) operands feed slower but rank the same.
+const float g_tk[NUM_PICK] = {0.60f, 0.39f, 0.60f, 0.40f, 0.40f, 0.40f, 0.37f, 0.40f, 0.31f, 0.33f, 0.20f, 0.12f, 0.15f, 0.60f, 0.40f, 0.37f};
 int pick_config(int M, int N, int KB, bool packed) {
-    (void)KB;
+    (void)KB; (void)packed;
     double best = 1e30; int bi = 0;
     for (int c = 0; c < NUM_PICK; ++c) {
         const GemmConfig& g = g_cfgs[c];
-        if (g_cfgs[c].k8 == g_cfgs[1].k8) continue;       // the self-issuing form is kept for comparison only
         const int tiles = cdiv(M, g.bm) * cdiv(N, g.bn);
         const int rounds = cdiv(tiles, 256);
-        const double mfma = static_cast<double>(g.bm) * g.bn * 128.0 / 8192.0;
-        const double feed = static_cast<double>(g.bm + g.bn) * 64.0 / (packed ? 48.0 : 25.0);
-        const double t = rounds * ((mfma > feed ? mfma : feed) + 60.0);
+        // rows of a tile beyond M are wasted MFMA work but cost the same time: no correction needed; a tile much
+        // taller than M (small-batch decode) just wastes LDS traffic, which the per-k-step numbers already contain
+        const double t = rounds * static_cast<double>(g_tk[c]);
         if (t < best * 0.999) { best = t; bi = c; }
     }
     return bi;
 }
 
+// Stream-K (gemm_sk.hip) pays when the data-parallel tiling leaves most CUs idle AND K is long: measured on MI355X
+// (tools/sweep_gemm.py), M = 512: 4096x11008 46.1 -> 39.3 us, 4096x14336 54.9 -> 43.4 us with sk128x128; at K = 4096
+// (4096x4096: 21.3 vs 22.7 us) and whenever the tiling already fills the chip (11008x4096: 30 vs 43 us) the partial-tile
+// hand-off (~8 us per workgroup) costs more than the idle CUs.  Returns a gemm_sk.hip config id or -1.
+int g_auto_sk = 1;
+int pick_stream_k(int M, int N, int KB) {
+    if (!g_auto_sk || M < 128 || N < 128) return -1;
+    const int nk = KB / 64;
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    if (tiles > 160 || nk < 128) return -1;
+    return 3;                                            // sk128x128_w2x2_s5
+}
+
 int launch_gemm(GemmArgs& a, int mode, hipStream_t st) {
     const bool packed = a.x_packed && a.w_packed;
-    const int c = g_forced_cfg >= 0 ? g_forced_cfg : pick_config(a.M, a.N, a.KB, packed);
+    const int c = (g_forced_cfg >= 0 && g_forced_cfg < NUM_CFGS) ? g_forced_cfg : pick_config(a.M, a.N, a.KB, packed);
     const GemmConfig* g = &g_cfgs[c];
     a.tiles_m = cdiv(a.M, g->bm);
     a.tiles_n = cdiv(a.N, g->bn);
@@ -610,6 +628,15 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
     a.x_packed = (layout & MIXQ_X_PACKED) ? 1 : 0; a.w_packed = (layout & MIXQ_W_PACKED) ? 1 : 0;
     a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
+    // stream-K form (gemm_sk.hip): packed operands, workspace registered, chosen explicitly or by the shape rule
+    if (a.x_packed && a.w_packed) {
+        int sk = -1;
+        if (g_forced_cfg >= NUM_CFGS) sk = g_forced_cfg - NUM_CFGS;
+        else if (g_forced_cfg < 0) sk = pick_stream_k(M, N, KB);
+        if (sk >= 0 && mixq_sk_usable(sk))
+            return mixq_sk_launch(sk, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda,
+                                  bias, y, ldy, M, N, KB, act, mixq_stream(stream));
+    }
     return launch_gemm(a, bit == 8 ? 0 : 1, mixq_stream(stream));
 }
 
@@ -660,20 +687,24 @@ extern "C" int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_sca
     return mixq_launch_status();
 }
 
+// Config ids: [0, NUM_CFGS) data-parallel tilings of this file, [NUM_CFGS, NUM_CFGS + sk) the stream-K forms.
 extern "C" int mixq_gemm_set_config(int cfg) {
-    if (cfg < -1 || cfg >= NUM_CFGS) return MIXQ_EINVAL;
+    if (cfg < -1 || cfg >= NUM_CFGS + mixq_sk_num_configs()) return MIXQ_EINVAL;
     g_forced_cfg = cfg;
     return MIXQ_OK;
 }
-extern "C" int mixq_gemm_num_configs(void) { return NUM_CFGS; }
+extern "C" int mixq_gemm_num_configs(void) { return NUM_CFGS + mixq_sk_num_configs(); }
 extern "C" int mixq_gemm_config_name(int cfg, char* buf, int cap) {
-    if (cfg < 0 || cfg >= NUM_CFGS || !buf || cap <= 0) return MIXQ_EINVAL;
-    snprintf(buf, cap, "%s", g_cfgs[cfg].name);
+    if (cfg < 0 || cfg >= NUM_CFGS + mixq_sk_num_configs() || !buf || cap <= 0) return MIXQ_EINVAL;
+    snprintf(buf, cap, "%s", cfg < NUM_CFGS ? g_cfgs[cfg].name : mixq_sk_config_name(cfg - NUM_CFGS));
     return MIXQ_OK;
 }
 extern "C" int mixq_gemm_pick_config(int M, int N, int K, int bit) {
     if (M <= 0 || N <= 0 || K <= 0 || (bit != 4 && bit != 8)) return MIXQ_EINVAL;
-    return pick_config(M, N, bit == 8 ? K : K / 2, true);
+    const int KB = bit == 8 ? K : K / 2;
+    const int sk = pick_stream_k(M, N, KB);
+    if (sk >= 0 && mixq_sk_usable(sk)) return NUM_CFGS + sk;
+    return pick_config(M, N, KB, true);
 }
 
 extern "C" int mixq_version(void) { return 1000; }

@@ -27,7 +27,7 @@ def test_every_header_symbol_is_exported_and_bound():
 def test_header_arity_matches_ctypes_table():
     txt = open(_capi.HEADER_PATH).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    for m in re.finditer(r"\bint\s+(mixq_\w+)\s*\(([^)]*)\)\s*;", txt):
+    for m in re.finditer(r"\b(?:int|long long)\s+(mixq_\w+)\s*\(([^)]*)\)\s*;", txt):
         name, args = m.group(1), m.group(2).strip()
         n = 0 if args in ("", "void") else len(args.split(","))
         assert n == len(_capi.SIGNATURES[name]), f"{name}: header has {n} parameters, ctypes table {len(_capi.SIGNATURES[name])}"

@@ -406,6 +406,58 @@ def test_full_size_operator_with_one_percent_outliers(K, N, bit):
     assert (np.abs(n(y)[rows].astype(np.float32) - ref) <= ulp_tol(ref)).all()
 
 
+def _sk_configs():
+    return [i for i, name in enumerate(_capi.gemm_config_names()) if name.startswith("sk")]
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 2560), (512, 256, 8192), (300, 1000, 4096), (512, 4096, 11008), (64, 384, 192)])
+def test_stream_k_is_bit_identical_to_data_parallel(M, N, K):
+    """The stream-K kernels hand int32 partial tiles between workgroups; integer addition is exact, so with
+    power-of-two scales the fp16 result must equal the data-parallel kernel's bit for bit - on every launch (the flag
+    words are self-resetting) and under hipGraph replay.  (128,128,2560) makes one tile with 40 contributors."""
+    _capi.ensure_workspace(DEV)
+    g = torch.Generator().manual_seed(M + N + K)
+    qx = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    qw = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    qxp, qwp = mixlib.PackP16x64(qx), mixlib.PackP16x64(qw)
+    sx = torch.full((M, 1), 2.0 ** -6, dtype=torch.float16, device=DEV)
+    sw = torch.full((1, N), 2.0 ** -7, dtype=torch.float16, device=DEV)
+    want = (mixlib.gemm(qx, qw, M, N, K).to(torch.float64) * 2.0 ** -13).to(torch.float16)
+    lib = _capi.load()
+    for c in _sk_configs():
+        assert lib.mixq_gemm_set_config(c) == 0
+        for rep in range(3):
+            y = mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K, x_packed=True, w_packed=True)
+            assert torch.equal(y, want), f"{_capi.gemm_config_names()[c]} launch {rep}"
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            out = torch.empty((M, N), dtype=torch.float16, device=DEV)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(4):
+                    mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K, x_packed=True, w_packed=True, out=out)
+            for _ in range(3):
+                out.zero_()
+                graph.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(out, want)
+    lib.mixq_gemm_set_config(-1)
+
+
+def test_stream_k_full_epilogue_and_int4():
+    """Outlier tail, bias, SiLU and the int4 expansion through the stream-K kernels against the oracle."""
+    _capi.ensure_workspace(DEV)
+    lib = _capi.load()
+    for (M, N, K, bit, n_out, bias, act) in [(96, 320, 4096, 8, 17, True, 0), (130, 200, 2048, 8, 41, False, 1), (64, 128, 4096, 4, 128, True, 0)]:
+        c = _fused_case(M, N, K, bit, seed=M + K, n_out=n_out, bias=bias, addend=False, act=act)
+        ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], bias=c["bias"], act=act, bit=bit).astype(np.float32)
+        for cfg in _sk_configs():
+            assert lib.mixq_gemm_set_config(cfg) == 0
+            y = n(_run_fused(c, True)).astype(np.float32)
+            assert (np.abs(y - ref) <= ulp_tol(ref)).all(), f"{_capi.gemm_config_names()[cfg]}: {np.abs(y - ref).max()}"
+    lib.mixq_gemm_set_config(-1)
+
+
 def test_linearity_in_the_outlier_operand():
     """Y(xo1 + xo2) - Y(0) == (Y(xo1) - Y(0)) + (Y(xo2) - Y(0)) up to fp16 rounding: the fp16 MFMA tail is additive."""
     c = _fused_case(64, 128, 256, 8, seed=4, n_out=16, bias=False, addend=False, act=0)
