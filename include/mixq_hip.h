@@ -153,6 +153,22 @@ int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_scale, const u
                  const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy,
                  int M, int N, int act, mixq_stream_t stream);
 
+/* ---- RMSNorm in front of the path -----------------------------------------------------
+ * mixq_rmsnorm replaces mixlib.layernorm_forward_cuda(x, weight, out, eps)                         (norm.py:21)
+ * mixq_rmsnorm_quant_fused replaces mixlib.layernorm_forward_cuda_extract_outliers[_int4](x, weight, out, eps, ind,
+ *   x_scale) -> (X_out, q_x)  (norm.py:24-33): out = RMSNorm(x) with the NEXT linear's known outlier columns `ind`
+ *   zeroed, x_out[m,j] = the normalised value of column ind[j], x_scale/q of the zeroed row, misprediction flag, q
+ *   plain or P16x64 - the activation is read once.  x is not modified.
+ * Arithmetic: y = fp16((float(x) * inv_rms) * float(weight)), inv_rms = 1/sqrt(mean(x^2) + eps) in fp32 with the fixed
+ * summation order documented in mixq_amd/csrc/norm.hip (restated by the oracle, so results are bit-reproducible).
+ *   x fp16 [M,K] ldx, weight fp16 [K], out fp16 [M,K] ldout; K % 8 == 0, K <= 32768. */
+int mixq_rmsnorm(const uint16_t* x, const uint16_t* weight, uint16_t* out, int M, int K, int ldx, int ldout, float eps,
+                 mixq_stream_t stream);
+int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
+                             const int32_t* n_dev, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
+                             int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma, int qfmt,
+                             mixq_stream_t stream);
+
 /* ---- stream-K workspace ---------------------------------------------------------------------------------
  * The stream-K form of the GEMM (chosen for shapes whose tile count leaves CUs idle, e.g. M = 512, N = 11008) hands
  * int32 partial tiles between workgroups through a device buffer the HOST provides once:

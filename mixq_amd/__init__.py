@@ -7,7 +7,8 @@ Public surface (mirrors the reference operator API):
 from .cache import MixLibCache, MLPCache
 from .linear import MixLinear_GEMM, MixQLinear, pack_to_i4, two_compl, unpack_int8_to_int4
 from . import mixlib
+from .fused import FasterTransformerRMSNorm, MixLlamaMLP
 
 __all__ = ["MixLinear_GEMM", "MixQLinear", "MixLibCache", "MLPCache", "pack_to_i4", "two_compl", "unpack_int8_to_int4",
-           "mixlib"]
+           "mixlib", "FasterTransformerRMSNorm", "MixLlamaMLP"]
 __version__ = "0.1.0"

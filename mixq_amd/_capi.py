@@ -59,6 +59,8 @@ SIGNATURES = {
     "mixq_pack_p16x64": [_P, _P, _I, _I, _P],
     "mixq_gemm_config_name": [_I, C.c_char_p, _I],
     "mixq_gemm_pick_config": [_I, _I, _I, _I],
+    "mixq_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "mixq_rmsnorm_quant_fused": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
     "mixq_gemm_workspace_bytes": [],
     "mixq_gemm_set_workspace": [_P, C.c_longlong],
 }

@@ -1,0 +1,66 @@
+"""The two modules either side of the path, mirrored from the reference so its Llama glue
+(`mixquant/models/llama.py:10-22,173-178`) can wire them unchanged:
+
+  FasterTransformerRMSNorm  (mixquant/modules/fused/norm.py:6-39): RMSNorm whose `next_layer` (the fused QKV or the up
+      projection) gets its activation extracted + quantised in the same pass, so that linear runs with unfused=False.
+  MixLlamaMLP               (mixquant/modules/fused/mlp.py:37-70): up_proj, the SiLU-fused gate_proj sharing up_proj's
+      quantised activation, elementwise product, down_proj(unfused=True).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import mixlib as _hip_mixlib
+
+_backend = _hip_mixlib
+
+
+def set_backend(mod):
+    global _backend
+    prev, _backend = _backend, mod
+    return prev
+
+
+class FasterTransformerRMSNorm(nn.Module):
+    def __init__(self, weight, eps=1e-6, cache=None):
+        super().__init__()
+        self.weight = weight.to(torch.float16)
+        self.variance_epsilon = eps
+        self.cache = cache
+        self.next_layer = None
+
+    @torch.no_grad()
+    def forward(self, x):
+        output = torch.empty_like(x)
+        nl = self.next_layer
+        if nl is None:
+            _backend.layernorm_forward_cuda(x, self.weight, output, self.variance_epsilon)
+            return output
+        if nl.bit not in (4, 8):
+            raise NotImplementedError
+        cache = self.cache
+        packed = hasattr(nl, "_packed_weight") and nl._packed_weight() is not None and hasattr(_backend, "PackP16x64")
+        ind = nl.ind if nl.ind.shape[0] else None
+        q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
+                                           sigma=getattr(cache, "sigma_value", 6.0), packed=packed)
+        cache.q_xcache, cache.q_xcache_packed = q, packed
+        cache.activation_outliers = xo
+        return output
+
+
+class MixLlamaMLP(nn.Module):
+    def __init__(self, gate_proj, down_proj, up_proj, MixGemmCache=None):
+        super().__init__()
+        self.down_proj_ = down_proj
+        self.gate_proj_ = gate_proj
+        self.up_proj_ = up_proj
+        self.out_features = down_proj.out_features
+        self.MLPCache = MixGemmCache
+
+    @torch.no_grad()
+    def forward(self, x):
+        up_output = self.up_proj_(x, self.MLPCache)
+        gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache)
+        gate_output *= up_output
+        return self.down_proj_(gate_output, None, True)

@@ -264,3 +264,54 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
                _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act,
                (X_PACKED if x_packed else 0) | (W_PACKED if w_packed else 0), _stream())
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------
+# RMSNorm in front of the path (mixquant/modules/fused/norm.py:21-33)
+# ------------------------------------------------------------------------------------------------------------
+def layernorm_forward_cuda(x, weight, out, eps):
+    """mixlib.layernorm_forward_cuda(x, weight, out, eps): out = RMSNorm(x) * weight (FasterTransformer form)."""
+    _dev_check(x, weight, out)
+    K = x.shape[-1]
+    x2, o2 = x.reshape(-1, K), out.reshape(-1, K)
+    xp, ldx = _rows(x2, "x")
+    op, ldo = _rows(o2, "out")
+    _capi.call("mixq_rmsnorm", xp, weight.data_ptr(), op, x2.shape[0], K, ldx, ldo, float(eps), _stream())
+    return out
+
+
+def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=None, packed=False):
+    """RMSNorm fused with the next linear's extract + zero + scale + quantise.  Returns (q_x, x_out_view[M,n])."""
+    _dev_check(x, weight, out, x_scale, ind)
+    K = x.shape[-1]
+    x2, o2 = x.reshape(-1, K), out.reshape(-1, K)
+    xp, ldx = _rows(x2, "x")
+    op, ldo = _rows(o2, "out")
+    M = x2.shape[0]
+    n = 0 if ind is None else ind.numel()
+    q = torch.empty((packed_rows(M) if packed else M, K if bit == 8 else K // 2),
+                    dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
+    if n:
+        x_out = torch.empty((M, (n + 15) // 16 * 16), dtype=torch.float16, device=x.device)
+        xop, ldxo, ip = x_out.data_ptr(), x_out.stride(0), ind.data_ptr()
+    else:
+        x_out, xop, ldxo, ip = None, None, 0, None
+    _capi.call("mixq_rmsnorm_quant_fused", xp, weight.data_ptr(), op, ip, n, None, x_scale.data_ptr(), q.data_ptr(), xop,
+               _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), FMT_P16X64 if packed else FMT_PLAIN, _stream())
+    return q, (x_out[:, :n] if n else None)
+
+
+def layernorm_forward_cuda_extract_outliers(x, weight, out, eps, ind, x_scale):
+    """mixlib.layernorm_forward_cuda_extract_outliers(x, w, out, eps, ind, x_scale) -> (X_out, q_x) (norm.py:25-28)."""
+    q, xo = RMSNormQuantFused(x, weight, out, eps, ind, x_scale, 8)
+    if xo is None:
+        xo = torch.empty((q.shape[0], 0), dtype=torch.float16, device=x.device)
+    return xo, q
+
+
+def layernorm_forward_cuda_extract_outliers_int4(x, weight, out, eps, ind, x_scale):
+    """mixlib.layernorm_forward_cuda_extract_outliers_int4 (norm.py:30-33)."""
+    q, xo = RMSNormQuantFused(x, weight, out, eps, ind, x_scale, 4)
+    if xo is None:
+        xo = torch.empty((q.shape[0], 0), dtype=torch.float16, device=x.device)
+    return xo, q

@@ -292,3 +292,53 @@ void orc_linear_dequant_ref(const int8_t* qx, const int8_t* qw, const uint16_t* 
         free(xr);
     }
 }
+
+/* ---- §8f row 1: FasterTransformer RMSNorm (+ fused extract / quantise for the next linear) ----------------------
+ * Call sites mixquant/modules/fused/norm.py:21-33 (mixlib.layernorm_forward_cuda and
+ * mixlib.layernorm_forward_cuda_extract_outliers[_int4]); the kernels themselves are not in /root/reference, so the
+ * arithmetic is fixed by decision (see mixq_amd/csrc/norm.hip) and restated here INCLUDING the summation order of the
+ * 256-thread kernel, which makes the GPU result reproducible bit for bit:
+ *   thread t accumulates chunks t, t+256, ... (8 elements each, in order) with fmaf; per 64-lane wave a butterfly
+ *   (xor 32,16,8,4,2,1); then (w0+w1)+(w2+w3);  inv = 1/sqrt(ss/K + eps);  y = fp16((x*inv)*w). */
+static float rms_inv(const uint16_t* xr, int K, float eps)
+{
+    float part[256];
+    const int nchunk = K / 8;
+    for (int t = 0; t < 256; ++t) {
+        float s = 0.f;
+        for (int c = t; c < nchunk; c += 256)
+            for (int e = 0; e < 8; ++e) { float v = h2f(xr[c * 8 + e]); s = fmaf(v, v, s); }
+        part[t] = s;
+    }
+    float wsum[4];
+    for (int w = 0; w < 4; ++w) {
+        float a[64], b[64];
+        for (int l = 0; l < 64; ++l) a[l] = part[w * 64 + l];
+        for (int o = 32; o > 0; o >>= 1) {
+            for (int l = 0; l < 64; ++l) b[l] = a[l] + a[l ^ o];
+            memcpy(a, b, sizeof(a));
+        }
+        wsum[w] = a[0];
+    }
+    float total = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    return 1.0f / sqrtf(total / (float)K + eps);
+}
+
+void orc_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int M, int K, int ldx, int ldout, float eps)
+{
+    for (int m = 0; m < M; ++m) {
+        const uint16_t* xr = x + (size_t)m * ldx;
+        float inv = rms_inv(xr, K, eps);
+        for (int k = 0; k < K; ++k) out[(size_t)m * ldout + k] = f2h((h2f(xr[k]) * inv) * h2f(w[k]));
+    }
+}
+
+/* out = RMSNorm(x) with the columns `ind` zeroed; x_out[m,j] = the normalised value of column ind[j]; x_scale / q from
+ * the zeroed row as orc_find_row_scale does.  x itself is not modified. */
+void orc_rmsnorm_quant(const uint16_t* x, const uint16_t* w, uint16_t* out, const int32_t* ind, int n, uint16_t* x_scale,
+                       void* q, uint16_t* x_out, int M, int K, int ldx, int ldout, int ldxo, float eps, int bit)
+{
+    orc_rmsnorm(x, w, out, M, K, ldx, ldout, eps);
+    orc_extract_outliers_zero(out, ind, n, x_out, M, K, ldout, ldxo);
+    orc_find_row_scale(out, x_scale, q, M, K, ldout, bit);
+}

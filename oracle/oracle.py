@@ -211,3 +211,27 @@ def unpack_i4_all(packed):
     out[:, 0::2] = lo
     out[:, 1::2] = hi
     return out
+
+
+def rmsnorm(x, w, eps):
+    """mixlib.layernorm_forward_cuda (norm.py:21) -> fp16 [M,K]."""
+    x, w = _h(x), _h(w).reshape(-1)
+    M, K = x.shape
+    out = np.empty((M, K), dtype=np.float16)
+    lib().orc_rmsnorm(_p(x), _p(w), _p(out), M, K, K, K, C.c_float(eps))
+    return out
+
+
+def rmsnorm_quant(x, w, eps, ind, bit):
+    """mixlib.layernorm_forward_cuda_extract_outliers[_int4] (norm.py:24-33) -> (out, x_out [M,n], q, x_scale [M])."""
+    x, w = _h(x), _h(w).reshape(-1)
+    ind = np.ascontiguousarray(ind, dtype=np.int32)
+    M, K = x.shape
+    n = int(ind.size)
+    out = np.empty((M, K), dtype=np.float16)
+    xo = np.empty((M, n), dtype=np.float16)
+    s = np.empty(M, dtype=np.float16)
+    q = np.empty((M, K) if bit == 8 else (M, K // 2), dtype=np.int8 if bit == 8 else np.uint8)
+    lib().orc_rmsnorm_quant(_p(x), _p(w), _p(out), _p(ind), n, _p(s), _p(q), _p(xo) if n else None, M, K, K, K, n,
+                            C.c_float(eps), bit)
+    return out, xo, q, s

@@ -71,3 +71,26 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
     y = O.linear_fused(_np(q_x), _np(q_w), _np(x_scale.reshape(-1)[0:M]), _np(scale_col), xo=xo, wo=wo,
                        addend=None if addend is None else _np(addend), bias=None if bias is None else _np(bias), act=act, bit=bit)
     return torch.from_numpy(y)
+
+
+def layernorm_forward_cuda(x, weight, out, eps):
+    calls.append("layernorm_forward_cuda")
+    K = x.shape[-1]
+    y = O.rmsnorm(_np(x.reshape(-1, K)), _np(weight), eps)
+    out.reshape(-1, K).copy_(torch.from_numpy(y))
+    return out
+
+
+def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=None, packed=False):
+    calls.append("RMSNormQuantFused")
+    assert not packed
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    idx = np.zeros(0, np.int32) if ind is None else _np(ind)
+    y, xo, q, s = O.rmsnorm_quant(_np(x2), _np(weight), eps, idx, bit)
+    out.reshape(-1, K).copy_(torch.from_numpy(y))
+    x_scale.reshape(-1)[0:M] = torch.from_numpy(s)
+    if flag is not None and O.mispredicted(s, sigma, bit):
+        flag |= 1
+    return torch.from_numpy(q), (torch.from_numpy(xo) if idx.size else None)

@@ -406,6 +406,77 @@ def test_full_size_operator_with_one_percent_outliers(K, N, bit):
     assert (np.abs(n(y)[rows].astype(np.float32) - ref) <= ulp_tol(ref)).all()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# RMSNorm (+ fused extract / quantise) - bit-exact against the oracle's restatement
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K", [(1, 64), (7, 512), (33, 4096), (16, 8192), (5, 11008), (3, 28672)])
+def test_rmsnorm_bit_exact(M, K):
+    rng = np.random.default_rng(M + K)
+    x = (rng.standard_normal((M, K)) * 2.5).astype(np.float16)
+    x[0] = 0
+    w = (1 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    out = torch.empty((M, K), dtype=torch.float16, device=DEV)
+    mixlib.layernorm_forward_cuda(t(x), t(w), out, 1e-6)
+    assert np.array_equal(bits(n(out)), bits(O.rmsnorm(x, w, 1e-6)))
+
+
+@pytest.mark.parametrize("M,K,ncols,bit", [(8, 64, 0, 8), (32, 512, 3, 8), (64, 4096, 41, 8), (12, 8192, 128, 8), (24, 4096, 128, 4),
+                                            (5, 1024, 7, 4)])
+def test_rmsnorm_quant_fused_bit_exact(M, K, ncols, bit):
+    rng = np.random.default_rng(K + ncols + bit)
+    ind = rng.permutation(K)[:ncols].astype(np.int32)
+    x = (rng.standard_normal((M, K)) * 1.5).astype(np.float16)
+    x[:, ind] *= 30
+    w = (1 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    y_ref, xo_ref, q_ref, s_ref = O.rmsnorm_quant(x, w, 1e-5, ind, bit)
+    xt = t(x)
+    for packed in (False, True):
+        KB = K if bit == 8 else K // 2
+        if packed and KB % 64:
+            continue
+        out = torch.empty((M, K), dtype=torch.float16, device=DEV)
+        xs = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        q, xo = mixlib.RMSNormQuantFused(xt, t(w), out, 1e-5, t(ind) if ncols else None, xs, bit, sigma=6.0, flag=flag, packed=packed)
+        assert np.array_equal(bits(n(xt)), bits(x)), "the norm must not modify its input"
+        assert np.array_equal(bits(n(out)), bits(y_ref))
+        assert np.array_equal(bits(n(xs)[:, 0]), bits(s_ref))
+        got_q = p16x64_unpack(n(q).reshape(-1).view(np.uint8), M, KB) if packed else n(q).view(np.uint8)
+        assert np.array_equal(got_q, q_ref.view(np.uint8))
+        if ncols:
+            assert np.array_equal(bits(n(xo)), bits(xo_ref)) and xo.stride(0) % 16 == 0
+        assert bool(flag.item()) == O.mispredicted(s_ref, 6.0, bit)
+    # the reference-named entry points return (X_out, q_x) in that order (norm.py:25-33)
+    out = torch.empty((M, K), dtype=torch.float16, device=DEV)
+    xs = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+    fn = mixlib.layernorm_forward_cuda_extract_outliers if bit == 8 else mixlib.layernorm_forward_cuda_extract_outliers_int4
+    xo2, q2 = fn(xt, t(w), out, 1e-5, t(ind), xs)
+    assert np.array_equal(n(q2).view(np.uint8), q_ref.view(np.uint8)) and tuple(xo2.shape) == (M, ncols)
+
+
+def test_fused_norm_then_linear_on_gpu():
+    """norm.next_layer = W_pack; W_pack(hidden) with unfused=False equals plain norm + unfused linear (attn.py:219)."""
+    from mixq_amd import FasterTransformerRMSNorm
+    torch.manual_seed(0)
+    K, N, M = 4096, 512, 64
+    lin = torch.nn.Linear(K, N, bias=False).half()
+    cache, cache2 = MixLibCache(M, device=DEV), MixLibCache(M, device=DEV)
+    a = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
+    b = MixLinear_GEMM.from_linear(lin, 8, cache=cache2, dev=DEV)
+    wn = (torch.ones(K) + 0.1 * torch.randn(K)).to(DEV)
+    norm = FasterTransformerRMSNorm(wn, eps=1e-6, cache=cache)
+    norm.next_layer = a
+    plain = FasterTransformerRMSNorm(wn, eps=1e-6)
+    cols = torch.randperm(K)[:41]
+    for call in range(3):
+        h = torch.randn(M, K, generator=torch.Generator().manual_seed(call)).half()
+        h[:, cols] *= 25
+        y = a(norm(h.to(DEV)), None, False)
+        y_ref = b(plain(h.to(DEV)), None, True)
+        assert torch.equal(y, y_ref)
+    assert torch.equal(a.ind, b.ind) and a.ind.numel() == 41 and a.add_outliers is False
+
+
 def _sk_configs():
     return [i for i, name in enumerate(_capi.gemm_config_names()) if name.startswith("sk")]
 
