@@ -183,6 +183,11 @@ int mixq_gemm_set_workspace(void* ws, long long bytes);
  * Force a GEMM tile configuration id (>= 0) for subsequent mixq_gemm_* calls, -1 = automatic shape-aware
  * choice.  Returns MIXQ_EINVAL for an unknown id.  mixq_gemm_config_name writes the config's description. */
 int mixq_gemm_set_config(int cfg);
+/* Diagnostics: when buf is non-null every workgroup of the data-parallel fused GEMM writes 16 x u64 to
+ * buf[16 * workgroup + i]: i in 0..7 = the 100 MHz device wall clock at 0 entry, 1 first stage landed, 2 k loop
+ * done, 3 epilogue arithmetic done, 4 stores issued, 5 stores retired, 6/7 inside the epilogue; 8 + i = s_memtime
+ * at the same points.  buf needs 128 bytes per workgroup (tools/trace_gemm.py). */
+int mixq_gemm_set_trace(unsigned long long* buf);
 int mixq_gemm_num_configs(void);
 int mixq_gemm_config_name(int cfg, char* buf_host, int cap);
 /* The config the automatic choice picks for (M,N,K,bit). */

@@ -13,6 +13,7 @@ typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4  __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2  __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_u __attribute__((aligned(2)));   // fp16-aligned access to 4 halves
 
 #define MIXQ_WAVE 64
 

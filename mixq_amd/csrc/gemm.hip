@@ -50,6 +50,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int x_packed, w_packed;                           // operand stored in the P16x64 tile-major layout
     int xrows16, wrows16;                             // rows rounded up to 16 (packed operands)
+    unsigned long long* trace;                        // diagnostics: 2 x 8 timestamps per workgroup, or null
 };
 
 constexpr int BKB = 64;                               // bytes of K per stage and row
@@ -66,7 +67,7 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
 // physical 16-byte chunk of logical chunk c in row r (an involution in c for fixed r)
 __device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 2) & 3); }
 
-__device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   // 1-ulp rcp: below fp16 resolution
 
 // BM: activation rows per tile, BN: weight rows per tile, WAVES_M x WAVES_N consumer waves, NSTAGE ring depth,
 // MODE 0: int8 fused epilogue, 1: int4 fused epilogue, 2: int8 raw int32 output.  LOADERS: dedicated DMA waves
@@ -109,6 +110,15 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
     const int nk = a.KB / BKB;
+    auto stamp = [&](int slot) {                         // diagnostics only (mixq_gemm_set_trace)
+        if (a.trace && tid == 0) {
+            a.trace[blockIdx.x * 16 + slot] = wall_clock64();
+            a.trace[blockIdx.x * 16 + 8 + slot] = __builtin_readcyclecounter();   // s_memtime
+        }
+    };
+    stamp(0);
+    int n_out_dev_v = 0;                                 // requested now, consumed by the epilogue
+    if constexpr (MODE != 2) { if (a.n_out_dev) n_out_dev_v = *a.n_out_dev; }
 
     // ---- DMA piece table of an issuing wave ------------------------------------------------------------------
     // Plain [R,KB] operands: a 1-KiB piece is 16 rows x 64 B with the XOR swizzle on the SOURCE chunk.
@@ -229,52 +239,83 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
         // One region = the MFMAs of fragment set P with (a) ND_ reads of the other set and (b) NG_ DMA pieces issued
         // in the gaps behind the MFMAs, in exactly this program order (sched_barrier(0) pins it): an MFMA keeps the
         // matrix pipe busy for 32 cycles while the wave issues the next LDS reads (and DMA pieces when LOADERS = 0).
+        // W4A4: 16 packed bytes = 32 int4.  Even columns (low nibbles) and odd columns (high nibbles) become two int8
+        // fragments holding 16*v (A and B split identically, so the k pairing is preserved).  The expansion of the set
+        // read in this region is spread behind this region's MFMAs (3 VALU per dword) so it never stands in front of them.
+        i32x4 cwl[2][I4 ? NI : 1], cwh[2][I4 ? NI : 1], cxl[2][I4 ? MI : 1], cxh[2][I4 ? MI : 1];
+        if constexpr (I4 && ABL != 0 && ABL != 5) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) { cwl[p][i] = cwh[p][i] = i32x4{lane, lane, lane, lane}; asm volatile("" : "+v"(cwl[p][i]), "+v"(cwh[p][i])); }
+#pragma unroll
+                for (int j = 0; j < MI; ++j) { cxl[p][j] = cxh[p][j] = i32x4{lane, 1, lane, 1}; asm volatile("" : "+v"(cxl[p][j]), "+v"(cxh[p][j])); }
+            }
+        }
+        uint32_t nib = 0xf0f0f0f0u;                          // kept in an SGPR: a literal would double every v_and's size
+        if constexpr (I4) asm volatile("s_mov_b32 %0, 0xf0f0f0f0" : "=s"(nib));
+        auto convert_dword = [&](int p, int idx, int d) {     // idx in the order of load_one
+            if constexpr (I4) {
+                if (idx == 0 || idx > MI) {
+                    const int i = idx == 0 ? 0 : idx - MI;
+                    const uint32_t v = static_cast<uint32_t>(wf[p][i][d]);
+                    cwl[p][i][d] = static_cast<int>((v << 4) & nib);
+                    cwh[p][i][d] = static_cast<int>(v & nib);
+                } else {
+                    const int j = idx - 1;
+                    const uint32_t v = static_cast<uint32_t>(xf[p][j][d]);
+                    cxl[p][j][d] = static_cast<int>((v << 4) & nib);
+                    cxh[p][j][d] = static_cast<int>(v & nib);
+                }
+            }
+        };
         auto region = [&](auto p_c, auto nd_c, auto ng_c, int rbuf, int rsub, int dma_buf) {
             constexpr int P = decltype(p_c)::value, ND_ = decltype(nd_c)::value, NG_ = decltype(ng_c)::value;
             constexpr int NM = NI * MI, SL = NM > 1 ? NM - 1 : 1;
             uint8_t* dbase = lds + dma_buf * STAGE_BYTES;
-            i32x4 wl[NI], wh[NI], xl[MI], xh[MI];
-            if constexpr (I4) {
-                // 16 packed bytes = 32 int4: even columns (low nibbles) and odd columns (high nibbles) become two int8
-                // fragments holding 16*v; A and B use the same split so the k pairing is preserved.
+            if constexpr (!I4) {
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const uint32_t v = static_cast<uint32_t>(wf[P][i][d]);
-                        wl[i][d] = static_cast<int>((v << 4) & 0xf0f0f0f0u);
-                        wh[i][d] = static_cast<int>(v & 0xf0f0f0f0u);
-                    }
-#pragma unroll
-                for (int j = 0; j < MI; ++j)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const uint32_t v = static_cast<uint32_t>(xf[P][j][d]);
-                        xl[j][d] = static_cast<int>((v << 4) & 0xf0f0f0f0u);
-                        xh[j][d] = static_cast<int>(v & 0xf0f0f0f0u);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const int i = m / MI, j = m % MI;
-                if constexpr (ABL != 1) {
-                    if constexpr (!I4) {
+                for (int m = 0; m < NM; ++m) {
+                    const int i = m / MI, j = m % MI;
+                    if constexpr (ABL != 1)
                         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[P][i], xf[P][j], acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wl[i], xl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh[i], xh[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m < SL) {
+                        if constexpr (ABL != 2 && ABL != 3 && NG_ > 0) {
+#pragma unroll
+                            for (int g = (NG_ * m) / SL; g < (NG_ * (m + 1)) / SL; ++g) { glds16(nsrc[g], dbase + piece[g] * 1024); nsrc[g] += kstr[g]; }
+                        }
+                        if constexpr (ABL != 1 && ABL != 3) {
+#pragma unroll
+                            for (int d = (ND_ * m) / SL; d < (ND_ * (m + 1)) / SL; ++d) load_one(1 - P, rbuf, rsub, d);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (m < SL) {
-                    if constexpr (ABL != 2 && ABL != 3 && NG_ > 0) {
+            } else {
+                // 2*NM MFMA slots: one LDS read behind each of the first ND_ MFMAs, the DMA pieces with them, then the
+                // dword-wise expansion of what was just read, spread over the remaining slots (CS = first expansion slot).
+                constexpr int NS2 = 2 * NM, CS = (NS2 > 5) ? 4 : NS2 - 1, NCV = ND_ * 4;
 #pragma unroll
-                        for (int g = (NG_ * m) / SL; g < (NG_ * (m + 1)) / SL; ++g) { glds16(nsrc[g], dbase + piece[g] * 1024); nsrc[g] += kstr[g]; }
+                for (int mm = 0; mm < NS2; ++mm) {
+                    const int m = mm % NM, i = m / MI, j = m % MI;     // all low-nibble MFMAs, then all high-nibble ones:
+                    if constexpr (ABL != 1) {                         // consecutive MFMAs never share an accumulator
+                        if (mm < NM) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cwl[P][i], cxl[P][j], acc[i][j], 0, 0, 0);
+                        else               acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cwh[P][i], cxh[P][j], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (ABL != 2 && ABL != 3 && NG_ > 0) {
+                        if (mm < NS2 - 1) {
+#pragma unroll
+                            for (int g = (NG_ * mm) / (NS2 - 1); g < (NG_ * (mm + 1)) / (NS2 - 1); ++g) { glds16(nsrc[g], dbase + piece[g] * 1024); nsrc[g] += kstr[g]; }
+                        }
                     }
                     if constexpr (ABL != 1 && ABL != 3) {
+                        if (mm < ND_) load_one(1 - P, rbuf, rsub, mm);
+                        if (mm >= CS && NCV > 0) {
 #pragma unroll
-                        for (int d = (ND_ * m) / SL; d < (ND_ * (m + 1)) / SL; ++d) load_one(1 - P, rbuf, rsub, d);
+                            for (int g = (NCV * (mm - CS)) / (NS2 - CS); g < (NCV * (mm - CS + 1)) / (NS2 - CS); ++g) convert_dword(1 - P, g >> 2, g & 3);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -296,9 +337,14 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
             if (NEWER < nk) wait_vmcnt<LOADS * NEWER>(); else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
+        stamp(1);
         if constexpr (ABL != 1 && ABL != 3) {
 #pragma unroll
             for (int d = 0; d < NI + MI; ++d) load_one(0, 0, 0, d);
+            if constexpr (I4) {
+#pragma unroll
+                for (int g = 0; g < (NI + MI) * 4; ++g) convert_dword(0, g >> 2, g & 3);
+            }
         }
         int cur = 0, nxt = LOOK % NSTAGE;                // ring slots of stage kt and stage kt+LOOK
         // one k-step; ISSUE: DMA stage kt+LOOK from this wave, NEXT: a stage kt+1 exists.
@@ -332,24 +378,19 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 const int m = m0 + xrow[j];
-                sxh[j] = (m < a.M) ? a.sx[m] : static_cast<uint16_t>(0);
+                sxh[j] = a.sx[m < a.M ? m : a.M - 1];     // rows past M are computed but never stored
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < 4; ++g) {             // N % 4 == 0: a group of 4 columns is all in or all out
                     const int n = n0 + wn * WN + i * 32 + 4 * lh + 8 * g;
-                    if (n + 3 < a.N) swp[i][g] = *reinterpret_cast<const u32x2*>(a.sw + n);
-                    else {
-                        uint32_t h[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = (n + e < a.N) ? a.sw[n + e] : 0u;
-                        swp[i][g] = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-                    }
+                    swp[i][g] = *reinterpret_cast<const u32x2_u*>(a.sw + (n < a.N ? n : a.N - 4));
                 }
         }
         for (; kt + 1 < nk; ++kt) body(std::false_type{}, std::true_type{});
         body(std::false_type{}, std::false_type{});
+        stamp(2);
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------
@@ -381,93 +422,148 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
         const bool staged = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
         if (LOADERS == 0 || wave < CW) {
             int n_out = a.n_out;
-            if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out = nd < n_out ? nd : n_out; }
+            if (a.n_out_dev) n_out = n_out_dev_v < n_out ? n_out_dev_v : n_out;
             if (!a.xo || !a.wo) n_out = 0;
-            const int ksteps = (n_out + 15) >> 4;
+            const int ksteps = ABL == 6 ? 0 : (n_out + 15) >> 4;
             constexpr float PRE = I4 ? (1.f / 256.f) : 1.f;
 
             float sxv[MI];
 #pragma unroll
             for (int j = 0; j < MI; ++j) sxv[j] = h2f(sxh[j]) * PRE;
-            if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // every wave is done reading the ring
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int nloc = wn * WN + i * 32 + 4 * lh;
-                const int nb = n0 + nloc;
-                float swv[16];                                                  // the 16 weight scales of this lane
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    swv[4 * g]     = h2f(static_cast<uint16_t>(swp[i][g].x & 0xffffu));
-                    swv[4 * g + 1] = h2f(static_cast<uint16_t>(swp[i][g].x >> 16));
-                    swv[4 * g + 2] = h2f(static_cast<uint16_t>(swp[i][g].y & 0xffffu));
-                    swv[4 * g + 3] = h2f(static_cast<uint16_t>(swp[i][g].y >> 16));
-                }
+            const bool has_add = ABL != 6 && a.addend != nullptr, has_bias = ABL != 6 && a.bias != nullptr, do_silu = ABL != 6 && a.act == MIXQ_ACT_SILU;
+            auto unpack4 = [](u32x2 v, float* o) {
+                o[0] = h2f(static_cast<uint16_t>(v.x & 0xffffu)); o[1] = h2f(static_cast<uint16_t>(v.x >> 16));
+                o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
+            };
+            // fp16 outlier tail: operands of k-step kk+1 are requested before the MFMAs of k-step kk, and those of
+            // k-step 0 before the barrier, so the whole tail exposes (at most) one memory round trip.
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            u32x4 xoq[2][MI], woq[2][NI];
+            auto tail_load = [&](auto p_c, int kk) {
+                constexpr int P = decltype(p_c)::value;
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
-                    f32x16 f;
+                    int xr = m0 + xrow[j]; xr = xr < a.M ? xr : a.M - 1;
+                    xoq[P][j] = *reinterpret_cast<const u32x4*>(a.xo + static_cast<size_t>(xr) * a.ldxo + lh * 8 + kk * 16);
+                }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) f[r] = static_cast<float>(acc[i][j][r]) * sxv[j] * swv[r];
+                for (int i = 0; i < NI; ++i) {
+                    int wr = n0 + wrow[i]; wr = wr < a.N ? wr : a.N - 1;
+                    woq[P][i] = *reinterpret_cast<const u32x4*>(a.wo + static_cast<size_t>(wr) * a.ldwo + lh * 8 + kk * 16);
+                }
+            };
+            if (ksteps > 0) tail_load(I0{}, 0);
+            if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // every wave is done reading the ring
+            stamp(6);
 
-                    if (ksteps > 0) {                    // fp16 outlier tail on the same accumulator registers
-                        int wr = n0 + wrow[i]; wr = wr < a.N ? wr : a.N - 1;
-                        int xr = m0 + xrow[j]; xr = xr < a.M ? xr : a.M - 1;
-                        const uint16_t* wp = a.wo + static_cast<size_t>(wr) * a.ldwo + lh * 8;
-                        const uint16_t* xp = a.xo + static_cast<size_t>(xr) * a.ldxo + lh * 8;
-                        for (int kk = 0; kk < ksteps; ++kk) {
-                            u32x4 wq = *reinterpret_cast<const u32x4*>(wp + kk * 16);
-                            u32x4 xq = *reinterpret_cast<const u32x4*>(xp + kk * 16);
-                            const int kb = kk * 16 + lh * 8;           // mask columns >= n_out (pad may hold anything)
-                            if (kb + 8 > n_out) {
+            // dequantise in place: f = acc * x_scale[m] * scale_col[n]
+            f32x16 fa[NI][MI];
 #pragma unroll
-                                for (int d = 0; d < 4; ++d) {
-                                    uint32_t keep = 0;
-                                    if (kb + 2 * d < n_out)     keep |= 0x0000ffffu;
-                                    if (kb + 2 * d + 1 < n_out) keep |= 0xffff0000u;
-                                    wq[d] &= keep; xq[d] &= keep;
-                                }
-                            }
-                            f = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq), __builtin_bit_cast(f16x8, xq), f, 0, 0, 0);
-                        }
+            for (int i = 0; i < NI; ++i) {
+                float swv[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) unpack4(swp[i][g], swv + 4 * g);
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) fa[i][j][r] = static_cast<float>(acc[i][j][r]) * sxv[j] * swv[r];
+            }
+            auto tail_mma = [&](auto p_c, int kk) {
+                constexpr int P = decltype(p_c)::value;
+                const int kb = kk * 16 + lh * 8;                     // mask columns >= n_out (the pad may hold anything)
+                if (kb + 8 > n_out) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        uint32_t keep = 0;
+                        if (kb + 2 * d < n_out)     keep |= 0x0000ffffu;
+                        if (kb + 2 * d + 1 < n_out) keep |= 0xffff0000u;
+#pragma unroll
+                        for (int j = 0; j < MI; ++j) xoq[P][j][d] &= keep;
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) woq[P][i][d] &= keep;
                     }
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j)
+                        fa[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, woq[P][i]),
+                                                                          __builtin_bit_cast(f16x8, xoq[P][j]), fa[i][j], 0, 0, 0);
+            };
+            for (int kk = 0; kk < ksteps; kk += 2) {
+                if (kk + 1 < ksteps) tail_load(I1{}, kk + 1);
+                tail_mma(I0{}, kk);
+                if (kk + 1 < ksteps) {
+                    if (kk + 2 < ksteps) tail_load(I0{}, kk + 2);
+                    tail_mma(I1{}, kk + 1);
+                }
+            }
 
-                    const int m = m0 + xrow[j];
-                    if (m < a.M && (ABL != 5 || a.act == 77)) {
+            // Optional terms, fp16 rounding and the store.  Specialised on (staged, any optional term) so the common
+            // case is straight-line code (a taken branch costs a fetch bubble that nothing hides with one wave per SIMD);
+            // columns come in all-in/all-out groups of 4 (N % 4 == 0), and out-of-range rows/columns read clamped
+            // addresses and are dropped at the store.
+            auto finish_tile = [&](auto staged_c, auto opt_c) {
+                constexpr bool ST = decltype(staged_c)::value, OPT = decltype(opt_c)::value;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int nloc = wn * WN + i * 32 + 4 * lh;
+                    const int nb = n0 + nloc;
+                    float bv[16];
+                    if (OPT && has_bias) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int n = nb + 8 * g;
-                            float v[4] = {f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]};
-                            const bool full = (n + 3 < a.N);
-                            if (a.addend) {
-                                const uint16_t* ap = a.addend + static_cast<size_t>(m) * a.lda + n;
+                            unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + (n < a.N ? n : a.N - 4)), bv + 4 * g);
+                        }
+                    }
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) if (full || n + e < a.N) v[e] += h2f(ap[e]);
+                    for (int j = 0; j < MI; ++j) {
+                        f32x16 f = fa[i][j];
+                        const int m = m0 + xrow[j];
+                        if (OPT && has_add) {
+                            const uint16_t* ap = a.addend + static_cast<size_t>(m < a.M ? m : a.M - 1) * a.lda;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int n = nb + 8 * g;
+                                float av[4];
+                                unpack4(*reinterpret_cast<const u32x2_u*>(ap + (n < a.N ? n : a.N - 4)), av);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) f[4 * g + e] += av[e];
                             }
-                            if (a.act == MIXQ_ACT_SILU) {
+                        }
+                        if (OPT && do_silu) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
-                            }
-                            if (a.bias) {
+                            for (int r = 0; r < 16; ++r) f[r] = silu(f[r]);
+                        }
+                        if (OPT && has_bias) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) if (full || n + e < a.N) v[e] += h2f(a.bias[n + e]);
-                            }
-                            u32x2 o;
-                            o.x = static_cast<uint32_t>(f2h(v[0])) | (static_cast<uint32_t>(f2h(v[1])) << 16);
-                            o.y = static_cast<uint32_t>(f2h(v[2])) | (static_cast<uint32_t>(f2h(v[3])) << 16);
-                            if (staged) {
-                                *reinterpret_cast<u32x2*>(lds + xrow[j] * OPITCH + (nloc + 8 * g) * 2) = o;
-                            } else {
-                                uint16_t* yp = a.y + static_cast<size_t>(m) * a.ldy + n;
-                                if (full) *reinterpret_cast<u32x2*>(yp) = o;
-                                else {
+                            for (int r = 0; r < 16; ++r) f[r] += bv[r];
+                        }
+                        if (ABL != 5 || a.act == 77) {
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) if (n + e < a.N) yp[e] = f2h(v[e]);
+                            for (int g = 0; g < 4; ++g) {
+                                u32x2 o;
+                                o.x = static_cast<uint32_t>(f2h(f[4 * g])) | (static_cast<uint32_t>(f2h(f[4 * g + 1])) << 16);
+                                o.y = static_cast<uint32_t>(f2h(f[4 * g + 2])) | (static_cast<uint32_t>(f2h(f[4 * g + 3])) << 16);
+                                if constexpr (ST) {
+                                    *reinterpret_cast<u32x2*>(lds + xrow[j] * OPITCH + (nloc + 8 * g) * 2) = o;
+                                } else {
+                                    if (m < a.M && nb + 8 * g < a.N)
+                                        *reinterpret_cast<u32x2_u*>(a.y + static_cast<size_t>(m) * a.ldy + nb + 8 * g) = o;
                                 }
                             }
                         }
                     }
                 }
-            }
+            };
+            const bool opt = has_add || has_bias || do_silu;
+            if (staged) { if (opt) finish_tile(std::true_type{}, std::true_type{}); else finish_tile(std::true_type{}, std::false_type{}); }
+            else        { if (opt) finish_tile(std::false_type{}, std::true_type{}); else finish_tile(std::false_type{}, std::false_type{}); }
+            stamp(7);
             if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // staging tile complete
+            stamp(3);
         }
         if (staged) {
             // all waves (loader included): 16 bytes per lane, 16 consecutive lanes cover a 256-byte row segment
@@ -482,6 +578,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n));
                 }
             }
+        }
+        if (a.trace) {
+            stamp(4);
+            wait_vmcnt<0>();
+            stamp(5);
         }
     }
 }
@@ -517,7 +618,7 @@ struct GemmConfig {
       gemm_kernel<BM, BN, WMv, WNv, NS, 2, LD, 0> }
 #define MIXQ_ABL(BM, BN, WMv, WNv, NS, LD, ABL)                                                               \
     { #BM "x" #BN "_w" #WMv "x" #WNv "_s" #NS "_l" #LD "_abl" #ABL, BM, BN, (WMv) * (WNv) + (LD), NS,       \
-      gemm_kernel<BM, BN, WMv, WNv, NS, 0, LD, ABL>, gemm_kernel<BM, BN, WMv, WNv, NS, 0, LD, ABL>,         \
+      gemm_kernel<BM, BN, WMv, WNv, NS, 0, LD, ABL>, gemm_kernel<BM, BN, WMv, WNv, NS, 1, LD, ABL>,         \
       gemm_kernel<BM, BN, WMv, WNv, NS, 2, LD, ABL> }
 
 const GemmConfig g_cfgs[] = {
@@ -537,15 +638,16 @@ const GemmConfig g_cfgs[] = {
     MIXQ_CFG(256, 256, 4, 2, 5, 0),     // 13: 8 consumers 64(M) x 128(N) self-issuing
     MIXQ_CFG(128, 256, 2, 2, 5, 2),     // 14: 4 consumers 64 x 128 + 2 loaders
     MIXQ_CFG(128, 256, 2, 2, 5, 4),     // 15
-    MIXQ_ABL(256, 128, 2, 2, 5, 4, 1),  // 16: cfg 3, DMA only
-    MIXQ_ABL(256, 128, 2, 2, 5, 4, 2),  // 17: cfg 3, no DMA
-    MIXQ_ABL(256, 128, 2, 2, 5, 4, 3),  // 18: cfg 3, MFMA only
-    MIXQ_ABL(256, 128, 2, 2, 5, 4, 5),  // 19: cfg 3, no epilogue stores
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 1),  // 16: cfg 8, DMA only
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 2),  // 17: cfg 8, no DMA
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 3),  // 18: cfg 8, MFMA only
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 6),  // 19: cfg 8, epilogue without the optional terms compiled in (code size probe)
 };
 constexpr int NUM_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 constexpr int NUM_PICK = 16;                       // configs the automatic choice may use (the rest are ablations)
 
 int g_forced_cfg = -1;
+unsigned long long* g_trace = nullptr;             // diagnostics: see mixq_gemm_set_trace
 bool g_attr_done[NUM_CFGS][3];
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -591,6 +693,7 @@ int launch_gemm(GemmArgs& a, int mode, hipStream_t st) {
     const GemmConfig* g = &g_cfgs[c];
     a.tiles_m = cdiv(a.M, g->bm);
     a.tiles_n = cdiv(a.N, g->bn);
+    a.trace = g_trace;
     void (*k)(const GemmArgs) = mode == 0 ? g->k8 : (mode == 1 ? g->k4 : g->k32);
     const size_t shm = static_cast<size_t>(g->bm + g->bn) * BKB * g->nstage;
     if (!g_attr_done[c][mode]) {
@@ -693,6 +796,7 @@ extern "C" int mixq_gemm_set_config(int cfg) {
     g_forced_cfg = cfg;
     return MIXQ_OK;
 }
+extern "C" int mixq_gemm_set_trace(unsigned long long* buf) { g_trace = buf; return MIXQ_OK; }
 extern "C" int mixq_gemm_num_configs(void) { return NUM_CFGS + mixq_sk_num_configs(); }
 extern "C" int mixq_gemm_config_name(int cfg, char* buf, int cap) {
     if (cfg < 0 || cfg >= NUM_CFGS + mixq_sk_num_configs() || !buf || cap <= 0) return MIXQ_EINVAL;

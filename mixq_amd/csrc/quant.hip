@@ -86,7 +86,7 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
     uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int ldo,
     int32_t* __restrict__ flag, int K, float thr_scale, int rows16)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32 (+1)] column bitmask, then 4 floats
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32 (+1)] column bitmask, 4 floats, row copy
     const int row = blockIdx.x, tid = threadIdx.x;
     const int mask_words = (K + 31) >> 5;
     float* red = reinterpret_cast<float*>(smem + mask_words);
@@ -105,15 +105,29 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
         }
     }
 
+    // The first outlier index of this thread is requested speculatively (entries >= n are ignored) together with the
+    // device-side count, so row, count and indices share ONE memory round trip; the gather then reads the row from an LDS
+    // copy instead of going back to global memory for x[row][c].
+    int c0 = 0;
+    if (ind != nullptr && tid < n_cap) c0 = ind[tid];
     int n = n_cap;
     if (n_dev) { int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
     const bool have_out = (n > 0) && ind != nullptr;
     if (have_out) {
         for (int i = tid; i < mask_words; i += QT) smem[i] = 0u;
+        if constexpr (NCH > 0 && NCH <= 8) {      // up to 32 KB of LDS for the row copy
+            uint4* stage = reinterpret_cast<uint4*>(smem + ((mask_words + 4 + 3) & ~3));
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + i * QT;
+                if (c < nchunk) stage[c] = keep[i];
+            }
+        }
         __syncthreads();
+        const uint16_t* srow = reinterpret_cast<const uint16_t*>(smem + ((mask_words + 4 + 3) & ~3));
         for (int j = tid; j < n; j += QT) {
-            const int c = ind[j];
-            const uint16_t v = xr[c];
+            const int c = (j == tid) ? c0 : ind[j];
+            const uint16_t v = (NCH > 0 && NCH <= 8) ? srow[c] : xr[c];
             if (x_out) x_out[static_cast<size_t>(row) * ldo + j] = v;
             xr[c] = 0;                                             // reference zeroes the caller's tensor in place
             atomicOr(&smem[c >> 5], 1u << (c & 31));
@@ -268,8 +282,10 @@ template <int BIT>
 int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
                       uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st)
 {
-    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + 4) * sizeof(uint32_t);
     const int nchunk = K >> 3;
+    // column bitmask, 4 reduction floats, and (rows kept in registers) a copy of the row for the outlier gather
+    const size_t shm = ((static_cast<size_t>((K + 31) >> 5) + 4 + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t)
+                       + (nchunk <= 8 * QT ? static_cast<size_t>(K) * 2 : 0);
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g(M), b(QT);
 #define MIXQ_QLAUNCH(NCH) hipLaunchKernelGGL((quant_rows_kernel<BIT, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, K, thr_scale, rows16)

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of the fused GEMM from the kernel's own timestamps (mixq_gemm_set_trace, 100 MHz clock).
+Prints, over the workgroups of one launch, the distribution of each phase: launch skew (entry relative to the first
+workgroup's entry), first stage landed, k loop, epilogue arithmetic, store issue, store retire.  Development tool."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mixq_amd import _capi, mixlib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="512x11008x4096")
+    ap.add_argument("--cfgs", default="8")
+    ap.add_argument("--bit", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    dev = "cuda"
+    lib = _capi.load()
+    names = _capi.gemm_config_names()
+    for shp in args.shapes.split(","):
+        M, N, K = (int(v) for v in shp.split("x"))
+        g = torch.Generator(device="cpu").manual_seed(0)
+        KB = K if args.bit == 8 else K // 2
+        qx = torch.randint(-127, 128, (M, KB), generator=g, dtype=torch.int8).to(dev)
+        qw = torch.randint(-127, 128, (N, KB), generator=g, dtype=torch.int8).to(dev)
+        sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
+        sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
+        qxp, qwp = mixlib.PackP16x64(qx), mixlib.PackP16x64(qw)
+        out = torch.empty(M, N, dtype=torch.float16, device=dev)
+        trace = torch.zeros(16 * 4096, dtype=torch.int64, device=dev)
+        for c in [int(v) for v in args.cfgs.split(",")]:
+            assert lib.mixq_gemm_set_config(c) == 0
+            run = lambda: mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out,
+                                             x_packed=True, w_packed=True)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            lib.mixq_gemm_set_trace(trace.data_ptr())
+            rows = []
+            for _ in range(args.reps):
+                trace.zero_()
+                run(); run()            # back to back: the second launch overwrites the first (steady-state clocks)
+                torch.cuda.synchronize()
+                t = trace.cpu().numpy().reshape(-1, 16)
+                t = t[t[:, 0] != 0].astype(np.float64)
+                rows.append(t)
+            lib.mixq_gemm_set_trace(None)
+            t = rows[-1]
+            t0 = t[:, 0].min()
+            ph = {
+                "entry skew": t[:, 0] - t0,
+                "entry->stage0": t[:, 1] - t[:, 0],
+                "k loop": t[:, 2] - t[:, 1],
+                "  loop end->barrier": t[:, 6] - t[:, 2],
+                "  dequant+stage": t[:, 7] - t[:, 6],
+                "  ->barrier 2": t[:, 3] - t[:, 7],
+                "epilogue math": t[:, 3] - t[:, 2],
+                "store issue": t[:, 4] - t[:, 3],
+                "store retire": t[:, 5] - t[:, 4],
+                "WG total": t[:, 5] - t[:, 0],
+                "end (vs first entry)": t[:, 5] - t0,
+            }
+            mhz = (t[:, 10] - t[:, 9]) / ((t[:, 2] - t[:, 1]) / 100.0)
+            print(f"{shp} bit={args.bit} cfg{c} {names[c]}: {t.shape[0]} workgroups; s_memtime ticks per us in the k loop: "
+                  f"{np.median(mhz):.0f}; microseconds min / median / p90 / max")
+            for k, v in ph.items():
+                v = v / 100.0
+                print(f"  {k:22s} {v.min():7.2f} {np.median(v):7.2f} {np.percentile(v, 90):7.2f} {v.max():7.2f}")
+        lib.mixq_gemm_set_config(-1)
+
+
+if __name__ == "__main__":
+    main()
