@@ -239,6 +239,29 @@ def main():
     rec["up_weight"], rec["gate_weight"], rec["layer_scales"] = t2h(up.weight.data), t2h(gate.weight.data), t2h(layer_scales)
     np.savez(os.path.join(OUT, "g5d_forward_w4_silu.npz"), **rec)
 
+    # ---- G6: checkpoint layout: state_dict keys / shapes / dtypes of the reference module per flavour, and the
+    #      layer policy tables of utils/module.py ------------------------------------------
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("ref_utils_module", os.path.join(REF, "mixquant", "utils", "module.py"))
+    um = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(um)
+
+    def layout(m):
+        return {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+
+    lw = torch.nn.Linear(256, 96, bias=True).half()
+    wo = lin.MixLinear_GEMM.from_linear(lw, bit=8, weight_only=True, init_only=True, cache=cache8, dev="cpu", name="g6wo")
+    g6 = {
+        "w8_bias": layout(q8),
+        "w4_nobias": layout(q4),
+        "weight_only_w8_bias": layout(wo),
+        "eightbit_only_name": list(um.eightbit_only_name),
+        "weight_only_map": {k: list(v) for k, v in um.weight_only_map.items()},
+    }
+    with open(os.path.join(OUT, "g6_checkpoint_layout.json"), "w") as f:
+        json.dump(g6, f, indent=1, sort_keys=True)
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
