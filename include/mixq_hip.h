@@ -169,6 +169,18 @@ int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weight, uint16_t
                              int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma, int qfmt,
                              mixq_stream_t stream);
 
+/* ---- weight-only W8A16 Linear -----------------------------------------------------
+ * mixq_gemm_w8a16 replaces EETQ's w8_a16_gemm(x, q_weight, scale_col) as called at modules/linear.py:178-184:
+ *   y[M,N] fp16 = x[M,K] fp16 * (q[K,N] int8 * scale_col[N] fp16) (+ bias[N] fp16), fp32 accumulation, one fp16 rounding.
+ * The kernel streams the weights from a re-tiled copy: mixq_pack_w8a16 turns the checkpoint's row-major [K,N] int8
+ * matrix (modules/linear.py:70-71; EETQ's *unprocessed* quantised tensor) into round16(N) * K bytes of offset-binary
+ * P16x64 (rows = output channels) once per layer.
+ *   K % 64 == 0, N % 4 == 0, ldx % 8 == 0, x 16-byte aligned, ldy % 4 == 0, y 8-byte aligned. */
+int mixq_pack_w8a16(const int8_t* q_weight_kn, uint8_t* packed, int K, int N, mixq_stream_t stream);
+int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_packed, const uint16_t* scale_col, const uint16_t* bias,
+                    uint16_t* y, int ldy, int M, int N, int K, mixq_stream_t stream);
+int mixq_gemm_w8a16_set_config(int cfg);             /* tuning: force a tile config, -1 = automatic */
+
 /* ---- stream-K workspace ---------------------------------------------------------------------------------
  * The stream-K form of the GEMM (chosen for shapes whose tile count leaves CUs idle, e.g. M = 512, N = 11008) hands
  * int32 partial tiles between workgroups through a device buffer the HOST provides once:

@@ -562,6 +562,9 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
             if (staged) { if (opt) finish_tile(std::true_type{}, std::true_type{}); else finish_tile(std::true_type{}, std::false_type{}); }
             else        { if (opt) finish_tile(std::false_type{}, std::true_type{}); else finish_tile(std::false_type{}, std::false_type{}); }
             stamp(7);
+            // ds_write is asynchronous and a raw s_barrier does not wait for it: the tile writes must have been
+            // performed before another wave's copy-out reads are issued
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // staging tile complete
             stamp(3);
         }

@@ -399,6 +399,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_sk_kernel(const S
                         }
                     }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // tile writes performed, not just issued
                 __builtin_amdgcn_s_barrier();                               // staging half complete
                 if (staged) {
                     constexpr int CPR = BN * 2 / 16;

@@ -1,0 +1,356 @@
+// Weight-only W8A16 Linear for gfx950:  Y[M,N] = X[M,K] (fp16) * (Wq[K,N] (int8) * scale_col[N]) + bias
+// -- what the reference reaches through EETQ's `w8_a16_gemm(x, q_weight, scale_col)` (modules/linear.py:178-184; GPT-J
+// fc_out and the "down_weight_only" variants, utils/module.py:4-12).  EETQ is a third-party CUDA extension that is not
+// part of the reference tree and is not version-pinned; its CUTLASS-interleaved weight image is an implementation
+// detail of that library.  Here:
+//
+//  * the int8 weights are re-tiled ONCE (mixq_pack_w8a16) from the checkpoint's [K,N] matrix into the same P16x64
+//    tile-major layout the W8A8 GEMM streams (rows = output channels, 64 k-bytes per block row), stored offset-binary
+//    (q + 128) so that the int8 -> fp16 conversion in the k loop is two VALU per pair of elements:
+//        v_perm_b32   -> halves 0x6400 | u   (= 1024 + u exactly)
+//        v_pk_add_f16 -> - 1152              (= u - 128 = q, exact)
+//  * X stays the caller's fp16 [M,K] matrix; a k-step (64 elements) of a tile is staged as two [BM x 64 B] sub-tiles
+//    by LDS-DMA with the 16-byte-chunk XOR swizzle applied on the source address,
+//  * v_mfma_f32_32x32x16_f16, weights as the A operand (a lane holds 4 consecutive output columns of one token, as in
+//    gemm.hip, so the epilogue layout is shared).  One 16-byte LDS read of a weight row feeds two MFMA k-steps; the k
+//    order inside a stage is permuted identically for both operands (MFMA step 2t+u, lane half h covers
+//    k = 16(2t+h) + 8u .. +8),
+//  * dedicated loader waves, NSTAGE-deep ring, one s_barrier per k-step, fp16 tile staged through LDS for the stores:
+//    the structure of gemm.hip.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+struct WoArgs {
+    const uint16_t* x; const uint8_t* w; const uint16_t* sw; const uint16_t* bias; uint16_t* y;
+    int M, N, K, ldx, ldy, tiles_m, tiles_n, wrows16;
+};
+
+template <int N> __device__ __forceinline__ void wo_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+__device__ __forceinline__ void wo_glds16(const uint8_t* gsrc, uint8_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int wo_swz(int r, int c) { return c ^ ((r >> 2) & 3); }
+__device__ __forceinline__ void wo_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+
+// 4 offset-binary bytes -> 4 halves (two dwords)
+__device__ __forceinline__ void cvt_u8x4(uint32_t d, uint32_t& o0, uint32_t& o1) {
+    const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, d, 0x04010400u);      // (0x64, b1, 0x64, b0)
+    const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, d, 0x04030402u);      // (0x64, b3, 0x64, b2)
+    const h2_t off = {static_cast<_Float16>(1152.f), static_cast<_Float16>(1152.f)};
+    o0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, p0) - off);
+    o1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, p1) - off);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int LOADERS>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_w8a16_kernel(const WoArgs a)
+{
+    constexpr int CW = WAVES_M * WAVES_N, NT = (CW + LOADERS) * 64;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
+    constexpr int W_BYTES = BN * 64, XH_BYTES = BM * 64, STAGE_BYTES = W_BYTES + 2 * XH_BYTES;
+    constexpr int WP = BN / 16, XP = 2 * (BM / 16), TI = WP + XP;               // 1-KiB DMA pieces per stage
+    constexpr int LOADS = (TI + LOADERS - 1) / LOADERS;
+    constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
+    constexpr int OPITCH = BN * 2 + 16;
+    static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shapes");
+    static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
+    static_assert(BM * OPITCH <= NSTAGE * STAGE_BYTES, "output staging tile must fit in the ring");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int tile;
+    {   // XCD-aware remap (block b runs on XCD b % 8): consecutive logical tiles share an L2
+        const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, x = b & 7, s = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+    }
+    const int tn = tile / a.tiles_m, tm = tile - tn * a.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id_uniform();
+    const int nk = a.K / 64;
+
+    // ================================================================================================ loader waves
+    if (wave >= CW) {
+        __builtin_amdgcn_s_setprio(2);
+        const int iw = wave - CW;
+        const uint8_t* nsrc[LOADS];
+        int kstr[LOADS], loff[LOADS];
+        const int r = lane >> 2, pc = lane & 3;
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            int pw = i * LOADERS + iw;
+            if (pw >= TI) pw = iw;                                              // benign duplicate
+            if (pw < WP) {                                                      // 16 weight rows: one contiguous KiB
+                int rb = (n0 >> 4) + pw;
+                rb = rb < (a.wrows16 >> 4) ? rb : (a.wrows16 >> 4) - 1;
+                nsrc[i] = a.w + static_cast<size_t>(rb) * 1024 + lane * 16;
+                kstr[i] = a.wrows16 * 64;
+                loff[i] = pw * 1024;
+            } else {                                                            // 16 token rows x 64 bytes (32 halves)
+                const int xp = pw - WP, h = xp / (BM / 16), rbx = xp % (BM / 16);
+                int row = m0 + rbx * 16 + r;
+                row = row < a.M ? row : a.M - 1;
+                nsrc[i] = reinterpret_cast<const uint8_t*>(a.x) + static_cast<size_t>(row) * a.ldx * 2 + h * 64 + wo_swz(r, pc) * 16;
+                kstr[i] = 128;
+                loff[i] = W_BYTES + h * XH_BYTES + rbx * 1024;
+            }
+        }
+        auto stage = [&](int buf) {
+            uint8_t* base = lds + buf * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) { wo_glds16(nsrc[i], base + loff[i]); nsrc[i] += kstr[i]; }
+        };
+#pragma unroll
+        for (int s = 0; s < LOOK; ++s)
+            if (s < nk) stage(s);
+        if (NEWER < nk) wo_wait_vmcnt<LOADS * NEWER>(); else wo_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        int nxt = LOOK % NSTAGE, kt = 0;
+        for (; kt + LOOK < nk; ++kt) {
+            stage(nxt);
+            wo_wait_vmcnt<LOADS * NEWER>();
+            __builtin_amdgcn_s_barrier();
+            nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+        }
+        for (; kt + 1 < nk; ++kt) {
+            wo_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();                                           // epilogue: ring free
+        __builtin_amdgcn_s_barrier();                                           // epilogue: staging tile complete
+    }
+
+    // ================================================================================================ consumer waves
+    const int wn = wave % WAVES_N, wm = (wave / WAVES_N) % WAVES_M;
+    const int lr = lane & 31, lh = lane >> 5;
+    f32x16 acc[NI][MI];
+    if (wave < CW) {
+        int wrow[NI], xrow[MI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wrow[i] = wn * WN + i * 32 + lr;
+#pragma unroll
+        for (int j = 0; j < MI; ++j) xrow[j] = wm * WM + j * 32 + lr;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        u32x4 wraw[2][NI];                   // raw weight chunk t of the stage (16 k-bytes: MFMA steps 2t and 2t+1)
+        u32x4 xf[2][MI];                     // token fragments, by MFMA step parity
+        auto load_w = [&](auto t_c, int buf) {
+            constexpr int T = decltype(t_c)::value;
+            const uint8_t* wb = lds + buf * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                wraw[T][i] = *reinterpret_cast<const u32x4*>(wb + wrow[i] * 64 + wo_swz(wrow[i], 2 * T + lh) * 16);
+        };
+        auto load_x = [&](auto s_c, int buf) {
+            constexpr int S = decltype(s_c)::value;                             // MFMA step 0..3 of the stage
+            const uint8_t* xb = lds + buf * STAGE_BYTES + W_BYTES + (S >> 1) * XH_BYTES;
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+                xf[S & 1][j] = *reinterpret_cast<const u32x4*>(xb + xrow[j] * 64 + wo_swz(xrow[j], 2 * lh + (S & 1)) * 16);
+        };
+        auto mma_step = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value, T = S >> 1, U = S & 1;
+            f16x8 wc[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                uint32_t o0, o1, o2, o3;
+                cvt_u8x4(wraw[T][i][2 * U], o0, o1);
+                cvt_u8x4(wraw[T][i][2 * U + 1], o2, o3);
+                wc[i] = __builtin_bit_cast(f16x8, u32x4{o0, o1, o2, o3});
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[i], __builtin_bit_cast(f16x8, xf[U][j]), acc[i][j], 0, 0, 0);
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        using S3 = std::integral_constant<int, 3>;
+
+        __builtin_amdgcn_s_barrier();                                           // stage 0 landed
+        wo_fence();
+        load_w(S0{}, 0); load_x(S0{}, 0);
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur1 = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+            load_x(S1{}, cur);
+            mma_step(S0{});
+            wo_fence();
+            load_w(S1{}, cur); load_x(S2{}, cur);
+            mma_step(S1{});
+            wo_fence();
+            load_x(S3{}, cur);
+            mma_step(S2{});
+            wo_fence();
+            if (kt + 1 < nk) {
+                __builtin_amdgcn_s_barrier();                                   // stage kt+1 landed and visible
+                wo_fence();
+                load_w(S0{}, cur1); load_x(S0{}, cur1);
+            }
+            mma_step(S3{});
+            wo_fence();
+            cur = cur1;
+        }
+
+        // ---- epilogue: y = acc * scale_col[n] (+ bias[n]) -> fp16 tile in LDS ---------------------------------------
+        __builtin_amdgcn_s_barrier();                                           // every wave is done reading the ring
+        wo_fence();
+        const bool has_bias = a.bias != nullptr;
+        auto unpack4 = [](u32x2 v, float* o) {
+            o[0] = h2f(static_cast<uint16_t>(v.x & 0xffffu)); o[1] = h2f(static_cast<uint16_t>(v.x >> 16));
+            o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
+        };
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int nloc = wn * WN + i * 32 + 4 * lh;
+            float swv[16], bv[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + nloc + 8 * g;
+                const int nc = n < a.N ? n : a.N - 4;                           // N % 4 == 0: groups are all in or all out
+                unpack4(*reinterpret_cast<const u32x2_u*>(a.sw + nc), swv + 4 * g);
+                if (has_bias) unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv + 4 * g);
+            }
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][4 * g + e] * swv[4 * g + e];
+                        if (has_bias) v[e] += bv[4 * g + e];
+                    }
+                    u32x2 o;
+                    o.x = static_cast<uint32_t>(f2h(v[0])) | (static_cast<uint32_t>(f2h(v[1])) << 16);
+                    o.y = static_cast<uint32_t>(f2h(v[2])) | (static_cast<uint32_t>(f2h(v[3])) << 16);
+                    *reinterpret_cast<u32x2*>(lds + xrow[j] * OPITCH + (nloc + 8 * g) * 2) = o;
+                }
+            }
+        }
+        // ds_write is asynchronous and a raw s_barrier does not wait for it: without this the last tile writes of a
+        // wave can still be queued when another wave's copy-out read of the same bytes is served (seen on MI355X as
+        // a stale 2-row x 16-column patch, a few launches in a hundred)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                           // staging tile complete
+        wo_fence();
+    }
+    // all waves: 8-byte segments (N % 4 == 0 is the only alignment the ABI asks of N and ldy)
+    constexpr int CPR = BN * 2 / 8;
+    for (int q = tid; q < BM * CPR; q += NT) {
+        const int r = q / CPR, c = q - r * CPR;
+        const int m = m0 + r, n = n0 + c * 4;
+        if (m < a.M && n < a.N) {
+            const u32x2 v = *reinterpret_cast<const u32x2*>(lds + r * OPITCH + c * 8);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(a.y + static_cast<size_t>(m) * a.ldy + n));
+        }
+    }
+}
+
+// One-time re-tiling of the checkpoint's [K,N] int8 matrix into offset-binary P16x64 (rows = output channels).
+__global__ __launch_bounds__(256) void pack_w8a16_kernel(const int8_t* __restrict__ qkn, uint8_t* __restrict__ dst, int K, int N, int rows16)
+{
+    const long long t = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    const long long total = static_cast<long long>(rows16) * (K >> 4);
+    if (t >= total) return;
+    const int per_kb = rows16 * 4;
+    const int kb = static_cast<int>(t / per_kb), rem = static_cast<int>(t % per_kb);
+    const int rb = rem >> 6, r = (rem >> 2) & 15, pc = rem & 3;
+    const int n = rb * 16 + r, c = pc ^ ((r >> 2) & 3);
+    const int k0 = kb * 64 + c * 16;
+    uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};      // q = 0 for padding rows
+    if (n < N) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = qkn[static_cast<size_t>(k0 + 4 * d + e) * N + n];
+                v |= static_cast<uint32_t>((q + 128) & 0xff) << (8 * e);
+            }
+            w[d] = v;
+        }
+    }
+    reinterpret_cast<uint4*>(dst)[t] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+struct WoConfig {
+    const char* name; int bm, bn, waves, nstage;
+    void (*k)(const WoArgs);
+};
+const WoConfig g_wo[] = {
+    {"w8a16_128x192_w2x2_s4_l4", 128, 192, 8, 4, gemm_w8a16_kernel<128, 192, 2, 2, 4, 4>},
+    {"w8a16_128x128_w2x2_s4_l4", 128, 128, 8, 4, gemm_w8a16_kernel<128, 128, 2, 2, 4, 4>},
+    {"w8a16_64x128_w2x2_s4_l4",  64, 128, 8, 4, gemm_w8a16_kernel<64, 128, 2, 2, 4, 4>},
+};
+constexpr int NUM_WO = sizeof(g_wo) / sizeof(g_wo[0]);
+bool g_wo_attr[NUM_WO];
+int g_wo_forced = -1;
+
+inline int wo_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+int pick_wo(int M, int N) {
+    double best = 1e30; int bi = 0;
+    for (int c = 0; c < NUM_WO; ++c) {
+        const int tiles = wo_cdiv(M, g_wo[c].bm) * wo_cdiv(N, g_wo[c].bn);
+        // time ~ rounds x tile cost: MFMA work grows with bm*bn, the weight stream of a tile with bn
+        const double t = wo_cdiv(tiles, 256) * (static_cast<double>(g_wo[c].bm) * g_wo[c].bn + 4096.0 * g_wo[c].bn / 64.0);
+        if (t < best * 0.999) { best = t; bi = c; }
+    }
+    return bi;
+}
+
+}  // namespace
+
+extern "C" int mixq_pack_w8a16(const int8_t* q_weight_kn, uint8_t* packed, int K, int N, mixq_stream_t stream)
+{
+    if (K <= 0 || N <= 0 || !q_weight_kn || !packed) return MIXQ_EINVAL;
+    if (K % 64) return MIXQ_ESHAPE;
+    const int rows16 = (N + 15) & ~15;
+    const long long total = static_cast<long long>(rows16) * (K >> 4);
+    hipLaunchKernelGGL(pack_w8a16_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, mixq_stream(stream),
+                       q_weight_kn, packed, K, N, rows16);
+    return mixq_launch_status();
+}
+
+extern "C" int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_packed, const uint16_t* scale_col, const uint16_t* bias,
+                               uint16_t* y, int ldy, int M, int N, int K, mixq_stream_t stream)
+{
+    if (M < 0 || N < 0 || K <= 0 || (M > 0 && N > 0 && (!x || !w_packed || !scale_col || !y))) return MIXQ_EINVAL;
+    if ((K % 64) || (N & 3) || (ldy & 3) || ldy < N || ldx < K || (ldx & 7)) return MIXQ_ESHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) return MIXQ_EINVAL;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    const int c = (g_wo_forced >= 0 && g_wo_forced < NUM_WO) ? g_wo_forced : pick_wo(M, N);
+    const WoConfig& g = g_wo[c];
+    WoArgs a;
+    a.x = x; a.w = w_packed; a.sw = scale_col; a.bias = bias; a.y = y;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldy = ldy;
+    a.tiles_m = wo_cdiv(M, g.bm); a.tiles_n = wo_cdiv(N, g.bn); a.wrows16 = (N + 15) & ~15;
+    const size_t shm = static_cast<size_t>(g.bn * 64 + g.bm * 128) * g.nstage;
+    if (!g_wo_attr[c]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(g.k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
+        if (e != hipSuccess) return static_cast<int>(e);
+        g_wo_attr[c] = true;
+    }
+    hipLaunchKernelGGL(g.k, dim3(a.tiles_m * a.tiles_n), dim3(g.waves * 64), shm, mixq_stream(stream), a);
+    return mixq_launch_status();
+}
+
+extern "C" int mixq_gemm_w8a16_set_config(int cfg) {
+    if (cfg < -1 || cfg >= NUM_WO) return MIXQ_EINVAL;
+    g_wo_forced = cfg;
+    return MIXQ_OK;
+}

@@ -155,7 +155,14 @@ class MixLinear_GEMM(nn.Module):
         if init_only is True:
             return q
         if weight_only is True:
-            raise NotImplementedError("weight-only W8A16 (EETQ) layers are outside the hot path (SURVEY.md §8f row 4)")
+            # linear.py:102-106: EETQ's per-column symmetric int8 of W^T [K,N] (restated in mixq_amd/eetq.py)
+            from . import eetq
+            int8_weight, scales = eetq.quant_weights(torch.t(linear.weight.data).contiguous().cpu(), torch.int8, False)
+            q.q_weight.copy_(int8_weight)
+            q.scale_col.copy_(scales.half())
+            if linear.bias is not None:
+                q.bias.copy_(linear.bias.data.half())
+            return q
 
         W = linear.weight.data.to(dev)                      # a copy when it moves; cloned below before any in-place op
         N = linear.out_features
@@ -244,7 +251,12 @@ class MixLinear_GEMM(nn.Module):
         inputs = x.reshape(-1, x.shape[-1])
         M = inputs.shape[0]
         if self.weight_only is True:
-            raise NotImplementedError("weight-only W8A16 (EETQ) layers are outside the hot path (SURVEY.md §8f row 4)")
+            # linear.py:178-184 (w8_a16_gemm, then `y += bias`): here the bias rides in the GEMM epilogue
+            key = (self.q_weight.data_ptr(), self.q_weight._version)
+            if self._wpk is None or self._wpk_key != key:
+                self._wpk, self._wpk_key = _backend.PackW8A16(self.q_weight), key
+            y = _backend.W8A16Linear(inputs, self._wpk, self.scale_col, self.bias, self.out_features, self.in_features)
+            return y.reshape(cache.shape)
         qmax = 2 ** (self.bit - 1) - 1
 
         if unfused:

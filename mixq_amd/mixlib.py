@@ -315,3 +315,34 @@ def layernorm_forward_cuda_extract_outliers_int4(x, weight, out, eps, ind, x_sca
     if xo is None:
         xo = torch.empty((q.shape[0], 0), dtype=torch.float16, device=x.device)
     return xo, q
+
+
+# ------------------------------------------------------------------------------------------------------------
+# weight-only W8A16 (the reference reaches it through EETQ, linear.py:9,102-106,178-184)
+# ------------------------------------------------------------------------------------------------------------
+def PackW8A16(q_weight_kn):
+    """Re-tile the checkpoint's int8 [K,N] weight for mixq_gemm_w8a16 (once per layer) -> uint8 [round16(N) * K]."""
+    _dev_check(q_weight_kn)
+    if q_weight_kn.dtype != torch.int8 or q_weight_kn.dim() != 2 or not q_weight_kn.is_contiguous():
+        raise RuntimeError("PackW8A16: expected a contiguous int8 [K,N] tensor")
+    K, N = q_weight_kn.shape
+    out = torch.empty(((N + 15) // 16 * 16) * K, dtype=torch.uint8, device=q_weight_kn.device)
+    _capi.call("mixq_pack_w8a16", q_weight_kn.data_ptr(), out.data_ptr(), K, N, _stream())
+    return out
+
+
+def W8A16Linear(x, w_packed, scale_col, bias, N, K, out=None):
+    """y = x @ (q * scale_col) + bias with the weights from PackW8A16.  x fp16 [M,K] (row stride % 8 == 0)."""
+    _dev_check(x, w_packed, scale_col, bias)
+    if x.dtype != torch.float16 or scale_col.dtype != torch.float16:
+        raise RuntimeError("W8A16Linear: x and scale_col must be float16")
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.shape[1] != K or scale_col.numel() != N:
+        raise RuntimeError("W8A16Linear: shape mismatch")
+    if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=x.device)
+    _capi.call("mixq_gemm_w8a16", x2.data_ptr(), x2.stride(0) if M else K, w_packed.data_ptr(), scale_col.data_ptr(), _ptr(bias),
+               y.data_ptr(), y.stride(0) if M else N, M, N, K, _stream())
+    return y

@@ -342,3 +342,48 @@ void orc_rmsnorm_quant(const uint16_t* x, const uint16_t* w, uint16_t* out, cons
     orc_extract_outliers_zero(out, ind, n, x_out, M, K, ldout, ldxo);
     orc_find_row_scale(out, x_scale, q, M, K, ldout, bit);
 }
+
+/* ---- weight-only W8A16 (modules/linear.py:102-106, :178-184) --------------------------------------
+ * The arithmetic lives in EETQ (github.com/NetEase-FuXi/EETQ: `quant_weights`, `w8_a16_gemm`), a third-party CUDA
+ * extension that is absent from the reference tree and not version-pinned: PARITY UNPINNED for this row.  Restated from
+ * its published algorithm (FasterTransformer's symmetric_quantize_last_axis_of_batched_matrix, which EETQ wraps):
+ *   per output column n of W^T [K,N]:  s = colabsmax / 128  (float; the reference stores scales.half(), linear.py:106)
+ *   q[k,n] = clip(round(w / s), -128, 127),  round = C round(), half away from zero
+ * An all-zero column has s = 0 there (0/0); it is given q = 0 here (the dequantised weight is 0 either way).
+ * wkn: fp16 [K,N] (the transposed Linear weight), q: int8 [K,N], scale: fp16 [N]. */
+void orc_quant_weight_w8a16(const uint16_t* wkn, int K, int N, int8_t* q, uint16_t* scale)
+{
+    for (int n = 0; n < N; ++n) {
+        float amax = 0.f;
+        for (int k = 0; k < K; ++k) { float a = fabsf(h2f(wkn[(size_t)k * N + n])); if (a > amax) amax = a; }
+        const float s = amax * (1.0f / 128.0f);
+        scale[n] = f2h(s);
+        for (int k = 0; k < K; ++k) {
+            float v = 0.f;
+            if (s > 0.f) { v = roundf(h2f(wkn[(size_t)k * N + n]) / s); v = v < -128.f ? -128.f : (v > 127.f ? 127.f : v); }
+            q[(size_t)k * N + n] = (int8_t)v;
+        }
+    }
+}
+
+/* y[m,n] = fp16( float(scale[n]) * sum_k x[m,k] * q[k,n]  (+ bias[n]) ): exact products, double accumulation, one rounding. */
+void orc_w8a16_linear(const uint16_t* x, int ldx, const int8_t* q, const uint16_t* scale, const uint16_t* bias, uint16_t* y,
+                      int ldy, int M, int N, int K)
+{
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        double* accv = (double*)calloc((size_t)N, sizeof(double));
+        for (int k = 0; k < K; ++k) {
+            const double xv = (double)h2f(x[(size_t)m * ldx + k]);
+            if (xv == 0.0) continue;
+            const int8_t* qr = q + (size_t)k * N;
+            for (int n = 0; n < N; ++n) accv[n] += xv * (double)qr[n];
+        }
+        for (int n = 0; n < N; ++n) {
+            float v = (float)(accv[n] * (double)h2f(scale[n]));
+            if (bias) v += h2f(bias[n]);
+            y[(size_t)m * ldy + n] = f2h(v);
+        }
+        free(accv);
+    }
+}

@@ -235,3 +235,27 @@ def rmsnorm_quant(x, w, eps, ind, bit):
     lib().orc_rmsnorm_quant(_p(x), _p(w), _p(out), _p(ind), n, _p(s), _p(q), _p(xo) if n else None, M, K, K, K, n,
                             C.c_float(eps), bit)
     return out, xo, q, s
+
+
+def quant_weight_w8a16(wkn):
+    """EETQ quant_weights(W^T [K,N], int8) as used at linear.py:102-106 -> (q int8 [K,N], scale fp16 [N]).  PARITY
+    UNPINNED (EETQ absent): restates FasterTransformer's symmetric per-column quantisation (mixq_oracle.c)."""
+    wkn = _h(wkn)
+    K, N = wkn.shape
+    q = np.empty((K, N), dtype=np.int8)
+    s = np.empty(N, dtype=np.float16)
+    lib().orc_quant_weight_w8a16(_p(wkn), K, N, _p(q), _p(s))
+    return q, s
+
+
+def w8a16_linear(x, q, scale, bias=None):
+    """EETQ w8_a16_gemm(x, q_weight, scale) (+ bias, linear.py:178-184) -> fp16 [M,N]."""
+    x = _h(x)
+    q = np.ascontiguousarray(q, dtype=np.int8)
+    scale = _h(scale).reshape(-1)
+    M, K = x.shape
+    N = q.shape[1]
+    y = np.empty((M, N), dtype=np.float16)
+    b = None if bias is None else _h(bias).reshape(-1)
+    lib().orc_w8a16_linear(_p(x), K, _p(q), _p(scale), _p(b) if b is not None else None, _p(y), N, M, N, K)
+    return y

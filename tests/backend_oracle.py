@@ -94,3 +94,14 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
     if flag is not None and O.mispredicted(s, sigma, bit):
         flag |= 1
     return torch.from_numpy(q), (torch.from_numpy(xo) if idx.size else None)
+
+
+def PackW8A16(q_weight_kn):
+    calls.append("PackW8A16")
+    return q_weight_kn                        # the oracle reads the checkpoint layout directly
+
+
+def W8A16Linear(x, w_packed, scale_col, bias, N, K, out=None):
+    calls.append("W8A16Linear")
+    y = O.w8a16_linear(_np(x.reshape(-1, K)), _np(w_packed), _np(scale_col), None if bias is None else _np(bias))
+    return torch.from_numpy(y)

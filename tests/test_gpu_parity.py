@@ -587,3 +587,113 @@ def test_checkpoint_roundtrip_forward_identical(tmp_path, w_bit):
     yq = torch.cat(y2b, dim=1)
     # same operands, same per-tile arithmetic; only the outlier set's discovery order could differ (8-bit) - it does not
     assert torch.equal(yf, yq)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight-only W8A16 (parity UNPINNED: EETQ is absent; the oracle restates the published rule)
+# ---------------------------------------------------------------------------------------------------------------
+def _w8a16_case(M, N, K, seed, bias):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(-128, 128, size=(K, N), dtype=np.int8)
+    s = (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    b = (rng.standard_normal(N)).astype(np.float16) if bias else None
+    return q, s, x, b
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(1, 64, 64, False), (7, 192, 128, True), (33, 100, 256, False), (128, 128, 512, True),
+                                        (300, 1000, 1024, False), (512, 1536, 4096, True), (16, 4096, 4096, False), (64, 36, 192, True)])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
+def test_w8a16_linear_vs_oracle(M, N, K, bias, cfg):
+    q, s, x, b = _w8a16_case(M, N, K, 7 * M + N + K, bias)
+    lib = _capi.load()
+    assert lib.mixq_gemm_w8a16_set_config(cfg) == 0
+    try:
+        wp = mixlib.PackW8A16(t(q))
+        y = n(mixlib.W8A16Linear(t(x), wp, t(s), None if b is None else t(b), N, K))
+    finally:
+        lib.mixq_gemm_w8a16_set_config(-1)
+    ref = O.w8a16_linear(x, q, s, b)
+    d = np.abs(y.astype(np.float32) - ref.astype(np.float32))
+    assert (d <= ulp_tol(ref)).all(), float(d.max())
+    # the north-star gate: CPU Linear over the same dequantised operands
+    gate = torch.nn.functional.linear(torch.from_numpy(x).float(), torch.from_numpy(q.astype(np.float32) * s.astype(np.float32)).t(),
+                                      None if b is None else torch.from_numpy(b).float()).numpy()
+    small = np.abs(gate) < 8
+    assert np.abs(y.astype(np.float32) - gate)[small].max() <= GATE
+
+
+def test_w8a16_offset_binary_conversion_is_exact():
+    """One-hot activations read single weights back: every int8 value -128..127 must survive the perm / pk_add trick."""
+    K, N = 256, 64
+    q = np.zeros((K, N), np.int8)
+    vals = np.arange(-128, 128, dtype=np.int16)
+    for k in range(K):
+        q[k, :] = np.roll(vals, k)[:N].astype(np.int8)
+    s = np.ones(N, np.float16)
+    x = np.eye(K, dtype=np.float16)[:128]                        # row m selects k = m
+    y = n(mixlib.W8A16Linear(t(x), mixlib.PackW8A16(t(q)), t(s), None, N, K))
+    assert np.array_equal(y.astype(np.int16), q[:128].astype(np.int16))
+
+
+def test_w8a16_strided_input_and_operator_on_gpu():
+    torch.manual_seed(3)
+    K, N, M = 512, 320, 40
+    lin = torch.nn.Linear(K, N, bias=True).half()
+    cache = MixLibCache(64)
+    ql = MixLinear_GEMM.from_linear(lin, bit=8, weight_only=True, cache=cache, dev=DEV, name="fc_out")
+    big = torch.randn(M, K + 64, device=DEV).half()
+    x = big[:, :K]                                               # row stride K + 64
+    y = ql(x)
+    ref = O.w8a16_linear(n(x), n(ql.q_weight), n(ql.scale_col), n(ql.bias))
+    assert (np.abs(n(y).astype(np.float32) - ref.astype(np.float32)) <= ulp_tol(ref)).all()
+    from mixq_amd import eetq
+    y2 = eetq.w8_a16_gemm(x.reshape(2, M // 2, K), ql.q_weight, ql.scale_col)
+    ref2 = O.w8a16_linear(n(x), n(ql.q_weight), n(ql.scale_col))
+    assert y2.shape == (2, M // 2, N)
+    assert (np.abs(n(y2).reshape(M, N).astype(np.float32) - ref2.astype(np.float32)) <= ulp_tol(ref2)).all()
+
+
+def test_w8a16_full_size_linearity():
+    """Metric-size shape through size-independent properties: y(x1 + x2) = y(x1) + y(x2) for inputs whose sums are exact
+    in fp16, and sampled rows against the oracle."""
+    M, K, N = 512, 4096, 11008
+    rng = np.random.default_rng(5)
+    q = rng.integers(-128, 128, size=(K, N), dtype=np.int8)
+    s = (rng.random(N) * 0.004 + 0.001).astype(np.float16)
+    x1 = (rng.integers(-8, 9, size=(M, K)) / 8.0).astype(np.float16)
+    x2 = (rng.integers(-8, 9, size=(M, K)) / 8.0).astype(np.float16)
+    wp = mixlib.PackW8A16(t(q))
+    ts = t(s)
+    y1 = mixlib.W8A16Linear(t(x1), wp, ts, None, N, K).float()
+    y2 = mixlib.W8A16Linear(t(x2), wp, ts, None, N, K).float()
+    y12 = mixlib.W8A16Linear(t(x1 + x2), wp, ts, None, N, K).float()
+    tol = torch.from_numpy(ulp_tol(n(y12)) + ulp_tol(n(y1)) + ulp_tol(n(y2))).to(DEV)      # one rounding each
+    assert ((y12 - (y1 + y2)).abs() <= tol).all()
+    rows = [0, 1, 127, 128, 300, 511]
+    ref = O.w8a16_linear(x1[rows], q, s)
+    assert (np.abs(n(y1)[rows] - ref.astype(np.float32)) <= ulp_tol(ref)).all()
+
+
+def test_w8a16_cold_launches_have_no_stale_tile_patches():
+    """Regression: the staged output tile was once read back before a wave's last ds_writes had been performed
+    (raw s_barrier without lgkmcnt(0)); it showed only on cold launches of the 2-workgroups-per-CU config."""
+    M, N, K = 512, 11008, 1024
+    g = torch.Generator().manual_seed(0)
+    q = torch.randint(-128, 128, (K, N), generator=g, dtype=torch.int8).to(DEV)
+    s = (torch.rand(N, generator=g) * 0.01 + 0.001).half().to(DEV)
+    wdeq = q.float() * s.float()
+    lib = _capi.load()
+    keep = []
+    try:
+        for cfg in (2, 0):
+            assert lib.mixq_gemm_w8a16_set_config(cfg) == 0
+            for rep in range(10):
+                keep.append(torch.empty((rep + 1) * 3_000_000, dtype=torch.uint8, device=DEV))      # shift addresses
+                x = torch.randn(M, K, generator=g).half().to(DEV)
+                wp = mixlib.PackW8A16(q)
+                y = mixlib.W8A16Linear(x, wp, s, None, N, K)
+                ref = x.float() @ wdeq
+                assert ((y.float() - ref).abs() <= 0.01 * ref.abs().max()).all(), (cfg, rep)
+    finally:
+        lib.mixq_gemm_w8a16_set_config(-1)

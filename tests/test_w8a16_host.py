@@ -1,0 +1,106 @@
+"""SURVEY.md §8f row 4, host side on CPU: EETQ-style weight quantisation, the weight-only operator flow and its
+checkpoint layout, with the oracle standing in for the kernels (tests/backend_oracle.py).  Parity for this row is
+UNPINNED (EETQ is absent from the reference tree): the oracle restates the published FasterTransformer rule."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import backend_oracle
+from mixq_amd import MixLibCache, MixLinear_GEMM, eetq, linear as linmod
+from mixq_amd import checkpoint as ck
+from oracle import oracle as O
+
+
+@pytest.fixture(autouse=True)
+def _oracle_backend():
+    prev = linmod.set_backend(backend_oracle)
+    eetq.set_backend(backend_oracle)
+    backend_oracle.calls.clear()
+    yield
+    linmod.set_backend(prev)
+    from mixq_amd import mixlib
+    eetq.set_backend(mixlib)
+
+
+@pytest.mark.parametrize("K,N,seed", [(64, 16, 0), (256, 96, 1), (512, 40, 2)])
+def test_quant_weights_matches_oracle(K, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(K, N, generator=g) * 0.05).half()
+    w[:, 3] = 0                                   # all-zero output channel
+    w[5, 7] = w[:, 7].abs().max() * 2             # positive maximum -> 128 clips to 127
+    w[6, 8] = -w[:, 8].abs().max() * 2            # negative maximum -> exactly -128
+    q, s = eetq.quant_weights(w, torch.int8, False)
+    qo, so = O.quant_weight_w8a16(w.numpy())
+    assert q.dtype == torch.int8 and q.shape == (K, N) and s.dtype == torch.float16 and s.shape == (N,)
+    assert np.array_equal(q.numpy(), qo) and np.array_equal(s.numpy().view(np.uint16), so.view(np.uint16))
+    assert q[:, 3].abs().max() == 0 and s[3] == 0
+    assert q[5, 7] == 127 and q[6, 8] == -128
+    # dequantised weights are within half a quantisation step (+ the fp16 rounding of the stored scale, <= 128 * 2^-11
+    # steps; one whole step where the +128 clip bites)
+    err = (q.float() * s.float() - w.float()).abs()
+    bound = torch.where(q == 127, s.float() * 1.07, s.float() * 0.57) + 1e-7     # a column's positive maximum maps to 128
+    assert (err <= bound).all()
+
+
+def test_quant_weights_rejects_other_types():
+    with pytest.raises(NotImplementedError):
+        eetq.quant_weights(torch.zeros(4, 4).half(), torch.quint4x2, False)
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_weight_only_operator_flow(bias):
+    torch.manual_seed(0)
+    K, N, M = 256, 96, 24
+    lin = nn.Linear(K, N, bias=bias).half()
+    cache = MixLibCache(64, device="cpu")
+    q = MixLinear_GEMM.from_linear(lin, bit=8, weight_only=True, cache=cache, dev="cpu", name="fc_out")
+    assert q.weight_only and q.q_weight.shape == (K, N) and q.q_weight.dtype == torch.int8 and q.scale_col.shape == (N,)
+    assert set(q.state_dict()) == ({"q_weight", "scale_col", "bias"} if bias else {"q_weight", "scale_col"})
+    qo, so = O.quant_weight_w8a16(lin.weight.data.t().contiguous().numpy())
+    assert np.array_equal(q.q_weight.numpy(), qo) and np.array_equal(q.scale_col.numpy().view(np.uint16), so.view(np.uint16))
+    x = torch.randn(2, M // 2, K).half()
+    y = q(x)
+    assert y.shape == (2, M // 2, N) and y.dtype == torch.float16 and cache.shape == (2, M // 2, N)
+    assert backend_oracle.calls == ["PackW8A16", "W8A16Linear"]
+    q(x)
+    assert backend_oracle.calls == ["PackW8A16", "W8A16Linear", "W8A16Linear"]          # packed copy is cached
+    ref = torch.nn.functional.linear(x.float(), (q.q_weight.float() * q.scale_col.float()).t(),
+                                     None if not bias else q.bias.float())
+    assert (y.float() - ref).abs().max() <= 1e-2
+    # against the unquantised layer: int8 weight error only
+    full = torch.nn.functional.linear(x.float(), lin.weight.float(), None if not bias else lin.bias.float())
+    assert (y.float() - full).abs().max() < 5e-2
+
+
+def test_eetq_surface_w8_a16_gemm():
+    torch.manual_seed(1)
+    w = (torch.randn(128, 32) * 0.1).half()
+    q, s = eetq.quant_weights(w, torch.int8, False)
+    assert eetq.preprocess_weights(q) is q
+    x = torch.randn(3, 5, 128).half()
+    y = eetq.w8_a16_gemm(x, q, s)
+    assert y.shape == (3, 5, 32)
+    assert np.array_equal(y.reshape(-1, 32).numpy(), O.w8a16_linear(x.reshape(-1, 128).numpy(), q.numpy(), s.numpy()))
+
+
+class GptjMlp(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc_in, self.fc_out = nn.Linear(128, 256), nn.Linear(256, 128)
+
+
+def test_gptj_policy_quantises_fc_out_weight_only(tmp_path):
+    torch.manual_seed(2)
+    m = GptjMlp().half()
+    cache = MixLibCache(64, device="cpu")
+    done = ck.quantize_(m, 8, cache, arch="GPTJForCausalLM")
+    assert done == {"fc_in": (8, False), "fc_out": (8, True)}
+    assert m.fc_out.weight_only and m.fc_out.q_weight.shape == (256, 128) and not m.fc_in.weight_only
+    ck.save_quantized(m, str(tmp_path), {"w_bit": 8})
+    fresh = GptjMlp().half()
+    ck.load_quantized(fresh, str(tmp_path), MixLibCache(64, device="cpu"), arch="GPTJForCausalLM")
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, fresh.state_dict()[k])
+    x = torch.randn(4, 256).half()
+    assert torch.equal(m.fc_out(x), fresh.fc_out(x))
