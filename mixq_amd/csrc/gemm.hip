@@ -661,14 +661,15 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // packed operands, tools/sweep_gemm.py over the Llama-2-7b/70b and Llama-3-8B shapes).  The winner per
 // shape in those sweeps is what this picks: 128x128 when N is small, 128x192 around N = 10-12k, 256x128 / 128x256 at
 // N = 14k, 256x256 when there are >= ~200 such tiles.  Row-strided (plain) operands feed slower but rank the same.
-const float g_tk[NUM_PICK] = {0.60f, 0.39f, 0.60f, 0.40f, 0.40f, 0.40f, 0.37f, 0.40f, 0.31f, 0.33f, 0.20f, 0.12f, 0.15f, 0.60f, 0.40f, 0.37f};
+const float g_tk[NUM_PICK] = {0.60f, 0.39f, 0.60f, 0.40f, 0.40f, 0.40f, 0.37f, 0.40f, 0.31f, 0.33f, 0.20f, 0.17f, 0.15f, 0.60f, 0.40f, 0.36f};
 int pick_config(int M, int N, int KB, bool packed) {
     (void)KB; (void)packed;
     double best = 1e30; int bi = 0;
     for (int c = 0; c < NUM_PICK; ++c) {
         const GemmConfig& g = g_cfgs[c];
         const int tiles = cdiv(M, g.bm) * cdiv(N, g.bn);
-        const int rounds = cdiv(tiles, 256);
+        // the 64x64 tile (40 KB of LDS) runs two or more workgroups per CU; its per-k-step figure is for that regime
+        const int rounds = cdiv(tiles, g.bm * g.bn <= 64 * 64 ? 512 : 256);
         // rows of a tile beyond M are wasted MFMA work but cost the same time: no correction needed; a tile much
         // taller than M (small-batch decode) just wastes LDS traffic, which the per-k-step numbers already contain
         const double t = rounds * static_cast<double>(g_tk[c]);
