@@ -9,8 +9,9 @@
 //    (q + 128) so that the int8 -> fp16 conversion in the k loop is two VALU per pair of elements:
 //        v_perm_b32   -> halves 0x6400 | u   (= 1024 + u exactly)
 //        v_pk_add_f16 -> - 1152              (= u - 128 = q, exact)
-//  * X stays the caller's fp16 [M,K] matrix; a k-step (64 elements) of a tile is staged as two [BM x 64 B] sub-tiles
-//    by LDS-DMA with the 16-byte-chunk XOR swizzle applied on the source address,
+//  * X stays the caller's fp16 [M,K] matrix; a k-step (64 elements = 128 bytes per row) of a tile is staged by LDS-DMA
+//    in pieces of 8 rows x 128 bytes (whole 128-byte row segments feed a CU ~1.5x faster than 64-byte ones, DESIGN.md
+//    section 6) with an 8-chunk XOR swizzle (chunk c of row r at c ^ ((r >> 1) & 7)) applied on the source address,
 //  * v_mfma_f32_32x32x16_f16, weights as the A operand (a lane holds 4 consecutive output columns of one token, as in
 //    gemm.hip, so the epilogue layout is shared).  One 16-byte LDS read of a weight row feeds two MFMA k-steps; the k
 //    order inside a stage is permuted identically for both operands (MFMA step 2t+u, lane half h covers
@@ -33,7 +34,8 @@ __device__ __forceinline__ void wo_glds16(const uint8_t* gsrc, uint8_t* lds_wave
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ int wo_swz(int r, int c) { return c ^ ((r >> 2) & 3); }
+__device__ __forceinline__ int wo_swz(int r, int c) { return c ^ ((r >> 2) & 3); }       // weights: 4 chunks per row
+__device__ __forceinline__ int wo_swz8(int r, int c) { return c ^ ((r >> 1) & 7); }      // tokens: 8 chunks per row
 __device__ __forceinline__ void wo_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -47,13 +49,14 @@ __device__ __forceinline__ void cvt_u8x4(uint32_t d, uint32_t& o0, uint32_t& o1)
     o1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2_t, p1) - off);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int LOADERS>
+// ABL (tuning only): 0 normal, 2 no DMA, 3 MFMA only, 4 MFMA + conversions
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int LOADERS, int ABL = 0>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_w8a16_kernel(const WoArgs a)
 {
     constexpr int CW = WAVES_M * WAVES_N, NT = (CW + LOADERS) * 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
-    constexpr int W_BYTES = BN * 64, XH_BYTES = BM * 64, STAGE_BYTES = W_BYTES + 2 * XH_BYTES;
-    constexpr int WP = BN / 16, XP = 2 * (BM / 16), TI = WP + XP;               // 1-KiB DMA pieces per stage
+    constexpr int W_BYTES = BN * 64, X_BYTES = BM * 128, STAGE_BYTES = W_BYTES + X_BYTES;
+    constexpr int WP = BN / 16, XP = BM / 8, TI = WP + XP;                      // 1-KiB DMA pieces per stage
     constexpr int LOADS = (TI + LOADERS - 1) / LOADERS;
     constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
     constexpr int OPITCH = BN * 2 + 16;
@@ -81,7 +84,6 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_w8a16
         const int iw = wave - CW;
         const uint8_t* nsrc[LOADS];
         int kstr[LOADS], loff[LOADS];
-        const int r = lane >> 2, pc = lane & 3;
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             int pw = i * LOADERS + iw;
@@ -92,19 +94,19 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_w8a16
                 nsrc[i] = a.w + static_cast<size_t>(rb) * 1024 + lane * 16;
                 kstr[i] = a.wrows16 * 64;
                 loff[i] = pw * 1024;
-            } else {                                                            // 16 token rows x 64 bytes (32 halves)
-                const int xp = pw - WP, h = xp / (BM / 16), rbx = xp % (BM / 16);
-                int row = m0 + rbx * 16 + r;
+            } else {                                                            // 8 token rows x 128 bytes (64 halves)
+                const int xp = pw - WP, r = xp * 8 + (lane >> 3), pc = lane & 7;
+                int row = m0 + r;
                 row = row < a.M ? row : a.M - 1;
-                nsrc[i] = reinterpret_cast<const uint8_t*>(a.x) + static_cast<size_t>(row) * a.ldx * 2 + h * 64 + wo_swz(r, pc) * 16;
+                nsrc[i] = reinterpret_cast<const uint8_t*>(a.x) + static_cast<size_t>(row) * a.ldx * 2 + wo_swz8(r, pc) * 16;
                 kstr[i] = 128;
-                loff[i] = W_BYTES + h * XH_BYTES + rbx * 1024;
+                loff[i] = W_BYTES + xp * 1024;
             }
         }
         auto stage = [&](int buf) {
             uint8_t* base = lds + buf * STAGE_BYTES;
 #pragma unroll
-            for (int i = 0; i < LOADS; ++i) { wo_glds16(nsrc[i], base + loff[i]); nsrc[i] += kstr[i]; }
+            for (int i = 0; i < LOADS; ++i) { if constexpr (ABL == 0) wo_glds16(nsrc[i], base + loff[i]); nsrc[i] += kstr[i]; }
         };
 #pragma unroll
         for (int s = 0; s < LOOK; ++s)
@@ -145,8 +147,18 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_w8a16
 
         u32x4 wraw[2][NI];                   // raw weight chunk t of the stage (16 k-bytes: MFMA steps 2t and 2t+1)
         u32x4 xf[2][MI];                     // token fragments, by MFMA step parity
+        if constexpr (ABL != 0) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) { wraw[p][i] = u32x4{(uint32_t)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(wraw[p][i])); }
+#pragma unroll
+                for (int j = 0; j < MI; ++j) { xf[p][j] = u32x4{(uint32_t)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(xf[p][j])); }
+            }
+        }
         auto load_w = [&](auto t_c, int buf) {
             constexpr int T = decltype(t_c)::value;
+            if constexpr (ABL >= 3) return;
             const uint8_t* wb = lds + buf * STAGE_BYTES;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -154,26 +166,45 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_w8a16
         };
         auto load_x = [&](auto s_c, int buf) {
             constexpr int S = decltype(s_c)::value;                             // MFMA step 0..3 of the stage
-            const uint8_t* xb = lds + buf * STAGE_BYTES + W_BYTES + (S >> 1) * XH_BYTES;
+            if constexpr (ABL >= 3) return;
+            const uint8_t* xb = lds + buf * STAGE_BYTES + W_BYTES;
 #pragma unroll
-            for (int j = 0; j < MI; ++j)
-                xf[S & 1][j] = *reinterpret_cast<const u32x4*>(xb + xrow[j] * 64 + wo_swz(xrow[j], 2 * lh + (S & 1)) * 16);
+            for (int j = 0; j < MI; ++j)        // k = 16 (2t + lh) + 8u .. +8  ->  16-byte chunk 4t + 2 lh + u of the row
+                xf[S & 1][j] = *reinterpret_cast<const u32x4*>(xb + xrow[j] * 128 + wo_swz8(xrow[j], 4 * (S >> 1) + 2 * lh + (S & 1)) * 16);
         };
-        auto mma_step = [&](auto s_c) {
-            constexpr int S = decltype(s_c)::value, T = S >> 1, U = S & 1;
-            f16x8 wc[NI];
+        // The int8 -> fp16 conversion of the weight fragments of MFMA step S+1 is issued in the shadow of the MFMAs of
+        // step S (one cvt_u8x4 = 4 VALU behind an MFMA: what a wave can co-issue for free, tools/ubench_mfma_valu.hip);
+        // converted sets are double-buffered by step parity.
+        f16x8 wc[2][NI];
+        auto convert_unit = [&](auto sn_c, int u) {          // unit u of step SN: (weight block u / 2, dword u % 2)
+            constexpr int SN = decltype(sn_c)::value, T = SN >> 1, U = SN & 1;
+            const int i = u >> 1, d = u & 1;
+            uint32_t o0, o1;
+            cvt_u8x4(wraw[T][i][2 * U + d], o0, o1);
+            u32x4 t = __builtin_bit_cast(u32x4, wc[SN & 1][i]);
+            t[2 * d] = o0; t[2 * d + 1] = o1;
+            wc[SN & 1][i] = __builtin_bit_cast(f16x8, t);
+        };
+        auto mma_step = [&](auto s_c, auto convert_next_c) {
+            constexpr int S = decltype(s_c)::value, U = S & 1, SN = (S + 1) & 3;
+            constexpr bool CONV = decltype(convert_next_c)::value;
+            constexpr int NM = NI * MI, NU = 2 * NI;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                uint32_t o0, o1, o2, o3;
-                cvt_u8x4(wraw[T][i][2 * U], o0, o1);
-                cvt_u8x4(wraw[T][i][2 * U + 1], o2, o3);
-                wc[i] = __builtin_bit_cast(f16x8, u32x4{o0, o1, o2, o3});
+            for (int m = 0; m < NM; ++m) {
+                const int i = m / MI, j = m % MI;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[S & 1][i], __builtin_bit_cast(f16x8, xf[U][j]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (CONV && ABL != 3) {
+                    // late slots first: the raw chunk of step S+1 may have been requested at the start of this step
+                    constexpr int FIRST = NM > 2 ? 1 : 0;
+                    if (m >= FIRST) {
+#pragma unroll
+                        for (int u = (NU * (m - FIRST)) / (NM - FIRST); u < (NU * (m - FIRST + 1)) / (NM - FIRST); ++u)
+                            convert_unit(std::integral_constant<int, SN>{}, u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < MI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[i], __builtin_bit_cast(f16x8, xf[U][j]), acc[i][j], 0, 0, 0);
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
@@ -183,27 +214,36 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_w8a16
         __builtin_amdgcn_s_barrier();                                           // stage 0 landed
         wo_fence();
         load_w(S0{}, 0); load_x(S0{}, 0);
+#pragma unroll
+        for (int u = 0; u < 2 * NI; ++u) convert_unit(S0{}, u);
         int cur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
+        // one stage; NEXT: a following stage exists (its barrier sits in front of MFMA step 3).  The last stage is
+        // peeled so that the accumulators have a single definition inside the loop (no copies at a control-flow merge).
+        auto stage_body = [&](auto next_c) {
+            constexpr bool NEXT = decltype(next_c)::value;
             const int cur1 = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-            load_x(S1{}, cur);
-            mma_step(S0{});
+            load_x(S1{}, cur); load_w(S1{}, cur);
+            mma_step(S0{}, std::true_type{});
             wo_fence();
-            load_w(S1{}, cur); load_x(S2{}, cur);
-            mma_step(S1{});
+            load_x(S2{}, cur);
+            mma_step(S1{}, std::true_type{});
             wo_fence();
             load_x(S3{}, cur);
-            mma_step(S2{});
+            mma_step(S2{}, std::true_type{});
             wo_fence();
-            if (kt + 1 < nk) {
+            if constexpr (NEXT) {
                 __builtin_amdgcn_s_barrier();                                   // stage kt+1 landed and visible
                 wo_fence();
                 load_w(S0{}, cur1); load_x(S0{}, cur1);
+                mma_step(S3{}, std::true_type{});
+            } else {
+                mma_step(S3{}, std::false_type{});
             }
-            mma_step(S3{});
             wo_fence();
             cur = cur1;
-        }
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) stage_body(std::true_type{});
+        stage_body(std::false_type{});
 
         // ---- epilogue: y = acc * scale_col[n] (+ bias[n]) -> fp16 tile in LDS ---------------------------------------
         __builtin_amdgcn_s_barrier();                                           // every wave is done reading the ring
@@ -295,7 +335,11 @@ const WoConfig g_wo[] = {
     {"w8a16_128x192_w2x2_s4_l4", 128, 192, 8, 4, gemm_w8a16_kernel<128, 192, 2, 2, 4, 4>},
     {"w8a16_128x128_w2x2_s4_l4", 128, 128, 8, 4, gemm_w8a16_kernel<128, 128, 2, 2, 4, 4>},
     {"w8a16_64x128_w2x2_s4_l4",  64, 128, 8, 4, gemm_w8a16_kernel<64, 128, 2, 2, 4, 4>},
+    {"w8a16_128x192_abl2", 128, 192, 8, 4, gemm_w8a16_kernel<128, 192, 2, 2, 4, 4, 2>},     // tuning: no DMA
+    {"w8a16_128x192_abl3", 128, 192, 8, 4, gemm_w8a16_kernel<128, 192, 2, 2, 4, 4, 3>},     // tuning: MFMA only
+    {"w8a16_128x192_abl4", 128, 192, 8, 4, gemm_w8a16_kernel<128, 192, 2, 2, 4, 4, 4>},     // tuning: MFMA + conversions
 };
+constexpr int NUM_WO_PICK = 3;
 constexpr int NUM_WO = sizeof(g_wo) / sizeof(g_wo[0]);
 bool g_wo_attr[NUM_WO];
 int g_wo_forced = -1;
@@ -304,7 +348,7 @@ inline int wo_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int pick_wo(int M, int N) {
     double best = 1e30; int bi = 0;
-    for (int c = 0; c < NUM_WO; ++c) {
+    for (int c = 0; c < NUM_WO_PICK; ++c) {
         const int tiles = wo_cdiv(M, g_wo[c].bm) * wo_cdiv(N, g_wo[c].bn);
         // time ~ rounds x tile cost: MFMA work grows with bm*bn, the weight stream of a tile with bn
         const double t = wo_cdiv(tiles, 256) * (static_cast<double>(g_wo[c].bm) * g_wo[c].bn + 4096.0 * g_wo[c].bn / 64.0);

@@ -70,6 +70,15 @@ def test_argument_validation_without_device():
                                   None) == 0                                                        # M = 0
     assert lib.mixq_pack_p16x64(one, one, 4, 100, None) == _capi.MIXQ_ESHAPE
     assert lib.mixq_extract_outliers_zero(one, None, 3, one, 4, 64, 64, 3, None) == _capi.MIXQ_EINVAL
+    # weight-only W8A16
+    assert lib.mixq_pack_w8a16(one, one, 100, 64, None) == _capi.MIXQ_ESHAPE                        # K % 64
+    assert lib.mixq_pack_w8a16(None, one, 64, 64, None) == _capi.MIXQ_EINVAL
+    assert lib.mixq_gemm_w8a16(one, 128, one, one, None, one, 64, 4, 64, 100, None) == _capi.MIXQ_ESHAPE      # K % 64
+    assert lib.mixq_gemm_w8a16(one, 128, one, one, None, one, 64, 4, 62, 128, None) == _capi.MIXQ_ESHAPE      # N % 4
+    assert lib.mixq_gemm_w8a16(one, 100, one, one, None, one, 64, 4, 64, 128, None) == _capi.MIXQ_ESHAPE      # ldx < K
+    assert lib.mixq_gemm_w8a16(C.c_void_p(8), 128, one, one, None, one, 64, 4, 64, 128, None) == _capi.MIXQ_EINVAL  # x alignment
+    assert lib.mixq_gemm_w8a16(one, 128, one, one, None, one, 64, 0, 64, 128, None) == 0                      # M = 0
+    assert lib.mixq_gemm_w8a16_set_config(99) == _capi.MIXQ_EINVAL and lib.mixq_gemm_w8a16_set_config(-1) == 0
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):
