@@ -175,12 +175,12 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
             for (; kt + LOOK < nk; ++kt) {               // steady state: branch-free body
                 stage(nxt);
                 wait_vmcnt<LOADS * NEWER>();             // stage kt+1 landed, NEWER younger stages still in flight
-                __builtin_amdgcn_s_barrier();
+                if constexpr (ABL != 8) __builtin_amdgcn_s_barrier();
                 nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
             }
             for (; kt + 1 < nk; ++kt) {                  // drain
                 wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
+                if constexpr (ABL != 8) __builtin_amdgcn_s_barrier();
             }
             if constexpr (MODE != 2) {                   // take part in the epilogue's two barriers and its stores
                 __builtin_amdgcn_s_barrier();
@@ -358,7 +358,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                     if constexpr (ISSUE) wait_vmcnt<LOADS * NEWER>();
                     else                 wait_vmcnt<0>();
                 }
-                __builtin_amdgcn_s_barrier();
+                if constexpr (ABL != 8) __builtin_amdgcn_s_barrier();
                 region(I1{}, IND{}, I0{}, cur1, 0, nxt);                       // MFMA(set 1), first reads of stage kt+1
             } else {
                 region(I1{}, I0{}, I0{}, cur1, 0, nxt);
@@ -645,6 +645,7 @@ const GemmConfig g_cfgs[] = {
     MIXQ_ABL(128, 192, 2, 2, 5, 4, 2),  // 17: cfg 8, no DMA
     MIXQ_ABL(128, 192, 2, 2, 5, 4, 3),  // 18: cfg 8, MFMA only
     MIXQ_ABL(128, 192, 2, 2, 5, 4, 6),  // 19: cfg 8, epilogue without the optional terms compiled in (code size probe)
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 8),  // 20: cfg 8 without the k-loop barriers (timing probe: results are garbage)
 };
 constexpr int NUM_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 constexpr int NUM_PICK = 16;                       // configs the automatic choice may use (the rest are ablations)
