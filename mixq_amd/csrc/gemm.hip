@@ -31,6 +31,7 @@
 //    same XCD (same L2).  The tile shape is picked per problem so the tile count fills the 256 CUs.
 #include "common.h"
 #include "gemm_sk.h"
+#include "gemm_skinny.h"
 #include <stdio.h>
 #include <string.h>
 #include <type_traits>
@@ -736,6 +737,14 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
     a.x_packed = (layout & MIXQ_X_PACKED) ? 1 : 0; a.w_packed = (layout & MIXQ_W_PACKED) ? 1 : 0;
     a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
+    // small-batch form (gemm_skinny.hip): M <= 32, int8, packed operands: a weight stream, no LDS staging
+    {
+        const int skinny_id = NUM_CFGS + mixq_sk_num_configs();
+        if ((g_forced_cfg < 0 || g_forced_cfg == skinny_id) && mixq_skinny_applies(bit, M, N, KB, a.x_packed, a.w_packed))
+            return mixq_skinny_launch(q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+                                      ldy, M, N, KB, act, mixq_stream(stream));
+        if (g_forced_cfg == skinny_id) return MIXQ_EINVAL;
+    }
     // stream-K form (gemm_sk.hip): packed operands, workspace registered, chosen explicitly or by the shape rule
     if (a.x_packed && a.w_packed) {
         int sk = -1;
@@ -797,15 +806,16 @@ extern "C" int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_sca
 
 // Config ids: [0, NUM_CFGS) data-parallel tilings of this file, [NUM_CFGS, NUM_CFGS + sk) the stream-K forms.
 extern "C" int mixq_gemm_set_config(int cfg) {
-    if (cfg < -1 || cfg >= NUM_CFGS + mixq_sk_num_configs()) return MIXQ_EINVAL;
+    if (cfg < -1 || cfg >= NUM_CFGS + mixq_sk_num_configs() + 1) return MIXQ_EINVAL;
     g_forced_cfg = cfg;
     return MIXQ_OK;
 }
 extern "C" int mixq_gemm_set_trace(unsigned long long* buf) { g_trace = buf; return MIXQ_OK; }
-extern "C" int mixq_gemm_num_configs(void) { return NUM_CFGS + mixq_sk_num_configs(); }
+extern "C" int mixq_gemm_num_configs(void) { return NUM_CFGS + mixq_sk_num_configs() + 1; }
 extern "C" int mixq_gemm_config_name(int cfg, char* buf, int cap) {
-    if (cfg < 0 || cfg >= NUM_CFGS + mixq_sk_num_configs() || !buf || cap <= 0) return MIXQ_EINVAL;
-    snprintf(buf, cap, "%s", cfg < NUM_CFGS ? g_cfgs[cfg].name : mixq_sk_config_name(cfg - NUM_CFGS));
+    if (cfg < 0 || cfg >= NUM_CFGS + mixq_sk_num_configs() + 1 || !buf || cap <= 0) return MIXQ_EINVAL;
+    snprintf(buf, cap, "%s", cfg < NUM_CFGS ? g_cfgs[cfg].name
+                                           : (cfg < NUM_CFGS + mixq_sk_num_configs() ? mixq_sk_config_name(cfg - NUM_CFGS) : "decode32_i8"));
     return MIXQ_OK;
 }
 extern "C" int mixq_gemm_pick_config(int M, int N, int K, int bit) {

@@ -697,3 +697,48 @@ def test_w8a16_cold_launches_have_no_stale_tile_patches():
                 assert ((y.float() - ref).abs() <= 0.01 * ref.abs().max()).all(), (cfg, rep)
     finally:
         lib.mixq_gemm_w8a16_set_config(-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small-batch ("decode") kernel: M <= 32, packed int8 operands (gemm_skinny.hip)
+# ---------------------------------------------------------------------------------------------------------------
+def _skinny_id():
+    return _capi.gemm_config_names().index("decode32_i8")
+
+
+@pytest.mark.parametrize("M,N,K,n_out,bias,addend,act", [
+    (1, 64, 64, 0, False, False, 0), (5, 100, 512, 3, True, False, 0), (16, 4096, 4096, 41, False, False, 0),
+    (32, 1000, 1024, 128, True, True, 1), (17, 36, 11008, 17, False, True, 0), (32, 11008, 704, 0, True, False, 1),
+])
+def test_skinny_kernel_vs_oracle_and_tiled(M, N, K, n_out, bias, addend, act):
+    """Forced through the small-batch kernel: against the oracle, and bit-identical to the tiled kernel (same exact int32
+    accumulator, same epilogue arithmetic in the same order)."""
+    c = _fused_case(M, N, K, 8, seed=3 * M + N + K + n_out, n_out=n_out, bias=bias, addend=addend, act=act)
+    lib = _capi.load()
+    try:
+        assert lib.mixq_gemm_set_config(_skinny_id()) == 0
+        y = n(_run_fused(c, True))
+        assert lib.mixq_gemm_set_config(_capi.gemm_config_names().index("64x64_w2x2_s5_l1")) == 0
+        y_tiled = n(_run_fused(c, True))
+    finally:
+        lib.mixq_gemm_set_config(-1)
+    ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], addend=c["addend"], bias=c["bias"], act=act,
+                         bit=8).astype(np.float32)
+    assert np.isfinite(y).all()
+    assert (np.abs(y.astype(np.float32) - ref) <= ulp_tol(ref)).all()
+    assert np.array_equal(bits(y), bits(y_tiled))
+
+
+def test_skinny_is_the_automatic_choice_for_decode_and_refuses_large_batches():
+    lib = _capi.load()
+    c = _fused_case(8, 256, 512, 8, seed=1, n_out=5, bias=False, addend=False, act=0)
+    y_auto = n(_run_fused(c, True))
+    try:
+        assert lib.mixq_gemm_set_config(_skinny_id()) == 0
+        y_forced = n(_run_fused(c, True))
+        big = _fused_case(64, 256, 512, 8, seed=2, n_out=0, bias=False, addend=False, act=0)
+        with pytest.raises(_capi.MixqError):
+            _run_fused(big, True)                                # M > 32: not this kernel's job
+    finally:
+        lib.mixq_gemm_set_config(-1)
+    assert np.array_equal(bits(y_auto), bits(y_forced))
