@@ -741,7 +741,7 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     {
         const int skinny_id = NUM_CFGS + mixq_sk_num_configs();
         if ((g_forced_cfg < 0 || g_forced_cfg == skinny_id) && mixq_skinny_applies(bit, M, N, KB, a.x_packed, a.w_packed))
-            return mixq_skinny_launch(q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+            return mixq_skinny_launch(bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                                       ldy, M, N, KB, act, mixq_stream(stream));
         if (g_forced_cfg == skinny_id) return MIXQ_EINVAL;
     }
@@ -815,7 +815,7 @@ extern "C" int mixq_gemm_num_configs(void) { return NUM_CFGS + mixq_sk_num_confi
 extern "C" int mixq_gemm_config_name(int cfg, char* buf, int cap) {
     if (cfg < 0 || cfg >= NUM_CFGS + mixq_sk_num_configs() + 1 || !buf || cap <= 0) return MIXQ_EINVAL;
     snprintf(buf, cap, "%s", cfg < NUM_CFGS ? g_cfgs[cfg].name
-                                           : (cfg < NUM_CFGS + mixq_sk_num_configs() ? mixq_sk_config_name(cfg - NUM_CFGS) : "decode32_i8"));
+                                           : (cfg < NUM_CFGS + mixq_sk_num_configs() ? mixq_sk_config_name(cfg - NUM_CFGS) : "decode32"));
     return MIXQ_OK;
 }
 extern "C" int mixq_gemm_pick_config(int M, int N, int K, int bit) {

@@ -1,4 +1,4 @@
-// Small-batch ("decode") form of the fused W8A8 GEMM for gfx950: M <= 32 token rows, both operands in P16x64.
+// Small-batch ("decode") form of the fused W8A8 / W4A4 GEMM for gfx950: M <= 32 token rows, both operands in P16x64.
 //
 // At M <= 32 the GEMM is a weight stream: 2*M MACs per weight byte, i.e. HBM-/L2-bound, and the tiled kernel of gemm.hip
 // spends its time on per-k-step pipeline overhead (one barrier per 64 bytes of k for two MFMAs per wave) and cannot put
@@ -33,9 +33,11 @@ constexpr int SKW = 8;                                   // waves per workgroup 
 __device__ __forceinline__ int sk_swz(int r, int c) { return c ^ ((r >> 2) & 3); }
 __device__ __forceinline__ float sk_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
-// UNROLL: k-steps whose loads are in flight together (x2 buffers); MINW: waves per SIMD the register budget must allow
-template <int UNROLL, int MINW>
-__global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_i8_kernel(const SkinnyArgs a)
+// UNROLL: k-steps whose loads are in flight together (x2 buffers); MINW: waves per SIMD the register budget must allow.
+// I4: both operands nibble-packed int4 (KB = K/2 bytes per row): every 16-byte fragment is expanded in registers to the
+// two int8 fragments 16*q of its even / odd columns (as gemm.hip does) and the factor 256 leaves in the epilogue.
+template <int UNROLL, int MINW, bool I4>
+__global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_kernel(const SkinnyArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[SKW * 4096];    // [wave][4 reg groups][64 lanes] x 16 B
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
@@ -80,8 +82,23 @@ __global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_i8_kernel(const Sk
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (kb + u < k_hi) {                         // wave-uniform
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[P][u][0], xf[P][u][0], acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[P][u][1], xf[P][u][1], acc1, 0, 0, 0);
+                if constexpr (!I4) {
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[P][u][0], xf[P][u][0], acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[P][u][1], xf[P][u][1], acc1, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        i32x4 wl, wh, xl, xh;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t w = static_cast<uint32_t>(wf[P][u][sb][d]), x = static_cast<uint32_t>(xf[P][u][sb][d]);
+                            wl[d] = static_cast<int>((w << 4) & 0xf0f0f0f0u); wh[d] = static_cast<int>(w & 0xf0f0f0f0u);
+                            xl[d] = static_cast<int>((x << 4) & 0xf0f0f0f0u); xh[d] = static_cast<int>(x & 0xf0f0f0f0u);
+                        }
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wl, xl, acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh, xh, acc1, 0, 0, 0);
+                    }
+                }
             }
         }
     };
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_i8_kernel(const Sk
     };
     const int m = lr;                                                   // this lane's token row
     const int mc = m < a.M ? m : a.M - 1;
-    const float sxv = h2f(a.sx[mc]);
+    const float sxv = h2f(a.sx[mc]) * (I4 ? (1.f / 256.f) : 1.f);
     const int nloc = 4 * lh;                                            // columns nloc + 8 g + e
     float swv[16];
 #pragma unroll
@@ -194,10 +211,10 @@ __global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_i8_kernel(const Sk
 
 bool mixq_skinny_applies(int bit, int M, int N, int KB, bool x_packed, bool w_packed)
 {
-    return bit == 8 && M >= 1 && M <= 32 && x_packed && w_packed && (KB % 64) == 0 && N >= 4;
+    return (bit == 8 || bit == 4) && M >= 1 && M <= 32 && x_packed && w_packed && (KB % 64) == 0 && N >= 4;
 }
 
-int mixq_skinny_launch(const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col, const uint16_t* x_out,
+int mixq_skinny_launch(int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col, const uint16_t* x_out,
                        int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev, const uint16_t* addend,
                        int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act, hipStream_t st)
 {
@@ -206,6 +223,7 @@ int mixq_skinny_launch(const void* q_x, const void* q_w, const uint16_t* x_scale
     a.sx = x_scale; a.sw = scale_col; a.xo = x_out; a.wo = w_out; a.n_out_dev = n_out_dev; a.addend = addend; a.bias = bias; a.y = y;
     a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
     a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
-    hipLaunchKernelGGL((gemm_skinny_i8_kernel<4, 2>), dim3((N + 31) / 32), dim3(SKW * 64), 0, st, a);
+    if (bit == 8) hipLaunchKernelGGL((gemm_skinny_kernel<4, 2, false>), dim3((N + 31) / 32), dim3(SKW * 64), 0, st, a);
+    else          hipLaunchKernelGGL((gemm_skinny_kernel<4, 2, true>), dim3((N + 31) / 32), dim3(SKW * 64), 0, st, a);
     return mixq_launch_status();
 }

@@ -703,17 +703,19 @@ def test_w8a16_cold_launches_have_no_stale_tile_patches():
 # small-batch ("decode") kernel: M <= 32, packed int8 operands (gemm_skinny.hip)
 # ---------------------------------------------------------------------------------------------------------------
 def _skinny_id():
-    return _capi.gemm_config_names().index("decode32_i8")
+    return _capi.gemm_config_names().index("decode32")
 
 
-@pytest.mark.parametrize("M,N,K,n_out,bias,addend,act", [
-    (1, 64, 64, 0, False, False, 0), (5, 100, 512, 3, True, False, 0), (16, 4096, 4096, 41, False, False, 0),
-    (32, 1000, 1024, 128, True, True, 1), (17, 36, 11008, 17, False, True, 0), (32, 11008, 704, 0, True, False, 1),
+@pytest.mark.parametrize("M,N,K,n_out,bias,addend,act,bit", [
+    (1, 64, 64, 0, False, False, 0, 8), (5, 100, 512, 3, True, False, 0, 8), (16, 4096, 4096, 41, False, False, 0, 8),
+    (32, 1000, 1024, 128, True, True, 1, 8), (17, 36, 11008, 17, False, True, 0, 8), (32, 11008, 704, 0, True, False, 1, 8),
+    (16, 128, 512, 128, False, False, 0, 4), (7, 64, 1024, 16, True, False, 1, 4), (32, 4096, 4096, 128, False, True, 0, 4),
+    (1, 36, 128, 0, False, False, 0, 4),
 ])
-def test_skinny_kernel_vs_oracle_and_tiled(M, N, K, n_out, bias, addend, act):
+def test_skinny_kernel_vs_oracle_and_tiled(M, N, K, n_out, bias, addend, act, bit):
     """Forced through the small-batch kernel: against the oracle, and bit-identical to the tiled kernel (same exact int32
     accumulator, same epilogue arithmetic in the same order)."""
-    c = _fused_case(M, N, K, 8, seed=3 * M + N + K + n_out, n_out=n_out, bias=bias, addend=addend, act=act)
+    c = _fused_case(M, N, K, bit, seed=3 * M + N + K + n_out, n_out=n_out, bias=bias, addend=addend, act=act)
     lib = _capi.load()
     try:
         assert lib.mixq_gemm_set_config(_skinny_id()) == 0
@@ -723,7 +725,7 @@ def test_skinny_kernel_vs_oracle_and_tiled(M, N, K, n_out, bias, addend, act):
     finally:
         lib.mixq_gemm_set_config(-1)
     ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], addend=c["addend"], bias=c["bias"], act=act,
-                         bit=8).astype(np.float32)
+                         bit=bit).astype(np.float32)
     assert np.isfinite(y).all()
     assert (np.abs(y.astype(np.float32) - ref) <= ulp_tol(ref)).all()
     assert np.array_equal(bits(y), bits(y_tiled))

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--shapes", default="1x11008x4096,16x11008x4096,32x11008x4096,16x4096x4096,16x4096x11008")
     ap.add_argument("--cfgs", default="-1,12")
     ap.add_argument("--copies", type=int, default=10)
+    ap.add_argument("--bit", type=int, default=8)
     args = ap.parse_args()
     lib = _capi.load()
     names = _capi.gemm_config_names()
@@ -23,10 +24,11 @@ def main():
     for shp in args.shapes.split(","):
         M, N, K = (int(v) for v in shp.split("x"))
         g = torch.Generator().manual_seed(0)
-        qx = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(dev)
+        KB = K if args.bit == 8 else K // 2
+        qx = torch.randint(-127, 128, (M, KB), generator=g, dtype=torch.int8).to(dev)
         sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
         sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
-        ws = [mixlib.PackP16x64(torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(dev)) for _ in range(args.copies)]
+        ws = [mixlib.PackP16x64(torch.randint(-127, 128, (N, KB), generator=g, dtype=torch.int8).to(dev)) for _ in range(args.copies)]
         qxp = mixlib.PackP16x64(qx)
         out = torch.empty(M, N, dtype=torch.float16, device=dev)
         for c in [int(v) for v in args.cfgs.split(",")]:
@@ -34,13 +36,13 @@ def main():
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 for w in ws:
-                    mixlib.FusedLinear(qxp, w, sx, sw, None, None, 0, None, M, N, K, out=out, x_packed=True, w_packed=True)
+                    mixlib.FusedLinear(qxp, w, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out, x_packed=True, w_packed=True)
                 torch.cuda.synchronize()
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr, stream=st):
                     for _ in range(3):
                         for w in ws:
-                            mixlib.FusedLinear(qxp, w, sx, sw, None, None, 0, None, M, N, K, out=out, x_packed=True, w_packed=True)
+                            mixlib.FusedLinear(qxp, w, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out, x_packed=True, w_packed=True)
                 torch.cuda.synchronize()
                 gr.replay()
                 torch.cuda.synchronize()
@@ -52,7 +54,7 @@ def main():
                 torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (5 * 3 * len(ws))
             name = "auto" if c < 0 else names[c]
-            print(f"{shp} {name:24s} {us:8.2f} us  {N * K / us / 1e6:6.2f} TB/s of weights (cold)", flush=True)
+            print(f"{shp} {name:24s} {us:8.2f} us  {N * KB / us / 1e6:6.2f} TB/s of weights (cold)", flush=True)
         lib.mixq_gemm_set_config(-1)
 
 
