@@ -300,6 +300,113 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_w8a16
     }
 }
 
+// ---- small-batch (decode) form: M <= 32 ----------------------------------------------------------------------------
+// A weight stream, like gemm_skinny.hip: one workgroup per 32 output channels, its 8 waves split K, fragments go
+// global -> VGPR -> MFMA (weights: the packed offset-binary image; activations: the caller's fp16 rows, L2-resident), no LDS
+// staging, no barrier in the k loop.  The 8 fp32 partial tiles are summed through LDS in wave order (a fixed order: results
+// are reproducible run to run), wave 0 applies scale_col and bias.
+constexpr int WSK = 8, WUN = 2;
+__global__ __launch_bounds__(WSK * 64, 2) void gemm_w8a16_skinny_kernel(const WoArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WSK * 4096];
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = wave_id_uniform();
+    const int n0 = blockIdx.x * 32;
+    const int nk = a.K / 64;
+    const int k_lo = (nk * wave) / WSK, k_hi = (nk * (wave + 1)) / WSK;
+    int wr = n0 + lr; wr = wr < a.N ? wr : a.N - 1;
+    const int xr = lr < a.M ? lr : a.M - 1;
+    const uint8_t* wp = a.w + static_cast<size_t>(wr >> 4) * 1024 + (wr & 15) * 64;
+    const uint8_t* xp = reinterpret_cast<const uint8_t*>(a.x) + static_cast<size_t>(xr) * a.ldx * 2 + lh * 32;
+    const int wc0 = wo_swz(wr, lh) * 16, wc1 = wo_swz(wr, 2 + lh) * 16;      // chunk 2t + lh: MFMA steps 2t and 2t + 1
+    const size_t wks = static_cast<size_t>(a.wrows16) * 64;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    u32x4 wf[2][WUN][2], xf[2][WUN][4];
+    auto load_group = [&](auto p_c, int kb) {
+        constexpr int P = decltype(p_c)::value;
+#pragma unroll
+        for (int u = 0; u < WUN; ++u) {
+            int k = kb + u; k = k < k_hi ? k : k_hi - 1;
+            const uint8_t* w = wp + k * wks;
+            const uint8_t* x = xp + static_cast<size_t>(k) * 128;        // k = 16 (2t + lh) + 8u: byte 64 t + 32 lh + 16 u
+            wf[P][u][0] = *reinterpret_cast<const u32x4*>(w + wc0);
+            wf[P][u][1] = *reinterpret_cast<const u32x4*>(w + wc1);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                xf[P][u][s4] = *reinterpret_cast<const u32x4*>(x + (s4 >> 1) * 64 + (s4 & 1) * 16);
+        }
+    };
+    auto mma_group = [&](auto p_c, int kb) {
+        constexpr int P = decltype(p_c)::value;
+#pragma unroll
+        for (int u = 0; u < WUN; ++u) {
+            if (kb + u < k_hi) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    uint32_t o0, o1, o2, o3;
+                    cvt_u8x4(wf[P][u][s4 >> 1][2 * (s4 & 1)], o0, o1);
+                    cvt_u8x4(wf[P][u][s4 >> 1][2 * (s4 & 1) + 1], o2, o3);
+                    const f16x8 wc = __builtin_bit_cast(f16x8, u32x4{o0, o1, o2, o3});
+                    if (s4 & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc, __builtin_bit_cast(f16x8, xf[P][u][s4]), acc1, 0, 0, 0);
+                    else        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc, __builtin_bit_cast(f16x8, xf[P][u][s4]), acc0, 0, 0, 0);
+                }
+            }
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if (k_lo < k_hi) {
+        load_group(P0{}, k_lo);
+        for (int kb = k_lo; kb < k_hi; kb += 2 * WUN) {
+            if (kb + WUN < k_hi) load_group(P1{}, kb + WUN);
+            mma_group(P0{}, kb);
+            if (kb + WUN < k_hi) {
+                if (kb + 2 * WUN < k_hi) load_group(P0{}, kb + 2 * WUN);
+                mma_group(P1{}, kb + WUN);
+            }
+        }
+    }
+    f32x16 acc = acc0 + acc1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(lds + (wave * 4 + g) * 1024 + lane * 16) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(lds + g * 1024 + lane * 16);
+#pragma unroll
+        for (int w = 1; w < WSK; ++w) s += *reinterpret_cast<const f32x4*>(lds + (w * 4 + g) * 1024 + lane * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = s[e];
+    }
+    auto unpack4 = [](u32x2 v, float* o) {
+        o[0] = h2f(static_cast<uint16_t>(v.x & 0xffffu)); o[1] = h2f(static_cast<uint16_t>(v.x >> 16));
+        o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
+    };
+    const int m = lr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n0 + 4 * lh + 8 * g;
+        const int nc = n < a.N ? n : a.N - 4;
+        float sv[4], bv[4] = {0.f, 0.f, 0.f, 0.f};
+        unpack4(*reinterpret_cast<const u32x2_u*>(a.sw + nc), sv);
+        if (a.bias) unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+        if (m < a.M && n < a.N) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[4 * g + e] * sv[e]; if (a.bias) v[e] += bv[e]; }
+            u32x2 o;
+            o.x = static_cast<uint32_t>(f2h(v[0])) | (static_cast<uint32_t>(f2h(v[1])) << 16);
+            o.y = static_cast<uint32_t>(f2h(v[2])) | (static_cast<uint32_t>(f2h(v[3])) << 16);
+            *reinterpret_cast<u32x2_u*>(a.y + static_cast<size_t>(m) * a.ldy + n) = o;
+        }
+    }
+}
+
 // One-time re-tiling of the checkpoint's [K,N] int8 matrix into offset-binary P16x64 (rows = output channels).
 __global__ __launch_bounds__(256) void pack_w8a16_kernel(const int8_t* __restrict__ qkn, uint8_t* __restrict__ dst, int K, int N, int rows16)
 {
@@ -377,12 +484,17 @@ extern "C" int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_pack
     if ((K % 64) || (N & 3) || (ldy & 3) || ldy < N || ldx < K || (ldx & 7)) return MIXQ_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) return MIXQ_EINVAL;
     if (M == 0 || N == 0) return MIXQ_OK;
-    const int c = (g_wo_forced >= 0 && g_wo_forced < NUM_WO) ? g_wo_forced : pick_wo(M, N);
-    const WoConfig& g = g_wo[c];
     WoArgs a;
     a.x = x; a.w = w_packed; a.sw = scale_col; a.bias = bias; a.y = y;
-    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldy = ldy;
-    a.tiles_m = wo_cdiv(M, g.bm); a.tiles_n = wo_cdiv(N, g.bn); a.wrows16 = (N + 15) & ~15;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldy = ldy; a.tiles_m = a.tiles_n = 0; a.wrows16 = (N + 15) & ~15;
+    if ((g_wo_forced < 0 && M <= 32) || g_wo_forced == NUM_WO) {                 // small batch: the weight-stream form
+        if (M > 32) return MIXQ_EINVAL;
+        hipLaunchKernelGGL(gemm_w8a16_skinny_kernel, dim3((N + 31) / 32), dim3(WSK * 64), 0, mixq_stream(stream), a);
+        return mixq_launch_status();
+    }
+    const int c = (g_wo_forced >= 0 && g_wo_forced < NUM_WO) ? g_wo_forced : pick_wo(M, N);
+    const WoConfig& g = g_wo[c];
+    a.tiles_m = wo_cdiv(M, g.bm); a.tiles_n = wo_cdiv(N, g.bn);
     const size_t shm = static_cast<size_t>(g.bn * 64 + g.bm * 128) * g.nstage;
     if (!g_wo_attr[c]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(g.k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
@@ -394,7 +506,7 @@ extern "C" int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_pack
 }
 
 extern "C" int mixq_gemm_w8a16_set_config(int cfg) {
-    if (cfg < -1 || cfg >= NUM_WO) return MIXQ_EINVAL;
+    if (cfg < -1 || cfg > NUM_WO) return MIXQ_EINVAL;          // NUM_WO = the small-batch kernel
     g_wo_forced = cfg;
     return MIXQ_OK;
 }
