@@ -145,6 +145,8 @@ class MixLinear_GEMM(nn.Module):
         self._wstore = None          # _ColStore behind weight_cache once outliers were appended online
         self._wpk = None             # q_weight re-tiled to P16x64 (built once, on the first forward)
         self._wpk_key = None
+        self._wo_ready = None        # weight_cache in the GEMM tail's padded layout (built when it is not already)
+        self._wo_key = None
 
     # ------------------------------------------------------------------------------------------------------
     @classmethod
@@ -234,7 +236,15 @@ class MixLinear_GEMM(nn.Module):
     def _gemm(self, cache, M, act):
         n = int(self.ind.shape[0])
         xo = _gemm_ready(cache.activation_outliers) if n else None
-        wo = _gemm_ready(self.weight_cache) if n else None
+        wo = None
+        if n:
+            # weight_cache is static between outlier appends: re-pad it (e.g. a [N,129] buffer loaded from a checkpoint)
+            # once, not on every forward
+            wc = self.weight_cache
+            key = (wc.data_ptr(), wc._version, tuple(wc.shape), wc.stride(0))
+            if self._wo_key != key:
+                self._wo_ready, self._wo_key = _gemm_ready(wc), key
+            wo = self._wo_ready
         if n and (xo is None or wo is None or xo.shape[1] != n or wo.shape[1] != n):
             raise RuntimeError("MixLinear_GEMM: outlier operands do not match `ind`")
         wpk = self._packed_weight()
