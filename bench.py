@@ -34,7 +34,7 @@ SIGMA = 6
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")

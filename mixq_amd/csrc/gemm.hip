@@ -436,13 +436,15 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                 o[0] = h2f(static_cast<uint16_t>(v.x & 0xffffu)); o[1] = h2f(static_cast<uint16_t>(v.x >> 16));
                 o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
             };
-            // fp16 outlier tail: operands of k-step kk+1 are requested before the MFMAs of k-step kk, and those of
-            // k-step 0 before the barrier, so the whole tail exposes (at most) one memory round trip.
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            u32x4 xoq[2][MI], woq[2][NI];
-            auto tail_load = [&](auto p_c, int kk) {
-                constexpr int P = decltype(p_c)::value;
+            // fp16 outlier tail: the operands of TD k-steps are in flight at once (a ring of TD register sets: k-step 0 is
+            // requested before the barrier, 1..TD-1 after the dequantisation, set d again for k-step kk+TD right after its
+            // MFMAs), so the tail exposes one memory round trip per TD k-steps instead of one per k-step.  Small tiles
+            // have few MFMAs per k-step to hide a round trip behind and registers to spare: deeper ring.
+            constexpr int REG_CAP = 512 / ((CW + LOADERS + 3) / 4);        // VGPRs per wave at this workgroup's occupancy
+            constexpr int TD_FIT = (REG_CAP - NI * MI * 16 - 100) / ((NI + MI) * 4);
+            constexpr int TD = TD_FIT < 2 ? 2 : (TD_FIT > 8 ? 8 : TD_FIT);
+            u32x4 xoq[TD][MI], woq[TD][NI];
+            auto tail_load = [&](int P, int kk) {            // P: a constant after unrolling
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
                     int xr = m0 + xrow[j]; xr = xr < a.M ? xr : a.M - 1;
@@ -454,7 +456,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                     woq[P][i] = *reinterpret_cast<const u32x4*>(a.wo + static_cast<size_t>(wr) * a.ldwo + lh * 8 + kk * 16);
                 }
             };
-            if (ksteps > 0) tail_load(I0{}, 0);
+            if (ksteps > 0) tail_load(0, 0);                                   // the rest of the ring: after the dequantisation
             if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // every wave is done reading the ring
             stamp(6);
 
@@ -470,8 +472,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
 #pragma unroll
                     for (int r = 0; r < 16; ++r) fa[i][j][r] = static_cast<float>(acc[i][j][r]) * sxv[j] * swv[r];
             }
-            auto tail_mma = [&](auto p_c, int kk) {
-                constexpr int P = decltype(p_c)::value;
+            auto tail_mma = [&](int P, int kk) {
                 const int kb = kk * 16 + lh * 8;                     // mask columns >= n_out (the pad may hold anything)
                 if (kb + 8 > n_out) {
 #pragma unroll
@@ -492,12 +493,17 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                         fa[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, woq[P][i]),
                                                                           __builtin_bit_cast(f16x8, xoq[P][j]), fa[i][j], 0, 0, 0);
             };
-            for (int kk = 0; kk < ksteps; kk += 2) {
-                if (kk + 1 < ksteps) tail_load(I1{}, kk + 1);
-                tail_mma(I0{}, kk);
-                if (kk + 1 < ksteps) {
-                    if (kk + 2 < ksteps) tail_load(I0{}, kk + 2);
-                    tail_mma(I1{}, kk + 1);
+#pragma unroll
+            for (int d = 1; d < TD; ++d)
+                if (d < ksteps) tail_load(d, d);
+            for (int kk0 = 0; kk0 < ksteps; kk0 += TD) {
+#pragma unroll
+                for (int d = 0; d < TD; ++d) {
+                    const int kk = kk0 + d;
+                    if (kk < ksteps) {
+                        tail_mma(d, kk);
+                        if (kk + TD < ksteps) tail_load(d, kk + TD);
+                    }
                 }
             }
 
@@ -671,7 +677,7 @@ int pick_config(int M, int N, int KB, bool packed) {
         const GemmConfig& g = g_cfgs[c];
         const int tiles = cdiv(M, g.bm) * cdiv(N, g.bn);
         // the 64x64 tile (40 KB of LDS) runs two or more workgroups per CU; its per-k-step figure is for that regime
-        const int rounds = cdiv(tiles, g.bm * g.bn <= 64 * 64 ? 512 : 256);
+        const int rounds = cdiv(tiles, (g.bm == 64 && g.bn == 64) ? 512 : 256);
         // rows of a tile beyond M are wasted MFMA work but cost the same time: no correction needed; a tile much
         // taller than M (small-batch decode) just wastes LDS traffic, which the per-k-step numbers already contain
         const double t = rounds * static_cast<double>(g_tk[c]);
@@ -684,7 +690,11 @@ int pick_config(int M, int N, int KB, bool packed) {
 // (tools/sweep_gemm.py), M = 512: 4096x11008 46.1 -> 39.3 us, 4096x14336 54.9 -> 43.4 us with sk128x128; at K = 4096
 // (4096x4096: 21.3 vs 22.7 us) and whenever the tiling already fills the chip (11008x4096: 30 vs 43 us) the partial-tile
 // hand-off (~8 us per workgroup) costs more than the idle CUs.  Returns a gemm_sk.hip config id or -1.
-int g_auto_sk = 1;
+// Not chosen automatically any more: since the data-parallel epilogue was rewritten (straight-line dequant, burst-prefetched
+// outlier tail) the 64x64 / 128x128 tilings match stream-K without outlier columns (35.4 vs 35.8 us at 512 x 11008 -> 4096)
+// and beat it with the 1 % outlier columns of the real workload, whose tail stream-K still pays per 32x32 block.  The
+// kernels stay selectable through mixq_gemm_set_config and stay under test.
+int g_auto_sk = 0;
 int pick_stream_k(int M, int N, int KB) {
     if (!g_auto_sk || M < 128 || N < 128) return -1;
     const int nk = KB / 64;

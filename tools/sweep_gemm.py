@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--packed", default="0,1")
     ap.add_argument("--out", default="gpurun_out/sweep_gemm.json")
+    ap.add_argument("--nout", type=int, default=0, help="outlier columns fed to the fp16 tail (timing; the error check ignores them)")
     args = ap.parse_args()
     dev = "cuda"
     lib = _capi.load()
@@ -86,6 +87,11 @@ def main():
         flops = 2.0 * M * N * K
         qxp = mixlib.PackP16x64(qx) if (K if args.bit == 8 else K // 2) % 64 == 0 else None
         qwp = mixlib.PackP16x64(qw) if qxp is not None else None
+        xo = wo = None
+        if args.nout:
+            pad = (args.nout + 15) // 16 * 16
+            xo = torch.zeros((M, pad), dtype=torch.float16, device=dev)[:, :args.nout]
+            wo = torch.zeros((N, pad), dtype=torch.float16, device=dev)[:, :args.nout]
         for c, krot in [(c, int(kr)) for c in cfgs for kr in args.packed.split(",")]:
             if krot and (qxp is None or "x128_" in names[c].split("_w")[0][-5:]):
                 continue
@@ -94,7 +100,7 @@ def main():
             rc = lib.mixq_gemm_set_config(c)
             assert rc == 0
             try:
-                y = mixlib.FusedLinear(ax, aw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, **pk)
+                y = mixlib.FusedLinear(ax, aw, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, **pk)
                 torch.cuda.synchronize()
             except Exception as ex:  # config incompatible with the shape
                 print(f"{shp} cfg{c} {names[c]}: {ex}", flush=True)
@@ -102,8 +108,8 @@ def main():
             err = (y.double() - ref).abs().max().item()
             rel = err / ref.abs().max().item()
             out = torch.empty_like(y)
-            us = time_fn(lambda: mixlib.FusedLinear(ax, aw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out, **pk), args.iters)
-            usg = time_graph(lambda: mixlib.FusedLinear(ax, aw, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out, **pk), args.iters)
+            us = time_fn(lambda: mixlib.FusedLinear(ax, aw, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out, **pk), args.iters)
+            usg = time_graph(lambda: mixlib.FusedLinear(ax, aw, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out, **pk), args.iters)
             tops = flops / usg / 1e6
             r = dict(shape=shp, cfg=c, krot=krot, name=names[c], bit=args.bit, max_abs_err=err, rel_err=rel, us_eager=us, us_graph=usg,
                      tops=tops, frac=tops / PEAK_TOPS)
