@@ -182,7 +182,7 @@ int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_packed, const u
 int mixq_gemm_w8a16_set_config(int cfg);             /* tuning: force a tile config, -1 = automatic */
 
 /* ---- stream-K workspace ---------------------------------------------------------------------------------
- * The stream-K form of the GEMM (chosen for shapes whose tile count leaves CUs idle, e.g. M = 512, N = 11008) hands
+ * The stream-K form of the GEMM (opt-in through mixq_gemm_set_config) hands
  * int32 partial tiles between workgroups through a device buffer the HOST provides once:
  *   mixq_gemm_workspace_bytes()  size to allocate; mixq_gemm_set_workspace(ptr, bytes) registers it (bytes = 0
  *   unregisters).  The buffer must be zero-filled when registered; every launch leaves its flag words zero.
