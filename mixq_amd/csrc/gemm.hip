@@ -653,9 +653,11 @@ const GemmConfig g_cfgs[] = {
     MIXQ_ABL(128, 192, 2, 2, 5, 4, 3),  // 18: cfg 8, MFMA only
     MIXQ_ABL(128, 192, 2, 2, 5, 4, 6),  // 19: cfg 8, epilogue without the optional terms compiled in (code size probe)
     MIXQ_ABL(128, 192, 2, 2, 5, 4, 8),  // 20: cfg 8 without the k-loop barriers (timing probe: results are garbage)
+    MIXQ_CFG(64, 128, 2, 2, 5, 2),      // 21: 4 consumers 32 x 64 + 2 loaders: N = 4096 at M = 512 is exactly 256 such tiles
+    MIXQ_CFG(64, 128, 2, 2, 5, 4),      // 22
+    MIXQ_CFG(64, 192, 2, 2, 5, 4),      // 23: 4 consumers 32 x 96
 };
 constexpr int NUM_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
-constexpr int NUM_PICK = 16;                       // configs the automatic choice may use (the rest are ablations)
 
 int g_forced_cfg = -1;
 unsigned long long* g_trace = nullptr;             // diagnostics: see mixq_gemm_set_trace
@@ -667,20 +669,24 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 //   MFMA: BM*BN*64*2 ops at 8192 ops/clk/CU;  feed: (BM+BN)*64 bytes at ~48 B/clk/CU (packed) / 25 (plain rows).
 // Shape-aware choice.  Score = rounds over the 256 CUs x measured time per k-step of one tile (microseconds, MI355X,
 // packed operands, tools/sweep_gemm.py over the Llama-2-7b/70b and Llama-3-8B shapes).  The winner per
-// shape in those sweeps is what this picks: 128x128 when N is small, 128x192 around N = 10-12k, 256x128 / 128x256 at
-// N = 14k, 256x256 when there are >= ~200 such tiles.  Row-strided (plain) operands feed slower but rank the same.
-const float g_tk[NUM_PICK] = {0.60f, 0.39f, 0.60f, 0.40f, 0.40f, 0.40f, 0.37f, 0.40f, 0.31f, 0.33f, 0.20f, 0.17f, 0.15f, 0.60f, 0.40f, 0.36f};
+// shape in those sweeps is what this picks: whichever tile makes close to 256 tiles wins - 64x128 at N = 4096, 64x192 at
+// N = 6144, 128x128 at N = 8192, 128x192 around N = 10-12k, 128x256 at N = 14k, 256x256 when there are >= ~200 such tiles.  Row-strided (plain) operands feed slower but rank the same.
+struct PickEntry { int cfg; float tk; };
+const PickEntry g_pick[] = {{0, 0.60f}, {1, 0.39f}, {2, 0.60f}, {3, 0.40f}, {4, 0.40f}, {5, 0.40f}, {6, 0.37f}, {7, 0.40f}, {8, 0.31f},
+                            {9, 0.33f}, {10, 0.26f}, {11, 0.17f}, {12, 0.15f}, {13, 0.60f}, {14, 0.40f}, {15, 0.36f}, {22, 0.165f}, {23, 0.21f}};
+constexpr int NUM_PICK = sizeof(g_pick) / sizeof(g_pick[0]);
 int pick_config(int M, int N, int KB, bool packed) {
     (void)KB; (void)packed;
     double best = 1e30; int bi = 0;
-    for (int c = 0; c < NUM_PICK; ++c) {
+    for (int pi = 0; pi < NUM_PICK; ++pi) {
+        const int c = g_pick[pi].cfg;
         const GemmConfig& g = g_cfgs[c];
         const int tiles = cdiv(M, g.bm) * cdiv(N, g.bn);
         // the 64x64 tile (40 KB of LDS) runs two or more workgroups per CU; its per-k-step figure is for that regime
         const int rounds = cdiv(tiles, (g.bm == 64 && g.bn == 64) ? 512 : 256);
         // rows of a tile beyond M are wasted MFMA work but cost the same time: no correction needed; a tile much
         // taller than M (small-batch decode) just wastes LDS traffic, which the per-k-step numbers already contain
-        const double t = rounds * static_cast<double>(g_tk[c]);
+        const double t = rounds * static_cast<double>(g_pick[pi].tk);
         if (t < best * 0.999) { best = t; bi = c; }
     }
     return bi;
