@@ -744,3 +744,41 @@ def test_skinny_is_the_automatic_choice_for_decode_and_refuses_large_batches():
     finally:
         lib.mixq_gemm_set_config(-1)
     assert np.array_equal(bits(y_auto), bits(y_forced))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# randomized exactness / race hunting: every real tiling, odd shapes, cold allocations, repeated launches
+# ---------------------------------------------------------------------------------------------------------------
+def test_randomized_shapes_all_tilings_bit_exact():
+    """With int8 operands and power-of-two scales acc * sx * sw is exact in fp32, so every tiling (and the decode kernel)
+    must reproduce the correctly rounded int64 CPU matmul bit for bit - on freshly allocated buffers, launch after launch.  This is
+    the net that would have caught the epilogue's LDS write/read race (it only showed on cold launches of the tilings
+    that run several workgroups per CU)."""
+    rng = np.random.default_rng(2024)
+    names = _capi.gemm_config_names()
+    real = [i for i, nm in enumerate(names) if "abl" not in nm and not nm.startswith("sk") and not nm.startswith("decode")]
+    decode = names.index("decode32")
+    lib = _capi.load()
+    keep = []
+    try:
+        for case in range(24):
+            M = int(rng.choice([1, 7, 16, 32, 33, 64, 100, 128, 200, 257, 512]))
+            N = int(rng.integers(1, 400)) * 4
+            K = int(rng.integers(1, 40)) * 64
+            cfg = decode if (M <= 32 and case % 3 == 0) else int(rng.choice(real))
+            qx = rng.integers(-127, 128, size=(M, K), dtype=np.int8)
+            qw = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+            want = (qx.astype(np.int64) @ qw.astype(np.int64).T).astype(np.float64) * 2.0 ** -14
+            want16 = want.astype(np.float16)
+            sx = torch.full((M, 1), 2.0 ** -7, dtype=torch.float16, device=DEV)
+            sw = torch.full((1, N), 2.0 ** -7, dtype=torch.float16, device=DEV)
+            assert lib.mixq_gemm_set_config(cfg) == 0
+            for rep in range(3):
+                keep.append(torch.empty((case * 3 + rep + 1) * 1_000_003, dtype=torch.uint8, device=DEV))   # shift addresses
+                qxp, qwp = mixlib.PackP16x64(t(qx)), mixlib.PackP16x64(t(qw))
+                y = n(mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K, x_packed=True, w_packed=True))
+                assert np.array_equal(bits(y), bits(want16)), (names[cfg], M, N, K, rep)
+            if len(keep) > 24:
+                del keep[:12]
+    finally:
+        lib.mixq_gemm_set_config(-1)
