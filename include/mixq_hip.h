@@ -63,7 +63,8 @@ int mixq_device_info(char* buf_host, int cap);
 
 /* ---- (i) per-token absmax + quantise ------------------------------------------------------------------
  * Replaces mixlib.FindRowScale(x, x_scale, M, K, bit) -> q_x   (linear.py:190-193, :221).
- *   x        fp16 [M,K] row-major, ldx elements between rows (read only)
+ *   x        fp16 [M,K] row-major, ldx elements between rows (read only); values must be finite (the result for
+ *            inf / nan inputs is not specified - the reference does not define it either)
  *   x_scale  fp16 [M]   written in place (the reference passes its cache.x_scale[inputdim,1] buffer)
  *   q        bit=8: int8 [M,K];  bit=4: uint8 [M,K/2] nibble-packed.  K % 8 == 0 (bit 8) / K % 16 == 0 (bit 4).
  *   qfmt     MIXQ_FMT_PLAIN, or MIXQ_FMT_P16X64 to emit q directly in the tile-major layout (buffer of

@@ -782,3 +782,62 @@ def test_randomized_shapes_all_tilings_bit_exact():
                 del keep[:12]
     finally:
         lib.mixq_gemm_set_config(-1)
+
+
+def test_randomized_quantise_family_bit_exact():
+    """Random shapes, row strides, outlier sets (incl. device-side counts smaller than the capacity), both bit widths, plain
+    and packed outputs, extreme values (zero rows, fp16 max, denormals): fused extract + quantise, the fused RMSNorm form and
+    outlier detection against the oracle, bit for bit."""
+    rng = np.random.default_rng(77)
+    for case in range(30):
+        bit = int(rng.choice([8, 4]))
+        K = int(rng.integers(1, 48)) * 64 if rng.random() < 0.8 else int(rng.choice([8192, 11008, 16384, 28672]))
+        M = int(rng.choice([1, 3, 16, 17, 64, 130]))
+        ldx = K + int(rng.choice([0, 8, 64]))
+        ncap = int(rng.choice([0, 1, 7, 41, 128, 200])) if K >= 256 else int(rng.choice([0, 1, 5]))
+        ncap = min(ncap, K)
+        packed = bool(rng.random() < 0.5) and ((K if bit == 8 else K // 2) % 64 == 0)
+        x = rng.standard_normal((M, K)).astype(np.float16)
+        ind = rng.choice(K, ncap, replace=False).astype(np.int32)
+        x[:, ind] *= 20
+        if case % 5 == 0:
+            x[0] = 0                                            # all-zero row: scale 0, q 0
+        if case % 7 == 0:                                        # fp16 max and denormals (finite: inf/nan inputs are not defined)
+            free = np.setdiff1d(np.arange(K), ind)[:4]
+            x[M - 1, free] = np.array([65504, -65504, 6e-8, -6e-8], dtype=np.float16)[: free.size]
+        n_used = ncap if (ncap == 0 or rng.random() < 0.5) else int(rng.integers(0, ncap + 1))
+        buf = torch.zeros((M, ldx), dtype=torch.float16, device=DEV)
+        buf[:, :K] = t(x)
+        xv = buf[:, :K]
+        xs = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        n_dev = torch.tensor([n_used], dtype=torch.int32, device=DEV) if n_used != ncap else None
+        q, xo = mixlib.QuantFused(xv, t(ind) if ncap else None, xs, bit, 6.0, flag=flag, n_dev=n_dev, packed=packed)
+        xz = x.copy()
+        xo_ref = O.extract_outliers_zero(xz, ind[:n_used])
+        qo, so = O.find_row_scale(xz, bit)
+        KB = K if bit == 8 else K // 2
+        got_q = p16x64_unpack(n(q).reshape(-1).view(np.uint8), M, KB) if packed else n(q).view(np.uint8)
+        ctx = (case, M, K, bit, ncap, n_used, packed, ldx)
+        assert np.array_equal(got_q, qo.view(np.uint8)), ctx
+        assert np.array_equal(bits(n(xs)[:, 0]), bits(so)), ctx
+        assert np.array_equal(bits(n(xv)), bits(xz)), ctx
+        if n_used:
+            assert np.array_equal(bits(n(xo)[:, :n_used]), bits(xo_ref)), ctx
+        assert bool(flag.item()) == O.mispredicted(so, 6.0, bit), ctx
+        # detection on the (now zeroed) tensor and on the original
+        ibuf, cnt = mixlib.DetectOutlierCols(t(x), 6.0)
+        assert np.array_equal(n(ibuf)[: int(cnt.item())], O.find_outliers(x, 6.0)), ctx
+        # fused RMSNorm + quantise over the same input
+        if K <= 32768:
+            w = (rng.random(K) + 0.5).astype(np.float16)
+            out = torch.empty((M, K), dtype=torch.float16, device=DEV)
+            xs2 = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+            q2, xo2 = mixlib.RMSNormQuantFused(t(x), t(w), out, 1e-5, t(ind) if ncap else None, xs2, bit, packed=packed)
+            y_ref, xo_r, q_r, s_r = O.rmsnorm_quant(x, w, 1e-5, ind, bit)
+            got2 = p16x64_unpack(n(q2).reshape(-1).view(np.uint8), M, KB) if packed else n(q2).view(np.uint8)
+            assert np.array_equal(bits(n(out)), bits(y_ref)), ctx
+            assert np.array_equal(got2, q_r.view(np.uint8)), ctx
+            assert np.array_equal(bits(n(xs2)[:, 0]), bits(s_r)), ctx
+            if ncap:
+                assert np.array_equal(bits(n(xo2)), bits(xo_r)), ctx
