@@ -439,7 +439,7 @@ struct WoConfig {
     void (*k)(const WoArgs);
 };
 const WoConfig g_wo[] = {
-    {"w8a16_128x192_w2x2_s4_l4", 128, 192, 8, 4, gemm_w8a16_kernel<128, 192, 2, 2, 4, 4>},
+    {"w8a16_128x192_w2x2_s5_l4", 128, 192, 8, 5, gemm_w8a16_kernel<128, 192, 2, 2, 5, 4>},
     {"w8a16_128x128_w2x2_s4_l4", 128, 128, 8, 4, gemm_w8a16_kernel<128, 128, 2, 2, 4, 4>},
     {"w8a16_64x128_w2x2_s4_l4",  64, 128, 8, 4, gemm_w8a16_kernel<64, 128, 2, 2, 4, 4>},
     {"w8a16_128x192_abl2", 128, 192, 8, 4, gemm_w8a16_kernel<128, 192, 2, 2, 4, 4, 2>},     // tuning: no DMA
