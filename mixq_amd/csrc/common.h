@@ -31,10 +31,40 @@ __device__ __forceinline__ float h2f(uint16_t h) {
 __device__ __forceinline__ uint16_t f2h(float f) {   // round-to-nearest-even
     return __half_as_ushort(__float2half_rn(f));
 }
+// Maximum over the 64 lanes of a NON-NEGATIVE value, returned in every lane.  DPP moves inside the 16-lane rows (quad
+// swaps, half mirror, mirror: 4 VALU) and four v_readlane for the rows, instead of six ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {      // lanes without a source read 0: neutral for a max of values >= 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));          // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));          // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));         // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));         // row_mirror: every lane of a row now holds the row maximum
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// q = clamp(rint(x / s), +-QMAX) with the fp32 IEEE quotient rounded half-to-even (the convention of the oracle's
+// find_row_scale), WITHOUT a division per element.  x is an fp16 value, s an fp16 scale (both exact in fp32), rs = 1/s.
+// Why it is exact: where it matters |x/s| <= 128, and x/s = (a/b) 2^E with 11-bit a, b lies either exactly on a half-integer or at
+// least 1/(4b) > 6e-5 away from one, while t = x * rs is within 2e-5 of x/s - so rint(t) is the correctly rounded quotient
+// unless x/s is an exact tie; the tie is detected from the exact residual e = x - q0 s (|q0| s has <= 18 significant bits) and
+// resolved to even.  The same argument shows rint(RN(x/s)) == rint_half_even(x/s), i.e. this equals the division form bit
+// for bit.
+template <int BIT>
+__device__ __forceinline__ int quant_exact(float x, float s, float rs) {
+    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
+    float t = x * rs;
+    t = fminf(fmaxf(t, -2.f * QMAX), 2.f * QMAX);     // far-out values (denormal scales) clamp anyway; keeps q0 s exact
+    float q0 = rintf(t);
+    const float e = fmaf(-q0, s, x);
+    if (fabsf(e) * 2.f == s && (static_cast<int>(q0) & 1)) q0 += copysignf(1.f, e);
+    q0 = fminf(fmaxf(q0, -QMAX), QMAX);
+    return (s > 0.f) ? static_cast<int>(q0) : 0;
 }
 __device__ __forceinline__ int wave_id_uniform() {
     return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);

@@ -23,14 +23,6 @@ __device__ __forceinline__ size_t p16x64_offset(int row, int kb, int rows16) {
     return (static_cast<size_t>(kb >> 6) * (rows16 >> 4) + (row >> 4)) * 1024 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + (kb & 15);
 }
 
-template <int BIT>
-__device__ __forceinline__ int quant1(float x, float s) {
-    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
-    float q = (s > 0.f) ? rintf(__fdiv_rn(x, s)) : 0.f;
-    q = fminf(fmaxf(q, -QMAX), QMAX);
-    return static_cast<int>(q);
-}
-
 // y = fp16( fp32(fp32(x * inv) * w) ): every product is rounded to fp32 before the next step.  Written with the _rn
 // intrinsics and an opaque barrier so the compiler cannot fold the last multiply and the conversion into one
 // v_fma_mixlo_f16 (a single rounding of the exact product, which differs from the contract in ~1 of 30k elements).
@@ -146,6 +138,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
     const float s = h2f(sh);
+    const float rs = s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;
     if (tid == 0) {
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
@@ -159,8 +152,8 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
             int qv[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                qv[2 * e]     = quant1<BIT>(h2f(static_cast<uint16_t>(d[e] & 0xffffu)), s);
-                qv[2 * e + 1] = quant1<BIT>(h2f(static_cast<uint16_t>(d[e] >> 16)), s);
+                qv[2 * e]     = quant_exact<BIT>(h2f(static_cast<uint16_t>(d[e] & 0xffffu)), s, rs);
+                qv[2 * e + 1] = quant_exact<BIT>(h2f(static_cast<uint16_t>(d[e] >> 16)), s, rs);
             }
             if constexpr (BIT == 8) {
                 uint2 o;

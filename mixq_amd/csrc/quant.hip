@@ -22,27 +22,26 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
     return v;
 }
 
-// |x| of 8 packed halves with the outlier columns (bits of m8) forced to zero; returns the masked vector too.
-__device__ __forceinline__ float amax8_masked(uint4& v, uint32_t m8) {
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+// Running max of |x| as packed fp16 bit patterns (for finite halves |a| < |b| <=> (a & 0x7fff) < (b & 0x7fff) as unsigned):
+// 8 halves with the outlier columns (bits of m8) forced to zero cost one v_and + one v_pk_max_u16 per pair.  The masked
+// vector is written back for the quantise pass; amax_finish turns the accumulator into the float maximum.
+__device__ __forceinline__ uint32_t amax8_masked(uint4& v, uint32_t m8, uint32_t acc) {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    float a = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (m8 & (1u << (2 * i)))     w[i] &= 0xffff0000u;
-        if (m8 & (1u << (2 * i + 1))) w[i] &= 0x0000ffffu;
-        a = fmaxf(a, fabsf(h2f(static_cast<uint16_t>(w[i] & 0xffffu))));
-        a = fmaxf(a, fabsf(h2f(static_cast<uint16_t>(w[i] >> 16))));
+        if (m8) {                                              // rare: a chunk that holds outlier columns
+            if (m8 & (1u << (2 * i)))     w[i] &= 0xffff0000u;
+            if (m8 & (1u << (2 * i + 1))) w[i] &= 0x0000ffffu;
+        }
+        acc = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2_t, acc), __builtin_bit_cast(us2_t, w[i] & 0x7fff7fffu)));
     }
     v = make_uint4(w[0], w[1], w[2], w[3]);
-    return a;
+    return acc;
 }
-
-template <int BIT>
-__device__ __forceinline__ int quant1(float x, float s) {
-    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
-    float q = (s > 0.f) ? rintf(__fdiv_rn(x, s)) : 0.f;        // IEEE divide, round-half-even
-    q = fminf(fmaxf(q, -QMAX), QMAX);
-    return static_cast<int>(q);
+__device__ __forceinline__ float amax_finish(uint32_t acc) {
+    const uint32_t lo = acc & 0xffffu, hi = acc >> 16;
+    return h2f(static_cast<uint16_t>(lo > hi ? lo : hi));
 }
 
 // Byte address of byte `kb` of row `row` in the P16x64 tile-major layout (pack.hip): [KB/64][rows16/16] blocks of
@@ -54,13 +53,13 @@ __device__ __forceinline__ size_t p16x64_offset(int row, int kb, int rows16) {
 
 // q: plain -> row base pointer, packed -> matrix base pointer
 template <int BIT>
-__device__ __forceinline__ void quant_store8(const uint4& v, float s, void* q, int chunk, int row, int rows16) {
+__device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, void* q, int chunk, int row, int rows16) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     int qv[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        qv[2 * i]     = quant1<BIT>(h2f(static_cast<uint16_t>(w[i] & 0xffffu)), s);
-        qv[2 * i + 1] = quant1<BIT>(h2f(static_cast<uint16_t>(w[i] >> 16)), s);
+        qv[2 * i]     = quant_exact<BIT>(h2f(static_cast<uint16_t>(w[i] & 0xffffu)), s, rs);
+        qv[2 * i + 1] = quant_exact<BIT>(h2f(static_cast<uint16_t>(w[i] >> 16)), s, rs);
     }
     if constexpr (BIT == 8) {
         uint2 o;
@@ -136,27 +135,28 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
     if (x_out) for (int j = (have_out ? n : 0) + tid; j < ldo; j += QT) x_out[static_cast<size_t>(row) * ldo + j] = 0;
     if (have_out) __syncthreads();
 
-    float amax = 0.f;
+    uint32_t amax_acc = 0u;
     if constexpr (NCH > 0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * QT;
             if (c < nchunk) {
                 uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
-                amax = fmaxf(amax, amax8_masked(keep[i], m8));     // whatever the load saw in a zeroed column is masked
+                amax_acc = amax8_masked(keep[i], m8, amax_acc);    // whatever the load saw in a zeroed column is masked
             }
         }
     } else {
         for (int c = tid; c < nchunk; c += QT) {
             uint4 v = xv[c];
             uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
-            amax = fmaxf(amax, amax8_masked(v, m8));
+            amax_acc = amax8_masked(v, m8, amax_acc);
         }
     }
-    amax = block_max_256(amax, red);
+    const float amax = block_max_256(amax_finish(amax_acc), red);
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
     const float s = h2f(sh);
+    const float rs = s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;      // one division per row; quant_exact needs none per element
     if (tid == 0) {
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
@@ -166,14 +166,14 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * QT;
-            if (c < nchunk) quant_store8<BIT>(keep[i], s, qrow, c, row, rows16);
+            if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16);
         }
     } else {
         for (int c = tid; c < nchunk; c += QT) {
             uint4 v = xv[c];
             uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
-            (void)amax8_masked(v, m8);
-            quant_store8<BIT>(v, s, qrow, c, row, rows16);
+            (void)amax8_masked(v, m8, 0u);
+            quant_store8<BIT>(v, s, rs, qrow, c, row, rows16);
         }
     }
 }
