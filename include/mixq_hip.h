@@ -201,6 +201,10 @@ int mixq_gemm_set_config(int cfg);
  * done, 3 epilogue arithmetic done, 4 stores issued, 5 stores retired, 6/7 inside the epilogue; 8 + i = s_memtime
  * at the same points.  buf needs 128 bytes per workgroup (tools/trace_gemm.py). */
 int mixq_gemm_set_trace(unsigned long long* buf);
+/* Diagnostics: exhaustive self-test of the division-free quantiser used by the quantise kernels (q = rint(x / s) for all
+ * finite fp16 x and all finite fp16 s > 0, ~2e9 pairs, ~1 s): adds the number of disagreements with the IEEE-division form
+ * to *mismatches_dev (a zeroed device counter).  bit = 8 or 4. */
+int mixq_selftest_quant_exact(unsigned long long* mismatches_dev, int bit, mixq_stream_t stream);
 int mixq_gemm_num_configs(void);
 int mixq_gemm_config_name(int cfg, char* buf_host, int cap);
 /* The config the automatic choice picks for (M,N,K,bit). */

@@ -304,6 +304,33 @@ inline float fp16_round(float v) {                    // host: value of fp16(v) 
 
 }  // namespace
 
+// Self-test of quant_exact (common.h): every finite fp16 x against every finite fp16 scale s > 0, compared with the
+// division form rint(RN(x / s)) it replaces.  One workgroup per scale value; *mismatches receives the count.
+template <int BIT>
+__global__ __launch_bounds__(256) void selftest_quant_exact_kernel(unsigned long long* __restrict__ mismatches)
+{
+    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
+    const float s = h2f(static_cast<uint16_t>(blockIdx.x + 1));          // bits 0x0001 .. 0x7bff
+    const float rs = __fdiv_rn(1.0f, s);
+    unsigned long long bad = 0;
+    for (unsigned xb = threadIdx.x; xb < 65536u; xb += 256) {
+        if ((xb & 0x7c00u) == 0x7c00u) continue;                          // inf / nan
+        const float x = h2f(static_cast<uint16_t>(xb));
+        float q = rintf(__fdiv_rn(x, s));
+        q = fminf(fmaxf(q, -QMAX), QMAX);
+        bad += quant_exact<BIT>(x, s, rs) != static_cast<int>(q);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+extern "C" int mixq_selftest_quant_exact(unsigned long long* mismatches_dev, int bit, mixq_stream_t stream)
+{
+    if (!mismatches_dev || (bit != 8 && bit != 4)) return MIXQ_EINVAL;
+    if (bit == 8) hipLaunchKernelGGL(selftest_quant_exact_kernel<8>, dim3(0x7bff), dim3(256), 0, mixq_stream(stream), mismatches_dev);
+    else          hipLaunchKernelGGL(selftest_quant_exact_kernel<4>, dim3(0x7bff), dim3(256), 0, mixq_stream(stream), mismatches_dev);
+    return mixq_launch_status();
+}
+
 extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q, int M, int K, int ldx, int bit, int qfmt,
                                    mixq_stream_t stream)
 {

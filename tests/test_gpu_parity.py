@@ -841,3 +841,13 @@ def test_randomized_quantise_family_bit_exact():
             assert np.array_equal(bits(n(xs2)[:, 0]), bits(s_r)), ctx
             if ncap:
                 assert np.array_equal(bits(n(xo2)), bits(xo_r)), ctx
+
+
+@pytest.mark.parametrize("bit", [8, 4])
+def test_division_free_quantiser_is_exact_for_every_fp16_pair(bit):
+    """The quantise kernels compute q = rint(x / s) as x * (1/s) + a tie fix-up (common.h: quant_exact).  The library's
+    self-test compares it with the IEEE-division form for ALL finite fp16 x and all finite fp16 s > 0 (~2e9 pairs)."""
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    _capi.call("mixq_selftest_quant_exact", cnt.data_ptr(), bit, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 0
