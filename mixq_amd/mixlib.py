@@ -175,8 +175,6 @@ def PackP16x64(q):
     R, KB = q.shape
     out = torch.empty((packed_rows(R), KB), dtype=q.dtype, device=q.device)
     _capi.call("mixq_pack_p16x64", q.data_ptr(), out.data_ptr(), R, KB, _stream())
-    if not torch.cuda.is_current_stream_capturing():
-        _capi.ensure_workspace(q.device)       # packed operands enable the stream-K GEMM: give it its workspace once
     return out
 
 

@@ -65,6 +65,7 @@ def main():
     dev = "cuda"
     lib = _capi.load()
     print(_capi.device_info(), flush=True)
+    _capi.ensure_workspace(dev)            # the stream-K configs (opt-in) need their hand-off workspace
     names = _capi.gemm_config_names()
     cfgs = list(range(len(names))) if args.cfgs == "all" else [int(c) for c in args.cfgs.split(",")]
     results = []
