@@ -185,6 +185,8 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
     _dev_check(x, x_scale, ind)
     xp, ldx = _rows(x, "x")
     M, K = x.shape
+    if x_scale.numel() < M:
+        raise RuntimeError(f"QuantFused: x_scale holds {x_scale.numel()} rows, the batch has {M} (MixLibCache.inputdim too small)")
     n = 0 if ind is None else ind.numel()
     q = torch.empty((packed_rows(M) if packed else M, K if bit == 8 else K // 2),
                     dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
@@ -205,6 +207,8 @@ def FindRowScalePacked(x, x_scale, M, K, bit=8):
     """FindRowScale emitting the P16x64 layout."""
     _dev_check(x, x_scale)
     xp, ldx = _rows(x, "x")
+    if x_scale.numel() < M:
+        raise RuntimeError(f"FindRowScalePacked: x_scale holds {x_scale.numel()} rows, the batch has {M}")
     q = torch.empty((packed_rows(M), K if bit == 8 else K // 2), dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
     _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, FMT_P16X64, _stream())
     return q
@@ -245,6 +249,8 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
                 addend=None, out=None, x_packed=False, w_packed=False):
     """(iii)+(iv): int8/int4 MFMA GEMM + dequant + fp16 outlier correction + addend + act + bias -> fp16 [M,N]."""
     _dev_check(q_x, q_w, x_scale, scale_col)
+    if x_scale.numel() < M or scale_col.numel() < N:
+        raise RuntimeError("FusedLinear: x_scale / scale_col are shorter than M / N")
     y = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=q_x.device)
     if n_out and x_out is not None and w_out is not None:
         xop, ldxo = _rows(x_out, "x_out")
@@ -286,6 +292,8 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
     xp, ldx = _rows(x2, "x")
     op, ldo = _rows(o2, "out")
     M = x2.shape[0]
+    if x_scale.numel() < M:
+        raise RuntimeError(f"RMSNormQuantFused: x_scale holds {x_scale.numel()} rows, the batch has {M}")
     n = 0 if ind is None else ind.numel()
     q = torch.empty((packed_rows(M) if packed else M, K if bit == 8 else K // 2),
                     dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)

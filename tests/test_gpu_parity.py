@@ -851,3 +851,12 @@ def test_division_free_quantiser_is_exact_for_every_fp16_pair(bit):
     _capi.call("mixq_selftest_quant_exact", cnt.data_ptr(), bit, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert int(cnt.item()) == 0
+
+
+def test_batch_larger_than_the_cache_is_refused_not_overrun():
+    """The reference silently relies on M <= MixLibCache.inputdim; here it is an error, never a buffer overrun."""
+    lin = torch.nn.Linear(128, 64, bias=False).half()
+    cache = MixLibCache(16)
+    layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
+    with pytest.raises(RuntimeError, match="x_scale holds 16 rows"):
+        layer(torch.randn(32, 128, device=DEV).half(), None, True)
