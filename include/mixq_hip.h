@@ -40,6 +40,9 @@ extern "C" {
 
 #define MIXQ_ACT_NONE 0
 #define MIXQ_ACT_SILU 1      /* SiLU on (dequant + outlier + addend), bias added afterwards (linear.py:324-373) */
+#define MIXQ_ACT_SILU_MUL 2  /* SiLU on (dequant + outlier), then TIMES addend[m,n] (required), then bias: gate_proj's epilogue with
+                              * up_proj's output as the multiplier - the `gate_output *= up_output` pass of
+                              * modules/fused/mlp.py:61-63 folded into the GEMM */
 
 /* Quantised-operand storage formats.
  * MIXQ_FMT_PLAIN  : row-major [R, KB] bytes (KB = K for int8, K/2 for nibble-packed int4) - the reference's layout.

@@ -19,6 +19,7 @@ MIXQ_ESHAPE = -2
 MIXQ_ENODEV = -3
 ACT_NONE = 0
 ACT_SILU = 1
+ACT_SILU_MUL = 2
 FMT_PLAIN = 0
 FMT_P16X64 = 1
 X_PACKED = 1

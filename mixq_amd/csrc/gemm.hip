@@ -431,7 +431,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
             float sxv[MI];
 #pragma unroll
             for (int j = 0; j < MI; ++j) sxv[j] = h2f(sxh[j]) * PRE;
-            const bool has_add = ABL != 6 && a.addend != nullptr, has_bias = ABL != 6 && a.bias != nullptr, do_silu = ABL != 6 && a.act == MIXQ_ACT_SILU;
+            const bool has_add = ABL != 6 && a.addend != nullptr, has_bias = ABL != 6 && a.bias != nullptr, do_silu = ABL != 6 && a.act != MIXQ_ACT_NONE;
+            const bool mul_add = a.act == MIXQ_ACT_SILU_MUL;                   // addend multiplies after the SiLU instead of adding before it
             auto unpack4 = [](u32x2 v, float* o) {
                 o[0] = h2f(static_cast<uint16_t>(v.x & 0xffffu)); o[1] = h2f(static_cast<uint16_t>(v.x >> 16));
                 o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
@@ -529,20 +530,26 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                     for (int j = 0; j < MI; ++j) {
                         f32x16 f = fa[i][j];
                         const int m = m0 + xrow[j];
+                        float avv[16];
                         if (OPT && has_add) {
                             const uint16_t* ap = a.addend + static_cast<size_t>(m < a.M ? m : a.M - 1) * a.lda;
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 const int n = nb + 8 * g;
-                                float av[4];
-                                unpack4(*reinterpret_cast<const u32x2_u*>(ap + (n < a.N ? n : a.N - 4)), av);
+                                unpack4(*reinterpret_cast<const u32x2_u*>(ap + (n < a.N ? n : a.N - 4)), avv + 4 * g);
+                            }
+                            if (!mul_add) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) f[4 * g + e] += av[e];
+                                for (int r = 0; r < 16; ++r) f[r] += avv[r];
                             }
                         }
                         if (OPT && do_silu) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) f[r] = silu(f[r]);
+                            if (mul_add) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) f[r] *= avv[r];
+                            }
                         }
                         if (OPT && has_bias) {
 #pragma unroll
@@ -736,7 +743,8 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED)) return MIXQ_EINVAL;
     if (M < 0 || N < 0 || K <= 0 || n_out < 0) return MIXQ_EINVAL;
     if (M > 0 && N > 0 && (!q_x || !q_w || !x_scale || !scale_col || !y)) return MIXQ_EINVAL;
-    if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU) return MIXQ_EINVAL;
+    if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU && act != MIXQ_ACT_SILU_MUL) return MIXQ_EINVAL;
+    if (act == MIXQ_ACT_SILU_MUL && !addend) return MIXQ_EINVAL;            // the multiplier is mandatory
     const int KB = bit == 8 ? K : K / 2;
     if ((KB % 64) || (bit == 4 && (K & 1)) || (N & 3) || (ldy & 3) || ldy < N) return MIXQ_ESHAPE;
     if (addend && lda != 0 && lda < N) return MIXQ_EINVAL;
@@ -762,7 +770,7 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
         if (g_forced_cfg == skinny_id) return MIXQ_EINVAL;
     }
     // stream-K form (gemm_sk.hip): packed operands, workspace registered, chosen explicitly or by the shape rule
-    if (a.x_packed && a.w_packed) {
+    if (a.x_packed && a.w_packed && act != MIXQ_ACT_SILU_MUL) {       // (the stream-K epilogue has no multiplier form)
         int sk = -1;
         if (g_forced_cfg >= NUM_CFGS) sk = g_forced_cfg - NUM_CFGS;
         else if (g_forced_cfg < 0) sk = pick_stream_k(M, N, KB);

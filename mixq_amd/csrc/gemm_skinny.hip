@@ -182,15 +182,21 @@ __global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_kernel(const Skinn
         const int n = n0 + nloc + 8 * g;
         const int nc = n < a.N ? n : a.N - 4;                          // N % 4 == 0: groups are all in or all out
         float v[4] = {f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]};
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.addend) {
-            float av[4];
             unpack4(*reinterpret_cast<const u32x2_u*>(a.addend + static_cast<size_t>(mc) * a.lda + nc), av);
+            if (a.act != MIXQ_ACT_SILU_MUL) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += av[e];
+                for (int e = 0; e < 4; ++e) v[e] += av[e];
+            }
         }
-        if (a.act == MIXQ_ACT_SILU) {
+        if (a.act != MIXQ_ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = sk_silu(v[e]);
+            if (a.act == MIXQ_ACT_SILU_MUL) {                      // addend is the multiplier
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= av[e];
+            }
         }
         if (a.bias) {
             float bv[4];

@@ -61,6 +61,6 @@ class MixLlamaMLP(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         up_output = self.up_proj_(x, self.MLPCache)
-        gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache)
-        gate_output *= up_output
+        # silu(gate(x)) * up(x) in gate_proj's epilogue (the reference multiplies in a separate pass, mlp.py:61-63)
+        gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache, mul=up_output)
         return self.down_proj_(gate_output, None, True)

@@ -22,7 +22,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import mixlib as _hip_mixlib
-from ._capi import ACT_NONE, ACT_SILU
+from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL
 
 # The kernel backend.  Always the HIP module in the product; tests that exercise the host-side state machine on a
 # machine without a GPU swap in an oracle-backed stand-in (tests/backend_oracle.py) via `set_backend`.
@@ -233,7 +233,7 @@ class MixLinear_GEMM(nn.Module):
             self._wpk_key = key
         return self._wpk
 
-    def _gemm(self, cache, M, act):
+    def _gemm(self, cache, M, act, addend=None):
         n = int(self.ind.shape[0])
         xo = _gemm_ready(cache.activation_outliers) if n else None
         wo = None
@@ -249,7 +249,7 @@ class MixLinear_GEMM(nn.Module):
             raise RuntimeError("MixLinear_GEMM: outlier operands do not match `ind`")
         wpk = self._packed_weight()
         return _backend.FusedLinear(cache.q_xcache, wpk if wpk is not None else self.q_weight, cache.x_scale, self.scale_col,
-                                    xo, wo, n, self.bias, M, self.out_features, self.in_features, bit=self.bit, act=act,
+                                    xo, wo, n, self.bias, M, self.out_features, self.in_features, bit=self.bit, act=act, addend=addend,
                                     x_packed=bool(getattr(cache, "q_xcache_packed", False)), w_packed=wpk is not None)
 
     # ------------------------------------------------------------------------------------------------------
@@ -307,8 +307,10 @@ class MixLinear_GEMM(nn.Module):
         return y1.reshape(cache.shape)
 
     @torch.no_grad()
-    def forward_without_preconditionFusedSilu(self, x, cache):
-        """gate_proj path (linear.py:292-376): reuse the activation quantised for up_proj, SiLU in the epilogue."""
+    def forward_without_preconditionFusedSilu(self, x, cache, mul=None):
+        """gate_proj path (linear.py:292-376): reuse the activation quantised for up_proj, SiLU in the epilogue.
+        `mul` (an extension): an fp16 [..., N] tensor multiplied in after the SiLU, i.e. silu(gate(x)) * up(x) leaves the GEMM
+        directly and the `gate_output *= up_output` pass of modules/fused/mlp.py:61-63 disappears."""
         inputs = x.reshape(-1, x.shape[-1])
         M = inputs.shape[0]
         if not self.forward_without_precondition_len == cache.ind.shape[0]:
@@ -324,7 +326,10 @@ class MixLinear_GEMM(nn.Module):
                 self.forward_without_precondition_len = self.ind.shape[0]
         if self.bit == 4 and not self.ind.shape[0]:
             raise RuntimeError("int4 mod should have outliers !")
-        y1 = self._gemm(cache, M, ACT_SILU)
+        if mul is not None:
+            y1 = self._gemm(cache, M, ACT_SILU_MUL, addend=mul.reshape(-1, self.out_features))
+        else:
+            y1 = self._gemm(cache, M, ACT_SILU)
         return y1.reshape(cache.shape)
 
 

@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import _capi
-from ._capi import ACT_NONE, ACT_SILU, FMT_PLAIN, FMT_P16X64, X_PACKED, W_PACKED
+from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, X_PACKED, W_PACKED
 
 
 def _dev_check(*ts):
@@ -259,7 +259,12 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
         xop = wop = None
         ldxo = ldwo = 0
         n_out = 0
-    if _is_zero_addend(addend):
+    if act == ACT_SILU_MUL:                  # the addend slot carries the multiplier (silu(gate) * up): never dropped
+        if addend is None:
+            raise RuntimeError("FusedLinear: ACT_SILU_MUL needs the multiplier in `addend`")
+        _dev_check(addend)
+        ap, lda = _rows(addend, "addend")
+    elif _is_zero_addend(addend):
         ap, lda = None, 0
     else:
         ap, lda = _rows(addend, "addend")

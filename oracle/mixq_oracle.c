@@ -257,8 +257,11 @@ void orc_linear_fused(const void* qx, const void* qw, const uint16_t* sx, const 
             float o = 0.f;
             for (int j = 0; j < n_out; ++j) o += h2f(xo[(size_t)m * ldxo + j]) * h2f(wo[(size_t)n * ldwo + j]);
             v += o;
-            if (addend) v += h2f(addend[(size_t)m * lda + n]);
-            if (act == 1) v = silu_f(v);
+            if (act == 2) v = silu_f(v) * h2f(addend[(size_t)m * lda + n]);   /* MIXQ_ACT_SILU_MUL: addend is the multiplier */
+            else {
+                if (addend) v += h2f(addend[(size_t)m * lda + n]);
+                if (act == 1) v = silu_f(v);
+            }
             if (bias) v += h2f(bias[n]);
             y[(size_t)m * ldy + n] = f2h(v);
         }

@@ -6,7 +6,7 @@ import torch
 
 from oracle import oracle as O
 
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_SILU_MUL = 0, 1, 2
 calls = []
 
 

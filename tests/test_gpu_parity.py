@@ -860,3 +860,33 @@ def test_batch_larger_than_the_cache_is_refused_not_overrun():
     layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
     with pytest.raises(RuntimeError, match="x_scale holds 16 rows"):
         layer(torch.randn(32, 128, device=DEV).half(), None, True)
+
+
+@pytest.mark.parametrize("M,N,K,bit,n_out,bias", [(96, 320, 1024, 8, 17, True), (16, 256, 512, 8, 5, False), (40, 64, 1024, 4, 16, False),
+                                                 (512, 1536, 4096, 8, 41, False)])
+@pytest.mark.parametrize("packed", [False, True])
+def test_silu_times_multiplier_epilogue(M, N, K, bit, n_out, bias, packed):
+    """MIXQ_ACT_SILU_MUL: y = silu(dequant + outliers) * mul + bias in the GEMM epilogue (gate_proj with up_proj's output as
+    the multiplier), tiled and decode kernels, against the oracle."""
+    c = _fused_case(M, N, K, bit, seed=M + N + K + 5, n_out=n_out, bias=bias, addend=True, act=2)
+    y = n(_run_fused(c, packed)).astype(np.float32)
+    ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], addend=c["addend"], bias=c["bias"], act=2,
+                         bit=bit).astype(np.float32)
+    assert np.isfinite(y).all()
+    assert (np.abs(y - ref) <= ulp_tol(ref)).all(), float(np.abs(y - ref).max())
+    # and it is what the two-step form computes, up to the extra rounding of the intermediate
+    c1 = dict(c); c1["act"] = 1; c1["addend"] = None; c1["bias"] = None
+    two_step = n(_run_fused(c1, packed)).astype(np.float32) * c["addend"].astype(np.float32)
+    if c["bias"] is not None:
+        two_step = two_step + c["bias"].astype(np.float32)
+    assert (np.abs(y - two_step) <= 2 * ulp_tol(ref) + 2e-3 * np.abs(ref)).all()
+
+
+def test_silu_mul_needs_its_multiplier():
+    c = _fused_case(8, 64, 128, 8, seed=1, n_out=0, bias=False, addend=False, act=2)
+    with pytest.raises(RuntimeError):
+        _run_fused(c, True)
+    lib = _capi.load()
+    one = torch.zeros(64, dtype=torch.int8, device=DEV)
+    assert lib.mixq_gemm_i8_fused(one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr(), None, 0, None, 0, 0, None, None, 0,
+                                  None, one.data_ptr(), 64, 4, 64, 128, 2, 0, None) == _capi.MIXQ_EINVAL
