@@ -514,6 +514,18 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
             // addresses and are dropped at the store.
             auto finish_tile = [&](auto staged_c, auto opt_c) {
                 constexpr bool ST = decltype(staged_c)::value, OPT = decltype(opt_c)::value;
+                // the addend / multiplier of block (i, j+1) is requested while block (i, j) is computed: one exposed round trip
+                u32x2 aq[4];
+                auto add_load = [&](int i, int j) {
+                    const int m = m0 + xrow[j];
+                    const uint16_t* ap = a.addend + static_cast<size_t>(m < a.M ? m : a.M - 1) * a.lda;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + wn * WN + i * 32 + 4 * lh + 8 * g;
+                        aq[g] = *reinterpret_cast<const u32x2_u*>(ap + (n < a.N ? n : a.N - 4));
+                    }
+                };
+                if (OPT && has_add) add_load(0, 0);
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int nloc = wn * WN + i * 32 + 4 * lh;
@@ -532,12 +544,10 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                         const int m = m0 + xrow[j];
                         float avv[16];
                         if (OPT && has_add) {
-                            const uint16_t* ap = a.addend + static_cast<size_t>(m < a.M ? m : a.M - 1) * a.lda;
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const int n = nb + 8 * g;
-                                unpack4(*reinterpret_cast<const u32x2_u*>(ap + (n < a.N ? n : a.N - 4)), avv + 4 * g);
-                            }
+                            for (int g = 0; g < 4; ++g) unpack4(aq[g], avv + 4 * g);
+                            if (j + 1 < MI) add_load(i, j + 1);
+                            else if (i + 1 < NI) add_load(i + 1, 0);
                             if (!mul_add) {
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) f[r] += avv[r];
