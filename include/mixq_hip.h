@@ -40,9 +40,10 @@ extern "C" {
 
 #define MIXQ_ACT_NONE 0
 #define MIXQ_ACT_SILU 1      /* SiLU on (dequant + outlier + addend), bias added afterwards (linear.py:324-373) */
-#define MIXQ_ACT_SILU_MUL 2  /* SiLU on (dequant + outlier), then TIMES addend[m,n] (required), then bias: gate_proj's epilogue with
-                              * up_proj's output as the multiplier - the `gate_output *= up_output` pass of
-                              * modules/fused/mlp.py:61-63 folded into the GEMM */
+#define MIXQ_ACT_SILU_MUL 2  /* (SiLU(dequant + outlier) + bias) TIMES addend[m,n] (required): gate_proj's epilogue with up_proj's
+                              * output as the multiplier - linear.py:372-373 (`y1 += self.bias`) followed by the
+                              * `gate_output *= up_output` pass of modules/fused/mlp.py:61-63, folded into the GEMM
+                              *  */
 
 /* Quantised-operand storage formats.
  * MIXQ_FMT_PLAIN  : row-major [R, KB] bytes (KB = K for int8, K/2 for nibble-packed int4) - the reference's layout.
@@ -53,9 +54,17 @@ extern "C" {
  *                   (1.7x the operand-feed rate of 64-byte row segments on MI355X).  KB % 64 == 0. */
 #define MIXQ_FMT_PLAIN  0
 #define MIXQ_FMT_P16X64 1
+/* MIXQ_FMT_F16X64 : "fragment order": the same [KB/64][rows16/16] grid of 1 KiB blocks, but inside a block the four
+ *                   16-byte k-chunks c are the slow index: byte c*256 + r*16 + b.  Lane l of a wave that loads 16 bytes at
+ *                   block + 16 l holds row l & 15, k-chunk l >> 4 - one v_mfma_i32_16x16x64_i8 operand - so a weight
+ *                   fragment is ONE fully coalesced global_load_dwordx4 with no LDS round trip, and an activation block
+ *                   DMA-ed to LDS is read back by ds_read_b128 at lane * 16 without bank conflicts (gemm_wreg.hip). */
+#define MIXQ_FMT_F16X64 2
 /* `layout` bits of the GEMM entry points */
 #define MIXQ_X_PACKED 1      /* q_x is MIXQ_FMT_P16X64 */
 #define MIXQ_W_PACKED 2      /* q_w is MIXQ_FMT_P16X64 */
+#define MIXQ_X_F16X64 4      /* q_x is MIXQ_FMT_F16X64 */
+#define MIXQ_W_F16X64 8      /* q_w is MIXQ_FMT_F16X64 */
 
 typedef void* mixq_stream_t; /* hipStream_t */
 
@@ -70,7 +79,7 @@ int mixq_device_info(char* buf_host, int cap);
  *            inf / nan inputs is not specified - the reference does not define it either)
  *   x_scale  fp16 [M]   written in place (the reference passes its cache.x_scale[inputdim,1] buffer)
  *   q        bit=8: int8 [M,K];  bit=4: uint8 [M,K/2] nibble-packed.  K % 8 == 0 (bit 8) / K % 16 == 0 (bit 4).
- *   qfmt     MIXQ_FMT_PLAIN, or MIXQ_FMT_P16X64 to emit q directly in the tile-major layout (buffer of
+ *   qfmt     MIXQ_FMT_PLAIN, or MIXQ_FMT_P16X64 / MIXQ_FMT_F16X64 to emit q directly in a tile-major layout (buffer of
  *            roundup(M,16) * KB bytes; rows >= M are left untouched).
  */
 int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q,
@@ -124,7 +133,8 @@ int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col, const int
  *   x_out fp16 [M,ldxo], w_out fp16 [N,ldwo]: outlier operands (NULL / n_out = 0 for none);
  *         n_out_dev: optional device int32 overriding n_out (<= n_out); ldxo, ldwo >= roundup(n_out,16), % 8 == 0
  *   addend fp16 [M,lda] or NULL;  bias fp16 [N] or NULL;  y fp16 [M,ldy]
- *   layout  MIXQ_X_PACKED | MIXQ_W_PACKED bits (0 = both operands plain row-major as in the reference)
+ *   layout  MIXQ_X_PACKED | MIXQ_W_PACKED bits (0 = both operands plain row-major as in the reference), or
+ *           MIXQ_X_F16X64 | MIXQ_W_F16X64 (both together: the weights-in-registers kernels take both operands that way)
  *   K % 64 == 0, N % 4 == 0, ldy % 4 == 0.
  */
 int mixq_gemm_i8_fused(const int8_t* q_x, const int8_t* q_w, const uint16_t* x_scale,
@@ -146,6 +156,11 @@ int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x
  * Copy a plain [R,KB] byte matrix (int8 weights, or nibble-packed int4) into MIXQ_FMT_P16X64.
  * dst holds roundup(R,16) * KB bytes; rows >= R are zero-filled.  KB % 64 == 0.  Done once per weight at load. */
 int mixq_pack_p16x64(const void* src, void* dst, int R, int KB, mixq_stream_t stream);
+/* The same for either packed format (fmt = MIXQ_FMT_P16X64 or MIXQ_FMT_F16X64), and the inverse: mixq_unpack_operand
+ * writes the plain [R,KB] matrix back from a packed image (rows >= R of the image are ignored) - what lets an operator keep
+ * ONLY the packed weights in HBM and still serve `q_weight` / state_dict in the reference's layout. */
+int mixq_pack_operand(const void* src, void* dst, int R, int KB, int fmt, mixq_stream_t stream);
+int mixq_unpack_operand(const void* src, void* dst, int R, int KB, int fmt, mixq_stream_t stream);
 
 /* ---- unfused debug pair ---------------------------------------------------------------------------------
  * mixq_gemm_i8 replaces mixlib.gemm(q_x, q_w, M, N, K) -> int32 [M,N]        (linear.py:235,321)
@@ -199,6 +214,10 @@ int mixq_gemm_set_workspace(void* ws, long long bytes);
  * Force a GEMM tile configuration id (>= 0) for subsequent mixq_gemm_* calls, -1 = automatic shape-aware
  * choice.  Returns MIXQ_EINVAL for an unknown id.  mixq_gemm_config_name writes the config's description. */
 int mixq_gemm_set_config(int cfg);
+/* Launch geometry of the extract + scale + quantise pass (mixq_quant_fused / mixq_find_row_scale): -1 automatic, 0 the
+ * one-row-per-256-thread-workgroup kernel, 1..7 (threads per row, rows per workgroup) = (64,1) (64,2) (64,4) (128,1)
+ * (128,2) (256,1) (256,2).  Every geometry produces identical bytes. */
+int mixq_quant_set_config(int cfg);
 /* Diagnostics: when buf is non-null every workgroup of the data-parallel fused GEMM writes 16 x u64 to
  * buf[16 * workgroup + i]: i in 0..7 = the 100 MHz device wall clock at 0 entry, 1 first stage landed, 2 k loop
  * done, 3 epilogue arithmetic done, 4 stores issued, 5 stores retired, 6/7 inside the epilogue; 8 + i = s_memtime
@@ -210,8 +229,9 @@ int mixq_gemm_set_trace(unsigned long long* buf);
 int mixq_selftest_quant_exact(unsigned long long* mismatches_dev, int bit, mixq_stream_t stream);
 int mixq_gemm_num_configs(void);
 int mixq_gemm_config_name(int cfg, char* buf_host, int cap);
-/* The config the automatic choice picks for (M,N,K,bit). */
+/* The config the automatic choice picks for (M,N,K,bit) with MIXQ_FMT_P16X64 operands / with operands in `fmt`. */
 int mixq_gemm_pick_config(int M, int N, int K, int bit);
+int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt);
 
 #ifdef __cplusplus
 }

@@ -22,8 +22,11 @@ ACT_SILU = 1
 ACT_SILU_MUL = 2
 FMT_PLAIN = 0
 FMT_P16X64 = 1
+FMT_F16X64 = 2
 X_PACKED = 1
 W_PACKED = 2
+X_F16X64 = 4
+W_F16X64 = 8
 
 
 class MixqBuildError(RuntimeError):
@@ -60,8 +63,12 @@ SIGNATURES = {
     "mixq_selftest_quant_exact": [_P, _I, _P],
     "mixq_gemm_num_configs": [],
     "mixq_pack_p16x64": [_P, _P, _I, _I, _P],
+    "mixq_pack_operand": [_P, _P, _I, _I, _I, _P],
+    "mixq_unpack_operand": [_P, _P, _I, _I, _I, _P],
+    "mixq_quant_set_config": [_I],
     "mixq_gemm_config_name": [_I, C.c_char_p, _I],
     "mixq_gemm_pick_config": [_I, _I, _I, _I],
+    "mixq_gemm_pick_config_fmt": [_I, _I, _I, _I, _I],
     "mixq_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "mixq_rmsnorm_quant_fused": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
     "mixq_pack_w8a16": [_P, _P, _I, _I, _P],

@@ -8,6 +8,10 @@ MI355X differences, all behind the same names:
     zeros per GEMM as the "addend" when a layer has no outliers; here the GEMM gets a NULL addend instead).
   * `flag` / `scratch(K)`: device words for the misprediction flag and the outlier-column detection, so the check
     `x_scale.max() > sigma/qmax` (linear.py:201) is evaluated on device inside the quantise kernel.
+  * `n_dev`: the device-resident outlier count of the layer that filled the cache (kernel.py:108-111 reads its K the same
+    way): the quantise kernel and the GEMM tail take the count from there, `ind` / `activation_outliers` are capacities.
+  * the storage format of `q_xcache` (plain / P16x64 / F16x64) is a tag on the tensor itself (mixlib.fmt_of), not a flag
+    here: a flag on this shared object would describe whichever layer wrote last.
 """
 from __future__ import annotations
 
@@ -24,12 +28,13 @@ class MixLibCache:
         self.sigma_value = float(self.sigma.float().cpu().item())       # fp16-rounded threshold as a host float
         self._zero = torch.zeros((1, 1), dtype=torch.float16, device=device)
         self.zeros = self._zero.expand(inputdim, 12288 * 3)              # same shape as Cache.py:11, no storage
+        self.zeros._mixq_all_zero = True                                 # recognised by identity: the GEMM gets a NULL addend
         self.ind = None
         self.new_ind = None
         self.shape = None
         self.activation_outliers = None
         self.q_xcache = None
-        self.q_xcache_packed = False         # q_xcache is in the P16x64 layout (set by whoever fills it)
+        self.n_dev = None                    # int32[1] device count that goes with `ind` / `activation_outliers`
         self.is_prefill = False
         self.bit = bit
         self.max_outliers = 256
@@ -49,18 +54,11 @@ class MixLibCache:
             self._scratch[K] = s
         return s
 
-    def do_bench_cudagraph(self, fn):
-        """Capture `fn` into a hipGraph after 10 warm-up calls (Cache.py:26-38); must run on a side stream."""
-        if torch.cuda.current_stream() == torch.cuda.default_stream():
-            raise RuntimeError("Cannot capture graph in default stream. Please use side stream in benchmark code.")
-        for _ in range(10):
-            fn()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
-            fn()
-        torch.cuda.synchronize()
-        return g
+    @property
+    def q_xcache_packed(self):
+        """True when q_xcache is in a packed (tile-major) layout; derived from the tensor's own tag."""
+        from .mixlib import fmt_of
+        return self.q_xcache is not None and fmt_of(self.q_xcache) != 0
 
 
 class MLPCache:

@@ -66,6 +66,15 @@ __device__ __forceinline__ int quant_exact(float x, float s, float rs) {
     q0 = fminf(fmaxf(q0, -QMAX), QMAX);
     return (s > 0.f) ? static_cast<int>(q0) : 0;
 }
+// Byte address of byte `kb` of row `row` in a packed operand ([KB/64][rows16/16] blocks of 16 rows x 64 bytes = 1 KiB):
+//   MIXQ_FMT_P16X64: row r of a block stores its four 16-byte chunks c at r*64 + (c ^ ((r>>2)&3))*16 (the LDS image of gemm.hip)
+//   MIXQ_FMT_F16X64: chunk-major "fragment order" c*256 + r*16 - lane l of a wave owns bytes [16 l, 16 l + 16) of a block,
+//                    which is row l&15, k-chunk l>>4: exactly one v_mfma_i32_16x16x64_i8 operand (gemm_wreg.hip)
+__device__ __forceinline__ size_t packed_offset(int fmt, int row, int kb, int rows16) {
+    const int r = row & 15, c = (kb & 63) >> 4;
+    const size_t blk = (static_cast<size_t>(kb >> 6) * (rows16 >> 4) + (row >> 4)) * 1024;
+    return blk + (fmt == MIXQ_FMT_F16X64 ? c * 256 + r * 16 : r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) + (kb & 15);
+}
 __device__ __forceinline__ int wave_id_uniform() {
     return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
 }

@@ -32,6 +32,7 @@
 #include "common.h"
 #include "gemm_sk.h"
 #include "gemm_skinny.h"
+#include "gemm_wreg.h"
 #include <stdio.h>
 #include <string.h>
 #include <type_traits>
@@ -556,14 +557,14 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                         if (OPT && do_silu) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) f[r] = silu(f[r]);
-                            if (mul_add) {
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) f[r] *= avv[r];
-                            }
                         }
                         if (OPT && has_bias) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) f[r] += bv[r];
+                        }
+                        if (OPT && mul_add) {                  // (silu(z) + bias) * up: linear.py:372-373, then mlp.py:61
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) f[r] *= avv[r];
                         }
                         if (ABL != 5 || a.act == 77) {
 #pragma unroll
@@ -614,20 +615,56 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
     }
 }
 
-// Standalone epilogue for the unfused debug pair (mixlib.dequantizeInt8).
+// Standalone epilogue of the unfused pair (mixlib.gemm + mixlib.dequantizeInt8[Silu]) - the route the UNCHANGED reference takes
+// on gfx950, where torch reports capability major 9 (linear.py:86,234-241).  HBM-bound: 8 outputs per thread, 2 x 16-byte
+// int32 loads, one 16-byte fp16 store (VEC), or one element per thread for shapes that do not allow it.
+template <bool VEC>
 __global__ __launch_bounds__(256) void dequant_kernel(const int32_t* __restrict__ y32, int ldy32, const uint16_t* __restrict__ sx,
                                                       const uint16_t* __restrict__ sw, const uint16_t* __restrict__ addend, int lda,
                                                       const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int ldy,
                                                       int M, int N, int act)
 {
+    constexpr int E = VEC ? 8 : 1;
+    const int per_row = N / E;
     const long long t = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-    if (t >= static_cast<long long>(M) * N) return;
-    const int m = static_cast<int>(t / N), n = static_cast<int>(t % N);
-    float v = static_cast<float>(y32[static_cast<size_t>(m) * ldy32 + n]) * h2f(sx[m]) * h2f(sw[n]);
-    if (addend) v += h2f(addend[static_cast<size_t>(m) * lda + n]);
-    if (act == MIXQ_ACT_SILU) v = silu(v);
-    if (bias) v += h2f(bias[n]);
-    y[static_cast<size_t>(m) * ldy + n] = f2h(v);
+    if (t >= static_cast<long long>(M) * per_row) return;
+    const int m = static_cast<int>(t / per_row), n = static_cast<int>(t % per_row) * E;
+    const float sxv = h2f(sx[m]);
+    float v[E];
+    if constexpr (VEC) {
+        const i32x4 a0 = *reinterpret_cast<const i32x4*>(y32 + static_cast<size_t>(m) * ldy32 + n);
+        const i32x4 a1 = *reinterpret_cast<const i32x4*>(y32 + static_cast<size_t>(m) * ldy32 + n + 4);
+        const u32x4 s = *reinterpret_cast<const u32x4*>(sw + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e]     = static_cast<float>(a0[e]) * sxv * h2f(static_cast<uint16_t>(e & 1 ? s[e >> 1] >> 16 : s[e >> 1] & 0xffffu));
+            v[4 + e] = static_cast<float>(a1[e]) * sxv * h2f(static_cast<uint16_t>(e & 1 ? s[2 + (e >> 1)] >> 16 : s[2 + (e >> 1)] & 0xffffu));
+        }
+        if (addend) {
+            const u32x4 ad = *reinterpret_cast<const u32x4*>(addend + static_cast<size_t>(m) * lda + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += h2f(static_cast<uint16_t>(e & 1 ? ad[e >> 1] >> 16 : ad[e >> 1] & 0xffffu));
+        }
+    } else {
+        v[0] = static_cast<float>(y32[static_cast<size_t>(m) * ldy32 + n]) * sxv * h2f(sw[n]);
+        if (addend) v[0] += h2f(addend[static_cast<size_t>(m) * lda + n]);
+    }
+    if (act == MIXQ_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = silu(v[e]);
+    }
+    if (bias) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] += h2f(bias[n + e]);
+    }
+    if constexpr (VEC) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = static_cast<uint32_t>(f2h(v[2 * e])) | (static_cast<uint32_t>(f2h(v[2 * e + 1])) << 16);
+        *reinterpret_cast<u32x4*>(y + static_cast<size_t>(m) * ldy + n) = o;
+    } else {
+        y[static_cast<size_t>(m) * ldy + n] = f2h(v[0]);
+    }
 }
 
 // ---- configuration table ---------------------------------------------------------------------------------------
@@ -750,7 +787,11 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
                       const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int K,
                       int act, int layout, int bit, mixq_stream_t stream)
 {
-    if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED)) return MIXQ_EINVAL;
+    if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED | MIXQ_X_F16X64 | MIXQ_W_F16X64)) return MIXQ_EINVAL;
+    if ((layout & MIXQ_X_PACKED) && (layout & MIXQ_X_F16X64)) return MIXQ_EINVAL;
+    if ((layout & MIXQ_W_PACKED) && (layout & MIXQ_W_F16X64)) return MIXQ_EINVAL;
+    const bool xf16 = layout & MIXQ_X_F16X64, wf16 = layout & MIXQ_W_F16X64;
+    if (xf16 != wf16) return MIXQ_EINVAL;                 // the fragment-order kernels take both operands in that layout
     if (M < 0 || N < 0 || K <= 0 || n_out < 0) return MIXQ_EINVAL;
     if (M > 0 && N > 0 && (!q_x || !q_w || !x_scale || !scale_col || !y)) return MIXQ_EINVAL;
     if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU && act != MIXQ_ACT_SILU_MUL) return MIXQ_EINVAL;
@@ -771,14 +812,26 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
     a.x_packed = (layout & MIXQ_X_PACKED) ? 1 : 0; a.w_packed = (layout & MIXQ_W_PACKED) ? 1 : 0;
     a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
-    // small-batch form (gemm_skinny.hip): M <= 32, int8, packed operands: a weight stream, no LDS staging
+    const int sk_num = mixq_sk_num_configs();
+    const int skinny_id = NUM_CFGS + sk_num, wr0 = skinny_id + 1;
+    // small-batch form (gemm_skinny.hip): M <= 32, packed operands (either packed layout): a weight stream, no LDS staging
     {
-        const int skinny_id = NUM_CFGS + mixq_sk_num_configs();
-        if ((g_forced_cfg < 0 || g_forced_cfg == skinny_id) && mixq_skinny_applies(bit, M, N, KB, a.x_packed, a.w_packed))
+        const bool both_packed = (a.x_packed && a.w_packed) || xf16;
+        if ((g_forced_cfg < 0 || g_forced_cfg == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed))
             return mixq_skinny_launch(bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
-                                      ldy, M, N, KB, act, mixq_stream(stream));
+                                      ldy, M, N, KB, act, xf16 ? 1 : 0, mixq_stream(stream));
         if (g_forced_cfg == skinny_id) return MIXQ_EINVAL;
     }
+    // fragment-order operands: the weights-in-registers kernels (gemm_wreg.hip)
+    if (xf16) {
+        int c;
+        if (g_forced_cfg >= wr0) c = g_forced_cfg - wr0;
+        else if (g_forced_cfg >= 0) return MIXQ_EINVAL;  // a P16X64 / plain tiling was forced: wrong operand layout
+        else c = mixq_wr_pick(bit, M, N, KB);
+        return mixq_wr_launch(c, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+                              ldy, M, N, KB, act, g_trace, mixq_stream(stream));
+    }
+    if (g_forced_cfg >= wr0) return MIXQ_EINVAL;
     // stream-K form (gemm_sk.hip): packed operands, workspace registered, chosen explicitly or by the shape rule
     if (a.x_packed && a.w_packed && act != MIXQ_ACT_SILU_MUL) {       // (the stream-K epilogue has no multiplier form)
         int sk = -1;
@@ -832,24 +885,33 @@ extern "C" int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_sca
     if (!y32 || !x_scale || !scale_col || !y || M < 0 || N < 0 || ldy32 < N || ldy < N) return MIXQ_EINVAL;
     if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU) return MIXQ_EINVAL;
     if (M == 0 || N == 0) return MIXQ_OK;
-    const long long total = static_cast<long long>(M) * N;
-    hipLaunchKernelGGL(dequant_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, mixq_stream(stream), y32,
-                       ldy32, x_scale, scale_col, addend, lda, bias, y, ldy, M, N, act);
+    const bool vec = (N % 8 == 0) && (ldy32 % 4 == 0) && (ldy % 8 == 0) && (!addend || lda % 8 == 0 || lda == 0) &&
+                     ((reinterpret_cast<uintptr_t>(y32) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scale_col) |
+                       reinterpret_cast<uintptr_t>(addend)) & 15) == 0;
+    const long long total = static_cast<long long>(M) * (vec ? N / 8 : N);
+    const dim3 g(static_cast<unsigned>((total + 255) / 256));
+    if (vec) hipLaunchKernelGGL(dequant_kernel<true>, g, dim3(256), 0, mixq_stream(stream), y32, ldy32, x_scale, scale_col, addend, lda,
+                                bias, y, ldy, M, N, act);
+    else     hipLaunchKernelGGL(dequant_kernel<false>, g, dim3(256), 0, mixq_stream(stream), y32, ldy32, x_scale, scale_col, addend,
+                                lda, bias, y, ldy, M, N, act);
     return mixq_launch_status();
 }
 
-// Config ids: [0, NUM_CFGS) data-parallel tilings of this file, [NUM_CFGS, NUM_CFGS + sk) the stream-K forms.
+// Config ids: [0, NUM_CFGS) data-parallel tilings of this file, then the stream-K forms, "decode32", then the
+// weights-in-registers tilings of gemm_wreg.hip (MIXQ_FMT_F16X64 operands only).
+static int total_configs() { return NUM_CFGS + mixq_sk_num_configs() + 1 + mixq_wr_num_configs(); }
 extern "C" int mixq_gemm_set_config(int cfg) {
-    if (cfg < -1 || cfg >= NUM_CFGS + mixq_sk_num_configs() + 1) return MIXQ_EINVAL;
+    if (cfg < -1 || cfg >= total_configs()) return MIXQ_EINVAL;
     g_forced_cfg = cfg;
     return MIXQ_OK;
 }
 extern "C" int mixq_gemm_set_trace(unsigned long long* buf) { g_trace = buf; return MIXQ_OK; }
-extern "C" int mixq_gemm_num_configs(void) { return NUM_CFGS + mixq_sk_num_configs() + 1; }
+extern "C" int mixq_gemm_num_configs(void) { return total_configs(); }
 extern "C" int mixq_gemm_config_name(int cfg, char* buf, int cap) {
-    if (cfg < 0 || cfg >= NUM_CFGS + mixq_sk_num_configs() + 1 || !buf || cap <= 0) return MIXQ_EINVAL;
-    snprintf(buf, cap, "%s", cfg < NUM_CFGS ? g_cfgs[cfg].name
-                                           : (cfg < NUM_CFGS + mixq_sk_num_configs() ? mixq_sk_config_name(cfg - NUM_CFGS) : "decode32"));
+    if (cfg < 0 || cfg >= total_configs() || !buf || cap <= 0) return MIXQ_EINVAL;
+    const int sk0 = NUM_CFGS, dec = sk0 + mixq_sk_num_configs(), wr0 = dec + 1;
+    snprintf(buf, cap, "%s", cfg < sk0 ? g_cfgs[cfg].name : (cfg < dec ? mixq_sk_config_name(cfg - sk0)
+                                                                      : (cfg == dec ? "decode32" : mixq_wr_config_name(cfg - wr0))));
     return MIXQ_OK;
 }
 extern "C" int mixq_gemm_pick_config(int M, int N, int K, int bit) {
@@ -858,6 +920,15 @@ extern "C" int mixq_gemm_pick_config(int M, int N, int K, int bit) {
     const int sk = pick_stream_k(M, N, KB);
     if (sk >= 0 && mixq_sk_usable(sk)) return NUM_CFGS + sk;
     return pick_config(M, N, KB, true);
+}
+// The config the automatic choice runs for operands in the packed format `fmt` (MIXQ_FMT_P16X64 / MIXQ_FMT_F16X64).
+extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) {
+    if (M <= 0 || N <= 0 || K <= 0 || (bit != 4 && bit != 8)) return MIXQ_EINVAL;
+    const int KB = bit == 8 ? K : K / 2;
+    const int dec = NUM_CFGS + mixq_sk_num_configs();
+    if (fmt != MIXQ_FMT_PLAIN && mixq_skinny_applies(bit, M, N, KB, true, true)) return dec;
+    if (fmt == MIXQ_FMT_F16X64) return dec + 1 + mixq_wr_pick(bit, M, N, KB);
+    return mixq_gemm_pick_config(M, N, K, bit);
 }
 
 extern "C" int mixq_version(void) { return 1000; }

@@ -26,6 +26,7 @@ struct SkinnyArgs {
     const uint16_t* sx; const uint16_t* sw; const uint16_t* xo; const uint16_t* wo;
     const int32_t* n_out_dev; const uint16_t* addend; const uint16_t* bias; uint16_t* y;
     int M, N, KB, ldxo, ldwo, n_out, lda, ldy, act, xrows16, wrows16;
+    int f16;                                             // operands in MIXQ_FMT_F16X64 instead of MIXQ_FMT_P16X64
 };
 
 constexpr int SKW = 8;                                   // waves per workgroup = k splits
@@ -53,10 +54,11 @@ __global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_kernel(const Skinn
     // fragment addresses: row r of 16-row block rb, k-step kb: ((kb * rows16/16 + rb) * 1024) + (r & 15) * 64 + chunk * 16
     int wr = n0 + lr; wr = wr < a.N ? wr : a.N - 1;                      // clamped rows are computed and dropped
     int xr = lr < a.M ? lr : a.M - 1;
-    const uint8_t* wp = a.qw + static_cast<size_t>(wr >> 4) * 1024 + (wr & 15) * 64;
-    const uint8_t* xp = a.qx + static_cast<size_t>(xr >> 4) * 1024 + (xr & 15) * 64;
-    const int wc0 = sk_swz(wr, lh) * 16, wc1 = sk_swz(wr, 2 + lh) * 16;      // sub-steps 0 / 1 take chunks lh / 2 + lh
-    const int xc0 = sk_swz(xr, lh) * 16, xc1 = sk_swz(xr, 2 + lh) * 16;
+    // P16X64: row r at r*64, chunk c at (c ^ swizzle)*16;  F16X64: chunk c at c*256, row r at r*16
+    const uint8_t* wp = a.qw + static_cast<size_t>(wr >> 4) * 1024 + (wr & 15) * (a.f16 ? 16 : 64);
+    const uint8_t* xp = a.qx + static_cast<size_t>(xr >> 4) * 1024 + (xr & 15) * (a.f16 ? 16 : 64);
+    const int wc0 = a.f16 ? lh * 256 : sk_swz(wr, lh) * 16, wc1 = a.f16 ? (2 + lh) * 256 : sk_swz(wr, 2 + lh) * 16;   // sub-steps 0 / 1: chunks lh / 2 + lh
+    const int xc0 = a.f16 ? lh * 256 : sk_swz(xr, lh) * 16, xc1 = a.f16 ? (2 + lh) * 256 : sk_swz(xr, 2 + lh) * 16;
     const size_t wks = static_cast<size_t>(a.wrows16) * 64, xks = static_cast<size_t>(a.xrows16) * 64;
 
     i32x16 acc, acc1;                                    // two chains: consecutive MFMAs never wait on each other
@@ -193,16 +195,16 @@ __global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_kernel(const Skinn
         if (a.act != MIXQ_ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = sk_silu(v[e]);
-            if (a.act == MIXQ_ACT_SILU_MUL) {                      // addend is the multiplier
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= av[e];
-            }
         }
         if (a.bias) {
             float bv[4];
             unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        }
+        if (a.act == MIXQ_ACT_SILU_MUL) {                          // addend is the multiplier; the bias is already in:
+#pragma unroll                                                     // (silu(z) + bias) * up, linear.py:372-373 then mlp.py:61
+            for (int e = 0; e < 4; ++e) v[e] *= av[e];
         }
         if (m < a.M && n < a.N) {
             u32x2 o;
@@ -222,13 +224,13 @@ bool mixq_skinny_applies(int bit, int M, int N, int KB, bool x_packed, bool w_pa
 
 int mixq_skinny_launch(int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col, const uint16_t* x_out,
                        int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev, const uint16_t* addend,
-                       int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act, hipStream_t st)
+                       int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act, int f16, hipStream_t st)
 {
     SkinnyArgs a;
     a.qx = static_cast<const uint8_t*>(q_x); a.qw = static_cast<const uint8_t*>(q_w);
     a.sx = x_scale; a.sw = scale_col; a.xo = x_out; a.wo = w_out; a.n_out_dev = n_out_dev; a.addend = addend; a.bias = bias; a.y = y;
     a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
-    a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
+    a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15; a.f16 = f16;
     if (bit == 8) hipLaunchKernelGGL((gemm_skinny_kernel<4, 2, false>), dim3((N + 31) / 32), dim3(SKW * 64), 0, st, a);
     else          hipLaunchKernelGGL((gemm_skinny_kernel<4, 2, true>), dim3((N + 31) / 32), dim3(SKW * 64), 0, st, a);
     return mixq_launch_status();

@@ -1,0 +1,13 @@
+// Internal interface between gemm.hip (dispatch) and gemm_wreg.hip (weights-in-registers kernels, MIXQ_FMT_F16X64 operands).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+int mixq_wr_num_configs();
+const char* mixq_wr_config_name(int c);
+// config for (M, N, KB) or -1 when the data-parallel kernels of gemm.hip should run instead
+int mixq_wr_pick(int bit, int M, int N, int KB);
+int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
+                   const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
+                   const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
+                   unsigned long long* trace, hipStream_t st);

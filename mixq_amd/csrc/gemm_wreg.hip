@@ -1,0 +1,555 @@
+// (iii)+(iv) again, second structure: the WEIGHT operand never touches LDS.
+//
+//   Y[m,n] = fp16( act( (sum_k Xq[m,k] Wq[n,k]) * sx[m] * sw[n]  +  sum_j Xo[m,j] Wo[n,j]  + addend[m,n] ) + bias[n] )
+//
+// Why (round-1 measurements): in gemm.hip both operands go HBM/L2 -> LDS by LDS-DMA and come back by
+// ds_read_b128.  DMA writes drain into the LDS at ~50 B/clk and fragment reads at 256 B/clk through the same port, and
+// the two ADD: a 128 x 192 tile costs (128+192)*64/50 + 4*(64+96)*64/256 = 570 LDS cycles per 64-byte k-step against 384
+// MFMA cycles, so the loop ran at 70 % MFMA occupancy and, everything being busy at once, at 1.7 GHz.
+// Here:
+//   * the 4 consumer waves of a workgroup sit side by side along N (1 x 4): each owns WN = 16*WNB weight rows nobody else
+//     in the workgroup needs, so its weight fragments go global -> VGPR directly.  The operand layout MIXQ_FMT_F16X64
+//     makes a fragment (16 rows x 64 bytes, lane l = row l&15, k-chunk l>>4: one v_mfma_i32_16x16x64_i8 A operand) ONE
+//     contiguous KiB: a single fully coalesced global_load_dwordx4 with a wave-uniform base, D k-steps deep in a
+//     register ring.  No barrier, no LDS, no duplication between waves for 60 % of the operand bytes.
+//   * only the activation tile (16*MB rows, shared by the 4 waves) is staged: 1 KiB blocks by LDS-DMA from dedicated
+//     loader wave(s) into an NSTAGE ring, read back with ds_read_b128 at lane*16 - in F16X64 a block IS the fragment,
+//     and lane-linear 16-byte reads are bank-conflict free by construction.  LDS traffic per k-step of the 128 x 192
+//     tile drops from 20 KB written + 40 KB read to 8 KB written + 32 KB read (~290 LDS cycles < 384 MFMA cycles).
+//   * a fragment of X is re-read in place right behind the last MFMA that used it (j-major MFMA order), so X needs MB
+//     fragment registers, not 2 MB.
+// Everything after the k loop is gemm.hip's epilogue restated for the 16x16 accumulator layout: in-place dequantisation,
+// fp16 outlier tail on the same registers (v_mfma_f32_16x16x32_f16), optional addend / SiLU / bias / multiplier, fp16
+// tile staged through LDS, 16-byte row stores.  Same arithmetic in the same order: results are bit-identical to gemm.hip.
+// Reference call sites replaced: mixlib.int8FusedDequantize[Silu] / int4FusedDequantize[Silu] and the torch.mm + bias around
+// them, /root/reference/mixquant/modules/linear.py:244-285, :330-373.
+#include "common.h"
+#include "gemm_wreg.h"
+#include <stdio.h>
+#include <string.h>
+#include <type_traits>
+
+namespace {
+
+struct WrArgs {
+    const uint8_t* qx;  const uint8_t* qw;            // F16X64 images: [KB/64][blocks][1 KiB]
+    const uint16_t* sx; const uint16_t* sw;
+    const uint16_t* xo; const uint16_t* wo;
+    const int32_t* n_out_dev;
+    const uint16_t* addend; const uint16_t* bias;
+    uint16_t* y;
+    int M, N, KB;
+    int ldxo, ldwo, n_out, lda, ldy, act;
+    int tiles_m, tiles_n;
+    int xblocks, wblocks;                             // 16-row blocks per k-step of each operand
+    unsigned long long* trace;
+};
+
+constexpr int WR_CW = 4;                              // consumer waves, 1 x 4 along N
+
+template <int N> __device__ __forceinline__ void wr_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+__device__ __forceinline__ void wr_glds16(const uint8_t* gsrc, uint8_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ float wr_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
+// MB: 16-row activation blocks per tile (BM = 16 MB), WNB: 16-row weight blocks per wave (BN = 64 WNB), NSTAGE: X ring depth,
+// D: weight register ring depth (k-steps), I4: nibble-packed operands, LOADERS: DMA waves, ABL (tuning): 0 normal,
+// 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only.
+template <int MB, int WNB, int NSTAGE, int D, bool I4, int LOADERS, int ABL>
+__global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const WrArgs a)
+{
+    constexpr int CW = WR_CW;
+    constexpr int NT = (CW + LOADERS) * 64;
+    constexpr int BM = MB * 16, WN = WNB * 16, BN = CW * WN;
+    constexpr int STAGE_BYTES = MB * 1024;
+    constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
+    constexpr int LOADS = MB / LOADERS;                  // DMA pieces per loader wave and stage
+    constexpr int OPITCH = BN * 2 + 16;
+    static_assert(LOADERS >= 1 && MB % LOADERS == 0, "pieces must divide evenly over the loader waves");
+    static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int tile;
+    {
+        const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, x = b & 7, s = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;          // XCD-aware, bijective for any ntiles
+    }
+    const int tn = tile / a.tiles_m, tm = tile - tn * a.tiles_m;               // m fastest: a weight panel stays on one XCD
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id_uniform();
+    const int nk = a.KB >> 6;
+    auto stamp = [&](int slot) {
+        if (a.trace && tid == 0) {
+            a.trace[blockIdx.x * 16 + slot] = wall_clock64();
+            a.trace[blockIdx.x * 16 + 8 + slot] = __builtin_readcyclecounter();
+        }
+    };
+    stamp(0);
+
+    // =================================================================================================================
+    // loader wave(s): X stage kt+LOOK issued, stage kt+1 retired, then the k-step's barrier
+    // =================================================================================================================
+    if (wave >= CW) {
+        __builtin_amdgcn_s_setprio(2);
+        const int lw = wave - CW;
+        const uint8_t* src[LOADS];
+        int dsto[LOADS];
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int p = lw + i * LOADERS;
+            int rb = (m0 >> 4) + p; rb = rb < a.xblocks ? rb : a.xblocks - 1;      // blocks past M: loaded, computed, dropped
+            src[i] = a.qx + static_cast<size_t>(rb) * 1024 + lane * 16;
+            dsto[i] = p * 1024;
+        }
+        const size_t xks = static_cast<size_t>(a.xblocks) * 1024;
+        auto stage = [&](int slot) {
+            if constexpr (ABL != 2 && ABL != 3) {
+#pragma unroll
+                for (int i = 0; i < LOADS; ++i) { wr_glds16(src[i], lds + slot * STAGE_BYTES + dsto[i]); src[i] += xks; }
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < LOOK; ++s)
+            if (s < nk) stage(s);
+        if (NEWER < nk) wr_wait_vmcnt<LOADS * NEWER>(); else wr_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                            // B0: stage 0 landed
+        int nxt = LOOK % NSTAGE, kt = 0;
+        for (; kt + LOOK < nk; ++kt) {
+            stage(nxt);
+            wr_wait_vmcnt<LOADS * NEWER>();                                      // stage kt+1 landed
+            __builtin_amdgcn_s_barrier();
+            nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+        }
+        for (; kt + 1 < nk; ++kt) {
+            wr_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();                                            // the epilogue's two barriers
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // =================================================================================================================
+    // consumer waves
+    // =================================================================================================================
+    const int lm = lane & 15, lq = lane >> 4;
+    const int nw0 = n0 + wave * WN;                                              // first weight row of this wave (wave < CW)
+    i32x4 acc[MB][WNB];
+    uint16_t sxh[MB];
+    u32x2 swp[WNB];
+    int n_out_dev_v = 0;
+
+    if (wave < CW) {
+        if (a.n_out_dev) n_out_dev_v = *a.n_out_dev;
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+#pragma unroll
+            for (int i = 0; i < WNB; ++i) acc[j][i] = i32x4{0, 0, 0, 0};
+
+        // weight stream: wave-uniform block bases (scalar registers), one lane offset
+        const uint8_t* wb[WNB];
+#pragma unroll
+        for (int i = 0; i < WNB; ++i) {
+            int rb = (nw0 >> 4) + i; rb = rb < a.wblocks ? rb : a.wblocks - 1;      // blocks past N: computed and dropped
+            wb[i] = a.qw + static_cast<size_t>(rb) * 1024;
+        }
+        const size_t wks = static_cast<size_t>(a.wblocks) * 1024;
+        const int lane16 = lane * 16;
+        i32x4 wq[D][WNB];
+        i32x4 xf[MB];
+        if constexpr (ABL != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) { wq[d][i] = i32x4{lane, lane, lane, lane}; asm volatile("" : "+v"(wq[d][i])); }
+#pragma unroll
+            for (int j = 0; j < MB; ++j) { xf[j] = i32x4{lane, 1, lane, 1}; asm volatile("" : "+v"(xf[j])); }
+        }
+        // The weight loads are inline asm with hand-counted waits: left to the compiler, the loop header of the unrolled k
+        // loop gets `s_waitcnt vmcnt(0)` (its counter model merges the preheader and latch states conservatively), which
+        // drains the whole register ring every D k-steps.  A load's destination is only meaningful after wwait() for its slot.
+        auto wload = [&](auto d_c) {
+            constexpr int d = decltype(d_c)::value;
+            if constexpr (ABL != 1 && ABL != 3) {
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) {
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wq[d][i]) : "v"(lane16), "s"(wb[i]) : "memory");
+                    wb[i] += wks;
+                }
+            }
+        };
+        // wait until at most `younger` loads issued after slot d's are outstanding (vmcnt retires in order); naming the
+        // slot's registers as read-write operands makes every MFMA that uses them depend on this statement
+        auto wwait = [&](auto d_c, auto cnt_c) {
+            constexpr int d = decltype(d_c)::value, CNT = decltype(cnt_c)::value;
+            if constexpr (ABL != 1 && ABL != 3) {
+                if constexpr (WNB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wq[d][0]) : "i"(CNT));
+                if constexpr (WNB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wq[d][0]), "+v"(wq[d][1]) : "i"(CNT));
+                if constexpr (WNB == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]) : "i"(CNT));
+                if constexpr (WNB == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]), "+v"(wq[d][3]) : "i"(CNT));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto xread = [&](int slot, int j) {
+            if constexpr (ABL != 2 && ABL != 3)
+                xf[j] = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * 1024 + lane16);
+        };
+        uint32_t nib = 0xf0f0f0f0u;
+        if constexpr (I4) asm volatile("s_mov_b32 %0, 0xf0f0f0f0" : "=s"(nib));
+        auto lo4 = [&](i32x4 v) { i32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = static_cast<int>((static_cast<uint32_t>(v[e]) << 4) & nib);
+            return o; };
+        auto hi4 = [&](i32x4 v) { i32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = static_cast<int>(static_cast<uint32_t>(v[e]) & nib);
+            return o; };
+
+        // one k-step: MFMAs of ring slot d, X fragment j re-read from stage kt+1 right behind its last MFMA (REFILL), the
+        // weight loads of k-step kt+D into the slot just consumed (ISSUE)
+        auto step = [&](auto d_c, bool refill, bool issue, int rslot) {
+            constexpr int d = decltype(d_c)::value;
+            if constexpr (!I4) {
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[d][i], xf[j], acc[j][i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (refill) xread(rslot, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // nibbles -> int8 values 16 q: even columns (low nibbles) and odd columns (high nibbles) form two fragments,
+                // split identically on both operands so the k pairing is preserved; the factor 256 leaves in the epilogue
+                i32x4 wl[WNB], wh[WNB];
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) { wl[i] = lo4(wq[d][i]); wh[i] = hi4(wq[d][i]); }
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    const i32x4 xl = lo4(xf[j]), xh = hi4(xf[j]);
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wl[i], xl, acc[j][i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wh[i], xh, acc[j][i], 0, 0, 0);
+                    if (refill) xread(rslot, j);
+                }
+            }
+            if (issue) wload(d_c);
+        };
+
+        // ---- prologue ------------------------------------------------------------------------------------------------
+        // the epilogue's scales first: the oldest loads of this wave, so they never sit between the hand-counted weight loads
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = m0 + j * 16 + lm;
+            sxh[j] = a.sx[m < a.M ? m : a.M - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < WNB; ++i) {
+            const int n = nw0 + i * 16 + lq * 4;                                 // N % 4 == 0: 4 columns are all in or all out
+            swp[i] = *reinterpret_cast<const u32x2_u*>(a.sw + (n < a.N ? n : a.N - 4));
+        }
+        auto prologue_w = [&](auto d_c) { if (decltype(d_c)::value < nk) wload(d_c); };
+        prologue_w(std::integral_constant<int, 0>{});
+        if constexpr (D > 1) prologue_w(std::integral_constant<int, 1>{});
+        if constexpr (D > 2) prologue_w(std::integral_constant<int, 2>{});
+        if constexpr (D > 3) prologue_w(std::integral_constant<int, 3>{});
+        if constexpr (D > 4) prologue_w(std::integral_constant<int, 4>{});
+        if constexpr (D > 5) prologue_w(std::integral_constant<int, 5>{});
+        static_assert(D <= 6, "extend the prologue");
+        __builtin_amdgcn_s_barrier();                                            // B0
+        stamp(1);
+        // every scalar (kernel-argument) load has long returned; telling the compiler's counter model so keeps the loop
+        // header from merging "SMEM pending" with the LDS reads in flight into an lgkmcnt(0) per D k-steps
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                      // lgkmcnt(0)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) xread(0, j);
+
+        // ---- k loop: unrolled by D so ring slots are compile-time registers -------------------------------------------
+        int kt = 0, slot1 = 1 % NSTAGE;                                          // ring slot of stage kt+1
+        auto one = [&](auto d_c, auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;                       // FULL: stage kt+1 and k-step kt+D exist
+            if constexpr (FULL) {
+                wwait(d_c, std::integral_constant<int, WNB * (D - 1)>{});        // the D-1 younger slots stay in flight
+                __builtin_amdgcn_s_barrier();                                    // stage kt+1 landed; stage kt-2's slot is free
+                step(d_c, true, true, slot1);
+            } else {
+                const int younger = nk - 1 - kt;                                 // k-steps whose weights were requested after this one's
+                if (D > 1 && younger >= D - 1)      wwait(d_c, std::integral_constant<int, WNB * (D - 1)>{});
+                else if (D > 2 && younger == D - 2) wwait(d_c, std::integral_constant<int, WNB * (D > 2 ? D - 2 : 0)>{});
+                else if (D > 3 && younger == D - 3) wwait(d_c, std::integral_constant<int, WNB * (D > 3 ? D - 3 : 0)>{});
+                else if (D > 4 && younger == D - 4) wwait(d_c, std::integral_constant<int, WNB * (D > 4 ? D - 4 : 0)>{});
+                else if (D > 5 && younger == D - 5) wwait(d_c, std::integral_constant<int, WNB * (D > 5 ? D - 5 : 0)>{});
+                else                                wwait(d_c, std::integral_constant<int, 0>{});
+                const bool more = kt + 1 < nk;
+                if (more) __builtin_amdgcn_s_barrier();
+                step(d_c, more, kt + D < nk, slot1);
+            }
+            slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
+            ++kt;
+        };
+        auto group = [&](auto full_c) {
+            one(std::integral_constant<int, 0>{}, full_c);
+            if constexpr (D > 1) one(std::integral_constant<int, 1>{}, full_c);
+            if constexpr (D > 2) one(std::integral_constant<int, 2>{}, full_c);
+            if constexpr (D > 3) one(std::integral_constant<int, 3>{}, full_c);
+            if constexpr (D > 4) one(std::integral_constant<int, 4>{}, full_c);
+            if constexpr (D > 5) one(std::integral_constant<int, 5>{}, full_c);
+        };
+        while (kt + 2 * D <= nk) group(std::true_type{});                        // every k-step of the group has kt + D < nk
+        while (kt < nk) {                                                        // at most 2 D - 1 k-steps, guarded individually
+            // (a group is entered at ring slot 0, so slot d holds k-step kt + d here as well)
+            const int k0 = kt;
+            auto tail_one = [&](auto d_c) { if (k0 + decltype(d_c)::value < nk) one(d_c, std::false_type{}); };
+            tail_one(std::integral_constant<int, 0>{});
+            if constexpr (D > 1) tail_one(std::integral_constant<int, 1>{});
+            if constexpr (D > 2) tail_one(std::integral_constant<int, 2>{});
+            if constexpr (D > 3) tail_one(std::integral_constant<int, 3>{});
+            if constexpr (D > 4) tail_one(std::integral_constant<int, 4>{});
+            if constexpr (D > 5) tail_one(std::integral_constant<int, 5>{});
+        }
+        stamp(2);
+    }
+
+    // =================================================================================================================
+    // epilogue
+    // =================================================================================================================
+    const bool staged = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+    if (wave < CW) {
+        int n_out = a.n_out;
+        if (a.n_out_dev) n_out = n_out_dev_v < n_out ? n_out_dev_v : n_out;
+        if (!a.xo || !a.wo) n_out = 0;
+        const int kpad = (n_out + 15) & ~15;                                     // readable width of an outlier row
+        const int ksteps = (n_out + 31) >> 5;
+        constexpr float PRE = I4 ? (1.f / 256.f) : 1.f;
+        const bool has_add = a.addend != nullptr, has_bias = a.bias != nullptr, do_silu = a.act != MIXQ_ACT_NONE;
+        const bool mul_add = a.act == MIXQ_ACT_SILU_MUL;
+        auto unpack4 = [](u32x2 v, float* o) {
+            o[0] = h2f(static_cast<uint16_t>(v.x & 0xffffu)); o[1] = h2f(static_cast<uint16_t>(v.x >> 16));
+            o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
+        };
+
+        // fp16 outlier tail operands: 16 x 32 fragments, lane = row lm, columns kk*32 + lq*8 .. +8.  Two register sets.
+        u32x4 xoq[2][MB], woq[2][WNB];
+        auto tail_load = [&](int P, int kk) {              // P: constant after unrolling
+            const int kb = kk * 32 + lq * 8;
+            const bool in = kb < kpad;                     // chunks past the padded width are not addressable: zeros
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                int xr = m0 + j * 16 + lm; xr = xr < a.M ? xr : a.M - 1;
+                xoq[P][j] = in ? *reinterpret_cast<const u32x4*>(a.xo + static_cast<size_t>(xr) * a.ldxo + kb) : u32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < WNB; ++i) {
+                int wr = nw0 + i * 16 + lm; wr = wr < a.N ? wr : a.N - 1;
+                woq[P][i] = in ? *reinterpret_cast<const u32x4*>(a.wo + static_cast<size_t>(wr) * a.ldwo + kb) : u32x4{0, 0, 0, 0};
+            }
+        };
+        if (ksteps > 0) tail_load(0, 0);
+        __builtin_amdgcn_s_barrier();                                            // every wave is done reading the ring
+        stamp(6);
+
+        f32x4 fa[MB][WNB];
+        {
+            float swv[WNB][4];
+#pragma unroll
+            for (int i = 0; i < WNB; ++i) unpack4(swp[i], swv[i]);
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                const float sxv = h2f(sxh[j]) * PRE;
+#pragma unroll
+                for (int i = 0; i < WNB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fa[j][i][r] = static_cast<float>(acc[j][i][r]) * sxv * swv[i][r];
+            }
+        }
+        auto tail_mma = [&](int P, int kk) {
+            const int kb = kk * 32 + lq * 8;
+            if (kb + 8 > n_out) {                                                // mask columns >= n_out (the pad may hold anything)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t keep = 0;
+                    if (kb + 2 * d < n_out)     keep |= 0x0000ffffu;
+                    if (kb + 2 * d + 1 < n_out) keep |= 0xffff0000u;
+#pragma unroll
+                    for (int j = 0; j < MB; ++j) xoq[P][j][d] &= keep;
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) woq[P][i][d] &= keep;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+#pragma unroll
+                for (int i = 0; i < WNB; ++i)
+                    fa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, woq[P][i]),
+                                                                      __builtin_bit_cast(f16x8, xoq[P][j]), fa[j][i], 0, 0, 0);
+        };
+        if (ksteps > 1) tail_load(1, 1);
+        for (int kk0 = 0; kk0 < ksteps; kk0 += 2) {
+            tail_mma(0, kk0);
+            if (kk0 + 2 < ksteps) tail_load(0, kk0 + 2);
+            if (kk0 + 1 < ksteps) {
+                tail_mma(1, kk0 + 1);
+                if (kk0 + 3 < ksteps) tail_load(1, kk0 + 3);
+            }
+        }
+
+        auto finish_tile = [&](auto staged_c, auto opt_c) {
+            constexpr bool ST = decltype(staged_c)::value, OPT = decltype(opt_c)::value;
+#pragma unroll
+            for (int i = 0; i < WNB; ++i) {
+                const int nloc = wave * WN + i * 16 + lq * 4, n = n0 + nloc;
+                const int nc = n < a.N ? n : a.N - 4;
+                float bv[4];
+                if (OPT && has_bias) unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    const int mloc = j * 16 + lm, m = m0 + mloc;
+                    f32x4 f = fa[j][i];
+                    float av[4];
+                    if (OPT && has_add) {
+                        unpack4(*reinterpret_cast<const u32x2_u*>(a.addend + static_cast<size_t>(m < a.M ? m : a.M - 1) * a.lda + nc), av);
+                        if (!mul_add) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) f[r] += av[r];
+                        }
+                    }
+                    if (OPT && do_silu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] = wr_silu(f[r]);
+                    }
+                    if (OPT && has_bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] += bv[r];
+                    }
+                    if (OPT && mul_add) {                          // (silu(z) + bias) * up: linear.py:372-373, then mlp.py:61
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] *= av[r];
+                    }
+                    u32x2 o;
+                    o.x = static_cast<uint32_t>(f2h(f[0])) | (static_cast<uint32_t>(f2h(f[1])) << 16);
+                    o.y = static_cast<uint32_t>(f2h(f[2])) | (static_cast<uint32_t>(f2h(f[3])) << 16);
+                    if constexpr (ST) {
+                        *reinterpret_cast<u32x2*>(lds + mloc * OPITCH + nloc * 2) = o;
+                    } else {
+                        if (m < a.M && n < a.N) *reinterpret_cast<u32x2_u*>(a.y + static_cast<size_t>(m) * a.ldy + n) = o;
+                    }
+                }
+            }
+        };
+        const bool opt = has_add || has_bias || do_silu;
+        if (staged) { if (opt) finish_tile(std::true_type{}, std::true_type{}); else finish_tile(std::true_type{}, std::false_type{}); }
+        else        { if (opt) finish_tile(std::false_type{}, std::true_type{}); else finish_tile(std::false_type{}, std::false_type{}); }
+        stamp(7);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // ds_write is asynchronous; s_barrier does not wait for it
+        __builtin_amdgcn_s_barrier();                                            // staging tile complete
+        stamp(3);
+    }
+    if (staged) {
+        constexpr int CPR = BN / 8;                                              // 16-byte chunks per tile row
+        for (int q = tid; q < BM * CPR; q += NT) {
+            const int r = q / CPR, c = q - r * CPR;
+            const int m = m0 + r, n = n0 + c * 8;
+            if (m < a.M && n < a.N) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * OPITCH + c * 16);
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n));
+            }
+        }
+    }
+    if (a.trace) {
+        stamp(4);
+        wr_wait_vmcnt<0>();
+        stamp(5);
+    }
+}
+
+// ---- configuration table -------------------------------------------------------------------------------------------
+struct WrConfig {
+    const char* name;
+    int mb, wnb, nstage, loaders;
+    void (*k8)(const WrArgs);
+    void (*k4)(const WrArgs);
+};
+#define MIXQ_WR(MBv, WNBv, NS, Dv, LD, ABL, TAG)                                                                        \
+    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, false, LD, ABL>, gemm_wreg_kernel<MBv, WNBv, NS, Dv, true, LD, ABL> }
+
+const WrConfig g_wr[] = {
+    MIXQ_WR(8, 3, 8, 4, 1, 0, "128x192_s8_d4_l1"),     // 0: the metric shape's tile: 232 tiles at 512 x 11008
+    MIXQ_WR(8, 3, 8, 4, 2, 0, "128x192_s8_d4_l2"),     // 1
+    MIXQ_WR(8, 3, 6, 3, 1, 0, "128x192_s6_d3_l1"),     // 2
+    MIXQ_WR(8, 3, 8, 6, 1, 0, "128x192_s8_d6_l1"),     // 3
+    MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 4
+    MIXQ_WR(8, 4, 8, 3, 1, 0, "128x256_s8_d3_l1"),     // 5
+    MIXQ_WR(4, 2, 8, 4, 1, 0, "64x128_s8_d4_l1"),      // 6: N = 4096 at M = 512 is exactly 256 such tiles
+    MIXQ_WR(4, 3, 8, 4, 1, 0, "64x192_s8_d4_l1"),      // 7: N = 6144
+    MIXQ_WR(4, 4, 8, 4, 1, 0, "64x256_s8_d4_l1"),      // 8
+    MIXQ_WR(8, 1, 8, 4, 1, 0, "128x64_s8_d4_l1"),      // 9
+    MIXQ_WR(4, 1, 8, 4, 1, 0, "64x64_s8_d4_l1"),       // 10
+    MIXQ_WR(8, 3, 8, 4, 1, 1, "128x192_abl1_noW"),     // 11: cfg 0 without the weight loads
+    MIXQ_WR(8, 3, 8, 4, 1, 2, "128x192_abl2_noX"),     // 12: cfg 0 without X traffic
+    MIXQ_WR(8, 3, 8, 4, 1, 3, "128x192_abl3_mfma"),    // 13: cfg 0, MFMA + epilogue only
+};
+constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
+constexpr int WR_MAX_DEV = 16;
+bool g_wr_attr[NUM_WR][2][WR_MAX_DEV];
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+int mixq_wr_num_configs() { return NUM_WR; }
+const char* mixq_wr_config_name(int c) { return (c >= 0 && c < NUM_WR) ? g_wr[c].name : "?"; }
+
+// Estimated time ~ rounds over the 256 CUs x time per k-step of one tile (us, MI355X; tools/sweep_gemm.py).
+int mixq_wr_pick(int bit, int M, int N, int KB)
+{
+    (void)bit; (void)KB;
+    if (M <= 32) return 10;                              // (decode normally runs the weight-stream kernel of gemm_skinny.hip)
+    static const struct { int cfg; float tk; } cand[] = {{0, 0.30f}, {4, 0.22f}, {5, 0.38f}, {6, 0.13f}, {7, 0.17f}, {8, 0.21f}, {9, 0.15f}, {10, 0.09f}};
+    double best = 1e30; int bi = -1;
+    for (const auto& c : cand) {
+        const WrConfig& g = g_wr[c.cfg];
+        const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
+        const double t = cdiv(tiles, 256) * static_cast<double>(c.tk);
+        if (t < best * 0.999) { best = t; bi = c.cfg; }
+    }
+    return bi;
+}
+
+int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
+                   const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
+                   const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
+                   unsigned long long* trace, hipStream_t st)
+{
+    if (c < 0 || c >= NUM_WR) return MIXQ_EINVAL;
+    const WrConfig& g = g_wr[c];
+    WrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.qx = static_cast<const uint8_t*>(q_x); a.qw = static_cast<const uint8_t*>(q_w);
+    a.sx = x_scale; a.sw = scale_col; a.xo = x_out; a.wo = w_out; a.n_out_dev = n_out_dev;
+    a.addend = addend; a.bias = bias; a.y = y;
+    a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
+    const int bm = g.mb * 16, bn = g.wnb * 64;
+    a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, bn);
+    a.xblocks = (M + 15) >> 4; a.wblocks = (N + 15) >> 4;
+    a.trace = trace;
+    void (*k)(const WrArgs) = bit == 8 ? g.k8 : g.k4;
+    const size_t ring = static_cast<size_t>(g.nstage) * g.mb * 1024, stg = static_cast<size_t>(bm) * (bn * 2 + 16);
+    const size_t shm = ring > stg ? ring : stg;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WR_MAX_DEV) { (void)hipGetLastError(); return MIXQ_ENODEV; }
+    bool& done = g_wr_attr[c][bit == 8 ? 0 : 1][dev];
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
+        if (e != hipSuccess) return static_cast<int>(e);
+        done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3((WR_CW + g.loaders) * 64), shm, st, a);
+    return mixq_launch_status();
+}

@@ -18,11 +18,6 @@ namespace {
 
 constexpr int NT = 256;
 
-__device__ __forceinline__ size_t p16x64_offset(int row, int kb, int rows16) {
-    const int r = row & 15, c = (kb & 63) >> 4;
-    return (static_cast<size_t>(kb >> 6) * (rows16 >> 4) + (row >> 4)) * 1024 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + (kb & 15);
-}
-
 // y = fp16( fp32(fp32(x * inv) * w) ): every product is rounded to fp32 before the next step.  Written with the _rn
 // intrinsics and an opaque barrier so the compiler cannot fold the last multiply and the conversion into one
 // v_fma_mixlo_f16 (a single rounding of the exact product, which differs from the contract in ~1 of 30k elements).
@@ -53,7 +48,7 @@ template <int BIT, int NCH, bool QUANT>
 __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ w, float eps, uint16_t* __restrict__ out, int ldout,
     const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev, uint16_t* __restrict__ x_scale,
-    void* __restrict__ q, uint16_t* __restrict__ x_out, int ldxo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16)
+    void* __restrict__ q, uint16_t* __restrict__ x_out, int ldxo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];     // column bitmask, then 8 floats
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -159,13 +154,13 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
                 uint2 o;
                 o.x = (qv[0] & 0xff) | ((qv[1] & 0xff) << 8) | ((qv[2] & 0xff) << 16) | (static_cast<uint32_t>(qv[3] & 0xff) << 24);
                 o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
-                const size_t off = rows16 ? p16x64_offset(row, c * 8, rows16) : static_cast<size_t>(row) * K + c * 8;
+                const size_t off = fmt ? packed_offset(fmt, row, c * 8, rows16) : static_cast<size_t>(row) * K + c * 8;
                 *reinterpret_cast<uint2*>(qb + off) = o;
             } else {
                 uint32_t o = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o |= static_cast<uint32_t>((qv[2 * e] & 0xf) | ((qv[2 * e + 1] & 0xf) << 4)) << (8 * e);
-                const size_t off = rows16 ? p16x64_offset(row, c * 4, rows16) : static_cast<size_t>(row) * (K >> 1) + c * 4;
+                const size_t off = fmt ? packed_offset(fmt, row, c * 4, rows16) : static_cast<size_t>(row) * (K >> 1) + c * 4;
                 *reinterpret_cast<uint32_t*>(qb + off) = o;
             }
         }
@@ -181,7 +176,7 @@ int launch_norm(const uint16_t* x, int ldx, const uint16_t* w, float eps, uint16
     const int nchunk = K >> 3;
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g(M), b(NT);
-#define MIXQ_NLAUNCH(NCH) hipLaunchKernelGGL((rmsnorm_kernel<BIT, NCH, QUANT>), g, b, shm, st, x, ldx, w, eps, out, ldout, ind, n, n_dev, x_scale, q, x_out, ldxo, flag, K, thr, rows16)
+#define MIXQ_NLAUNCH(NCH) hipLaunchKernelGGL((rmsnorm_kernel<BIT, NCH, QUANT>), g, b, shm, st, x, ldx, w, eps, out, ldout, ind, n, n_dev, x_scale, q, x_out, ldxo, flag, K, thr, rows16, qfmt)
     if      (nchunk <= 2 * NT)  MIXQ_NLAUNCH(2);
     else if (nchunk <= 4 * NT)  MIXQ_NLAUNCH(4);
     else if (nchunk <= 8 * NT)  MIXQ_NLAUNCH(8);
@@ -212,10 +207,10 @@ extern "C" int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weigh
 {
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !weight || !out || !x_scale || !q))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
     if (n > 0 && (!ind || !x_out || ldxo < n)) return MIXQ_EINVAL;
     if ((K & 7) || (ldx & 7) || (ldout & 7) || ldx < K || ldout < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
-    if (qfmt == MIXQ_FMT_P16X64 && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
+    if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M == 0) return MIXQ_OK;
     const float qmax = static_cast<float>((1 << (bit - 1)) - 1);
     const float thr = fp16_round(fp16_round(sigma) / qmax);

@@ -44,16 +44,9 @@ __device__ __forceinline__ float amax_finish(uint32_t acc) {
     return h2f(static_cast<uint16_t>(lo > hi ? lo : hi));
 }
 
-// Byte address of byte `kb` of row `row` in the P16x64 tile-major layout (pack.hip): [KB/64][rows16/16] blocks of
-// 16 rows x 64 bytes whose 16-byte chunks are XOR-swizzled exactly like the GEMM's LDS image.
-__device__ __forceinline__ size_t p16x64_offset(int row, int kb, int rows16) {
-    const int r = row & 15, c = (kb & 63) >> 4;
-    return (static_cast<size_t>(kb >> 6) * (rows16 >> 4) + (row >> 4)) * 1024 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + (kb & 15);
-}
-
-// q: plain -> row base pointer, packed -> matrix base pointer
+// q: plain -> row base pointer, packed (fmt != 0) -> matrix base pointer
 template <int BIT>
-__device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, void* q, int chunk, int row, int rows16) {
+__device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, void* q, int chunk, int row, int rows16, int fmt) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     int qv[8];
 #pragma unroll
@@ -65,15 +58,15 @@ __device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, 
         uint2 o;
         o.x = (qv[0] & 0xff) | ((qv[1] & 0xff) << 8) | ((qv[2] & 0xff) << 16) | (static_cast<uint32_t>(qv[3] & 0xff) << 24);
         o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
-        if (rows16) *reinterpret_cast<uint2*>(static_cast<char*>(q) + p16x64_offset(row, chunk * 8, rows16)) = o;
-        else        reinterpret_cast<uint2*>(q)[chunk] = o;
+        if (fmt) *reinterpret_cast<uint2*>(static_cast<char*>(q) + packed_offset(fmt, row, chunk * 8, rows16)) = o;
+        else     reinterpret_cast<uint2*>(q)[chunk] = o;
     } else {   // nibble pack: low nibble = even column (linear.py:14-18)
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             o |= static_cast<uint32_t>((qv[2 * i] & 0xf) | ((qv[2 * i + 1] & 0xf) << 4)) << (8 * i);
-        if (rows16) *reinterpret_cast<uint32_t*>(static_cast<char*>(q) + p16x64_offset(row, chunk * 4, rows16)) = o;
-        else        reinterpret_cast<uint32_t*>(q)[chunk] = o;
+        if (fmt) *reinterpret_cast<uint32_t*>(static_cast<char*>(q) + packed_offset(fmt, row, chunk * 4, rows16)) = o;
+        else     reinterpret_cast<uint32_t*>(q)[chunk] = o;
     }
 }
 
@@ -83,7 +76,7 @@ template <int BIT, int NCH>
 __global__ __launch_bounds__(QT) void quant_rows_kernel(
     uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
     uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int ldo,
-    int32_t* __restrict__ flag, int K, float thr_scale, int rows16)
+    int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32 (+1)] column bitmask, 4 floats, row copy
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -161,22 +154,106 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
     }
-    void* qrow = rows16 ? q : static_cast<void*>(static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1)));
+    void* qrow = fmt ? q : static_cast<void*>(static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1)));
     if constexpr (NCH > 0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * QT;
-            if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16);
+            if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
         }
     } else {
         for (int c = tid; c < nchunk; c += QT) {
             uint4 v = xv[c];
             uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
             (void)amax8_masked(v, m8, 0u);
-            quant_store8<BIT>(v, s, rs, qrow, c, row, rows16);
+            quant_store8<BIT>(v, s, rs, qrow, c, row, rows16, fmt);
         }
     }
 }
+
+// Second form of the same pass (round 2): TPR threads per row, RPB rows per workgroup.  What changed against the kernel
+// above, which needed 5.9 us for 6.3 MB (13 % of the HBM rate): the outlier values are gathered straight from global
+// memory while the row loads are in flight (no LDS copy of the row, no second pass over it), the column bitmask is built
+// once per workgroup and shared by its RPB rows, and with TPR == 64 a row lives in ONE wave, so the absmax needs no LDS
+// round trip and no barrier at all when the layer has no outlier columns.  Results are bit-identical to the first form.
+template <int BIT, int TPR, int RPB, int NCH>
+__global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
+    uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
+    uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int ldo,
+    int32_t* __restrict__ flag, int M, int K, float thr_scale, int rows16, int fmt)
+{
+    constexpr int NT = TPR * RPB, WPR = TPR / 64;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32] column bitmask, RPB * WPR floats
+    const int tid = threadIdx.x, rw = tid / TPR, t = tid - rw * TPR;
+    const int row = blockIdx.x * RPB + rw;
+    const bool valid = row < M;
+    const int mask_words = (K + 31) >> 5;
+    float* red = reinterpret_cast<float*>(smem + mask_words);
+    uint16_t* xr = x + static_cast<size_t>(valid ? row : 0) * ldx;
+    const int nchunk = K >> 3;
+    const uint4* xv = reinterpret_cast<const uint4*>(xr);
+
+    uint4 keep[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = t + i * TPR;
+        keep[i] = (valid && c < nchunk) ? xv[c] : make_uint4(0, 0, 0, 0);
+    }
+    int n = n_cap;
+    if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
+    const bool have_out = (n > 0) && ind != nullptr;
+    if (have_out) {
+        for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
+        int cmine = 0;
+        if (t < n) cmine = ind[t];                             // in flight across the barrier
+        __syncthreads();
+        for (int j = tid; j < n; j += NT) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
+        if (valid) {
+            for (int j = t; j < n; j += TPR) {
+                const int c = (j == t) ? cmine : ind[j];
+                const uint16_t v = xr[c];                      // same thread reads, then zeroes: ordered
+                if (x_out) x_out[static_cast<size_t>(row) * ldo + j] = v;
+                xr[c] = 0;                                     // reference zeroes the caller's tensor in place
+            }
+        }
+        __syncthreads();
+    }
+    if (x_out && valid) for (int j = (have_out ? n : 0) + t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = 0;
+
+    uint32_t amax_acc = 0u;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = t + i * TPR;
+        if (c < nchunk) {
+            const uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
+            amax_acc = amax8_masked(keep[i], m8, amax_acc);
+        }
+    }
+    float amax = wave_max(amax_finish(amax_acc));
+    if constexpr (WPR > 1) {
+        if ((tid & 63) == 0) red[tid >> 6] = amax;
+        __syncthreads();
+        amax = red[rw * WPR];
+#pragma unroll
+        for (int w = 1; w < WPR; ++w) amax = fmaxf(amax, red[rw * WPR + w]);
+    }
+    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
+    const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
+    const float s = h2f(sh);
+    const float rs = s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;
+    if (!valid) return;
+    if (t == 0) {
+        x_scale[row] = sh;
+        if (flag && s > thr_scale) atomicOr(flag, 1);
+    }
+    void* qrow = fmt ? q : static_cast<void*>(static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1)));
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = t + i * TPR;
+        if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
+    }
+}
+
 
 __global__ __launch_bounds__(QT) void extract_kernel(uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind,
                                                      int n, uint16_t* __restrict__ x_out, int ldo)
@@ -262,20 +339,54 @@ __global__ __launch_bounds__(QT) void dequant_cols_kernel(const uint8_t* __restr
     out[static_cast<size_t>(r) * ldo + j] = f2h(f);
 }
 
-// Re-tile a plain [R,KB] byte matrix into P16x64; one 16-byte chunk per thread, rows >= R are zero-filled.
-__global__ __launch_bounds__(QT) void pack_p16x64_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R,
-                                                         int KB, int rows16)
+// Re-tile a plain [R,KB] byte matrix into a packed format (UNPACK: the inverse); one 16-byte chunk per thread in the
+// order of the packed image, rows >= R are zero-filled when packing and skipped when unpacking.
+template <bool UNPACK>
+__global__ __launch_bounds__(QT) void repack_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R, int KB,
+                                                    int rows16, int fmt)
 {
     const long long t = static_cast<long long>(blockIdx.x) * QT + threadIdx.x;
     const long long total = static_cast<long long>(rows16) * (KB >> 4);
     if (t >= total) return;
     const int per_kb = rows16 * 4;
     const int kb = static_cast<int>(t / per_kb), rem = static_cast<int>(t % per_kb);
-    const int rb = rem >> 6, r = (rem >> 2) & 15, pc = rem & 3;
-    const int row = rb * 16 + r, c = pc ^ ((r >> 2) & 3);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < R) v = *reinterpret_cast<const uint4*>(src + static_cast<size_t>(row) * KB + kb * 64 + c * 16);
-    reinterpret_cast<uint4*>(dst)[t] = v;
+    const int rb = rem >> 6;
+    int r, c;
+    if (fmt == MIXQ_FMT_F16X64) { c = (rem >> 4) & 3; r = rem & 15; }
+    else                        { r = (rem >> 2) & 15; c = (rem & 3) ^ ((r >> 2) & 3); }
+    const int row = rb * 16 + r;
+    const size_t plain = static_cast<size_t>(row) * KB + kb * 64 + c * 16;
+    if constexpr (UNPACK) {
+        if (row < R) *reinterpret_cast<uint4*>(dst + plain) = reinterpret_cast<const uint4*>(src)[t];
+    } else {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < R) v = *reinterpret_cast<const uint4*>(src + plain);
+        reinterpret_cast<uint4*>(dst)[t] = v;
+    }
+}
+
+// Launch geometry of the extract + scale + quantise pass: 0 = the round-1 kernel (256 threads, one row per workgroup), 1.. =
+// quant_rows2_kernel as (threads per row, rows per workgroup); -1 = choose by shape.  Tuning / test knob: mixq_quant_set_config.
+int g_quant_cfg = -1;
+constexpr int NUM_QUANT_CFGS = 8;
+
+template <int BIT, int TPR, int RPB>
+int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
+                       uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st)
+{
+    const int nchunk = K >> 3;
+    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + RPB * (TPR / 64)) * sizeof(uint32_t);
+    const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
+    dim3 g((M + RPB - 1) / RPB), b(TPR * RPB);
+#define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt)
+    if      (nchunk <= 1 * TPR)  MIXQ_QLAUNCH2(1);
+    else if (nchunk <= 2 * TPR)  MIXQ_QLAUNCH2(2);
+    else if (nchunk <= 4 * TPR)  MIXQ_QLAUNCH2(4);
+    else if (nchunk <= 8 * TPR)  MIXQ_QLAUNCH2(8);
+    else if (nchunk <= 16 * TPR) MIXQ_QLAUNCH2(16);
+    else return -100;                                     // the caller falls back to the any-K kernel
+#undef MIXQ_QLAUNCH2
+    return mixq_launch_status();
 }
 
 template <int BIT>
@@ -283,12 +394,33 @@ int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int
                       uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st)
 {
     const int nchunk = K >> 3;
+    int cfg = g_quant_cfg;
+    if (cfg < 0) {
+        // chosen on an MI355X (tools/time_quant.py, profiles/r02_quant_sweep.txt): rows of up to 8 K elements live in one or
+        // two waves; longer rows spread over 256 threads so the per-lane register file still holds the row
+        cfg = nchunk <= 8 * 64 ? 2 : (nchunk <= 8 * 128 ? 5 : 7);
+    }
+    int rc = -100;
+#define MIXQ_Q2(TPR, RPB) rc = launch_quant_rows2<BIT, TPR, RPB>(x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, qfmt, st)
+    switch (cfg) {
+        case 1: MIXQ_Q2(64, 1); break;
+        case 2: MIXQ_Q2(64, 2); break;
+        case 3: MIXQ_Q2(64, 4); break;
+        case 4: MIXQ_Q2(128, 1); break;
+        case 5: MIXQ_Q2(128, 2); break;
+        case 6: MIXQ_Q2(256, 1); break;
+        case 7: MIXQ_Q2(256, 2); break;
+        default: break;
+    }
+#undef MIXQ_Q2
+    if (rc != -100) return rc;
+    // round-1 kernel: also the any-K form (NCH == 0 re-reads the row)
     // column bitmask, 4 reduction floats, and (rows kept in registers) a copy of the row for the outlier gather
     const size_t shm = ((static_cast<size_t>((K + 31) >> 5) + 4 + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t)
                        + (nchunk <= 8 * QT ? static_cast<size_t>(K) * 2 : 0);
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g(M), b(QT);
-#define MIXQ_QLAUNCH(NCH) hipLaunchKernelGGL((quant_rows_kernel<BIT, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, K, thr_scale, rows16)
+#define MIXQ_QLAUNCH(NCH) hipLaunchKernelGGL((quant_rows_kernel<BIT, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, K, thr_scale, rows16, qfmt)
     if      (nchunk <= 2 * QT)  MIXQ_QLAUNCH(2);
     else if (nchunk <= 4 * QT)  MIXQ_QLAUNCH(4);
     else if (nchunk <= 8 * QT)  MIXQ_QLAUNCH(8);
@@ -334,8 +466,8 @@ extern "C" int mixq_selftest_quant_exact(unsigned long long* mismatches_dev, int
 extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q, int M, int K, int ldx, int bit, int qfmt,
                                    mixq_stream_t stream)
 {
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64) return MIXQ_EINVAL;
-    if (qfmt == MIXQ_FMT_P16X64 && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || (M > 0 && (!x || !x_scale || !q))) return MIXQ_EINVAL;   // empty inputs may carry null pointers
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
     if ((K & 7) || (ldx & 7) || ldx < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
@@ -349,8 +481,8 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
                                 uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt,
                                 mixq_stream_t stream)
 {
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64) return MIXQ_EINVAL;
-    if (qfmt == MIXQ_FMT_P16X64 && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !x_scale || !q))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
     if (n > 0 && (!ind || !x_out || ldo < n)) return MIXQ_EINVAL;
@@ -406,14 +538,40 @@ extern "C" int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col
     return mixq_launch_status();
 }
 
-extern "C" int mixq_pack_p16x64(const void* src, void* dst, int R, int KB, mixq_stream_t stream)
+static int repack_common(const void* src, void* dst, int R, int KB, int fmt, bool unpack, mixq_stream_t stream)
 {
     if (!src || !dst || R < 0 || KB <= 0) return MIXQ_EINVAL;
+    if (fmt != MIXQ_FMT_P16X64 && fmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
     if (KB % 64) return MIXQ_ESHAPE;
     if (R == 0) return MIXQ_OK;
     const int rows16 = (R + 15) & ~15;
     const long long total = static_cast<long long>(rows16) * (KB >> 4);
-    hipLaunchKernelGGL(pack_p16x64_kernel, dim3(static_cast<unsigned>((total + QT - 1) / QT)), dim3(QT), 0, mixq_stream(stream),
-                       static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), R, KB, rows16);
+    const dim3 g(static_cast<unsigned>((total + QT - 1) / QT));
+    if (unpack) hipLaunchKernelGGL(repack_kernel<true>, g, dim3(QT), 0, mixq_stream(stream), static_cast<const uint8_t*>(src),
+                                   static_cast<uint8_t*>(dst), R, KB, rows16, fmt);
+    else        hipLaunchKernelGGL(repack_kernel<false>, g, dim3(QT), 0, mixq_stream(stream), static_cast<const uint8_t*>(src),
+                                   static_cast<uint8_t*>(dst), R, KB, rows16, fmt);
     return mixq_launch_status();
+}
+
+extern "C" int mixq_pack_p16x64(const void* src, void* dst, int R, int KB, mixq_stream_t stream)
+{
+    return repack_common(src, dst, R, KB, MIXQ_FMT_P16X64, false, stream);
+}
+
+extern "C" int mixq_pack_operand(const void* src, void* dst, int R, int KB, int fmt, mixq_stream_t stream)
+{
+    return repack_common(src, dst, R, KB, fmt, false, stream);
+}
+
+extern "C" int mixq_unpack_operand(const void* src, void* dst, int R, int KB, int fmt, mixq_stream_t stream)
+{
+    return repack_common(src, dst, R, KB, fmt, true, stream);
+}
+
+extern "C" int mixq_quant_set_config(int cfg)
+{
+    if (cfg < -1 || cfg >= NUM_QUANT_CFGS) return MIXQ_EINVAL;
+    g_quant_cfg = cfg;
+    return MIXQ_OK;
 }

@@ -40,12 +40,22 @@ class FasterTransformerRMSNorm(nn.Module):
         if nl.bit not in (4, 8):
             raise NotImplementedError
         cache = self.cache
-        packed = hasattr(nl, "_packed_weight") and nl._packed_weight() is not None and hasattr(_backend, "PackP16x64")
-        ind = nl.ind if nl.ind.shape[0] else None
-        q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
-                                           sigma=getattr(cache, "sigma_value", 6.0), packed=packed)
-        cache.q_xcache, cache.q_xcache_packed = q, packed
-        cache.activation_outliers = xo
+        # the layout and the outlier bookkeeping (capacity-padded `ind`, device-resident count) are the NEXT layer's
+        fmt = nl.x_fmt() if (hasattr(nl, "x_fmt") and hasattr(_backend, "PackOperand")) else 0
+        n = int(nl.ind.shape[0])
+        if n and hasattr(nl, "_ind_dev") and hasattr(_backend, "PackOperand"):
+            ind, n_dev = nl._ind_dev()
+        else:
+            ind, n_dev = (nl.ind if n else None), None
+        if hasattr(_backend, "PackOperand"):
+            q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
+                                               sigma=getattr(cache, "sigma_value", 6.0), fmt=fmt, n_dev=n_dev)
+        else:                                                # host stand-in of the CPU tests
+            q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
+                                               sigma=getattr(cache, "sigma_value", 6.0))
+        cache.q_xcache = q
+        cache.activation_outliers = xo[:, :n] if n else None
+        cache.n_dev = n_dev
         return output
 
 

@@ -22,7 +22,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import mixlib as _hip_mixlib
-from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL
+from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64
 
 # The kernel backend.  Always the HIP module in the product; tests that exercise the host-side state machine on a
 # machine without a GPU swap in an oracle-backed stand-in (tests/backend_oracle.py) via `set_backend`.
@@ -34,6 +34,24 @@ def set_backend(mod):
     prev = _backend
     _backend = mod
     return prev
+
+
+# Packed layout new layers keep their weights in (and ask their activations in): MIXQ_FMT_F16X64 feeds the
+# weights-in-registers GEMM of gemm_wreg.hip, MIXQ_FMT_P16X64 the LDS-staged one of gemm.hip (include/mixq_hip.h).
+PACK_FMT = FMT_F16X64
+# After a layer's outlier search has frozen, keep ONLY the packed weight image in HBM (the plain [N,K] `q_weight` is
+# re-created on demand for state_dict / attribute reads).  False keeps both copies (2x the reference's weight memory).
+COMPACT_WEIGHTS = True
+
+
+def set_pack_fmt(fmt):
+    global PACK_FMT
+    prev, PACK_FMT = PACK_FMT, fmt
+    return prev
+
+
+def _fmt_of(t):
+    return getattr(t, "_mixq_fmt", FMT_PLAIN)
 
 
 def two_compl(x: Tensor, bits: int) -> Tensor:
@@ -143,10 +161,15 @@ class MixLinear_GEMM(nn.Module):
         self.arch = "gfx950"
         self.name = name
         self._wstore = None          # _ColStore behind weight_cache once outliers were appended online
-        self._wpk = None             # q_weight re-tiled to P16x64 (built once, on the first forward)
+        self._wpk = None             # q_weight re-tiled to PACK_FMT (built once, on the first forward)
         self._wpk_key = None
         self._wo_ready = None        # weight_cache in the GEMM tail's padded layout (built when it is not already)
         self._wo_key = None
+        self._ind_buf = None         # `ind` padded to a multiple of 16 entries: the capacity the kernels are given
+        self._ind_key = None
+        self._n_dev = None           # int32[1] on the device: the live outlier count (kernel.py:108-111 reads K this way)
+        self._n_dev_host = -1
+        self._silu_calls = 0
 
     # ------------------------------------------------------------------------------------------------------
     @classmethod
@@ -210,7 +233,7 @@ class MixLinear_GEMM(nn.Module):
         activation_outliers = _backend.ExtractOutliersAndSetToZeros(ind, inputs)
         weight_cache = _backend.DequantWeightCols(self.q_weight, self.scale_col, ind, self.bit)
         if self._wstore is None:
-            self._wstore = _ColStore(self.out_features, self.q_weight.device,
+            self._wstore = _ColStore(self.out_features, weight_cache.device,
                                      self.weight_cache if (self.weight_cache is not None and self.ind.shape[0]) else None)
         xs = _ColStore(inputs.shape[0], inputs.device,
                        cache.activation_outliers if (self.ind.shape[0] and cache.activation_outliers is not None) else None)
@@ -221,23 +244,91 @@ class MixLinear_GEMM(nn.Module):
         self.ind = torch.hstack((self.ind, ind))
         cache.ind = self.ind
 
+    # ---- weights: one packed image; the plain matrix only while the outlier search may still need its columns ----------
+    def __getattr__(self, name):
+        if name == "q_weight":
+            d = self.__dict__
+            bufs = d.get("_buffers")
+            if bufs is not None and "q_weight" in bufs and bufs["q_weight"] is None and d.get("_wpk") is not None:
+                return self._plain_weight()
+        return super().__getattr__(name)
+
+    def _plain_weight(self):
+        """The reference-layout q_weight re-created from the packed image (cold paths: state_dict, QKV fusion, new outlier
+        columns after compaction).  A fresh tensor every time: writes to it do not reach the layer - load_state_dict does."""
+        if self.weight_only:
+            raise RuntimeError("weight-only layers keep their plain q_weight")
+        return _backend.UnpackOperand(self._wpk, self.out_features)
+
+    def compact_weights_(self):
+        """Drop the plain [N,K] copy of q_weight, keeping only the packed image (half the weight memory of the first round)."""
+        if self.weight_only or self._buffers.get("q_weight") is None:
+            return self
+        if self._packed_weight() is not None:
+            self._buffers["q_weight"] = None
+        return self
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if "q_weight" in self._buffers and self._buffers["q_weight"] is None and self._wpk is not None:
+            destination[prefix + "q_weight"] = self._plain_weight()      # the reference's on-disk layout (base.py:78-119)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if "q_weight" in self._buffers and self._buffers["q_weight"] is None and prefix + "q_weight" in state_dict:
+            src = state_dict[prefix + "q_weight"]
+            self._buffers["q_weight"] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self._wpk.device)
+            self._wpk, self._wpk_key = None, None                        # re-packed on the next forward
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def x_fmt(self):
+        """Layout this layer wants its quantised activation in (what a fused norm in front of it should emit)."""
+        wpk = self._packed_weight()
+        return _fmt_of(wpk) if wpk is not None else FMT_PLAIN
+
     def _packed_weight(self):
-        """q_weight in the tile-major P16x64 layout the GEMM's DMA streams fastest (include/mixq_hip.h); rebuilt
-        when the buffer is replaced or rewritten (checkpoint load)."""
-        qw = self.q_weight
-        if qw.shape[1] % 64:
+        """q_weight in the tile-major layout the GEMM streams fastest (include/mixq_hip.h); rebuilt when the buffer is
+        replaced or rewritten (checkpoint load)."""
+        qw = self._buffers.get("q_weight")
+        if qw is None:
+            return self._wpk                                             # compacted: the packed image is all there is
+        if qw.shape[1] % 64 or not hasattr(_backend, "PackOperand"):
             return None
-        key = (qw.data_ptr(), qw._version)
+        key = (qw.data_ptr(), qw._version, PACK_FMT)
         if self._wpk is None or self._wpk_key != key:
-            self._wpk = _backend.PackP16x64(qw) if hasattr(_backend, "PackP16x64") else None
+            self._wpk = _backend.PackOperand(qw, PACK_FMT)
             self._wpk_key = key
         return self._wpk
 
+    # ---- outlier bookkeeping the kernels see: `ind` padded to a capacity, the live count in device memory ---------------
+    def _ind_dev(self):
+        """(ind buffer of capacity pad16(n), device count) for n = len(self.ind) > 0; (None, None) without outliers."""
+        n = int(self.ind.shape[0])
+        if n == 0:
+            return None, None
+        ind = self.ind
+        key = (ind.data_ptr(), ind._version, n)
+        if self._ind_buf is None or self._ind_key != key:
+            buf = torch.zeros((_pad16(n),), dtype=torch.int32, device=ind.device)
+            buf[:n] = ind
+            self._ind_buf, self._ind_key = buf, key
+        buf = self._ind_buf
+        if self._n_dev is None or self._n_dev.device != ind.device:
+            self._n_dev = torch.zeros((1,), dtype=torch.int32, device=ind.device)
+            self._n_dev_host = -1
+        if self._n_dev_host != n:
+            self._n_dev.fill_(n)                                         # a device-side write: no host sync
+            self._n_dev_host = n
+        return buf[:_pad16(n)], self._n_dev
+
     def _gemm(self, cache, M, act, addend=None):
         n = int(self.ind.shape[0])
-        xo = _gemm_ready(cache.activation_outliers) if n else None
-        wo = None
+        xo = wo = n_dev = None
+        cap = 0
         if n:
+            xo = cache.activation_outliers
+            if xo is None or xo.shape[1] != n:
+                raise RuntimeError("MixLinear_GEMM: outlier operands do not match `ind`")
+            xo = _gemm_ready(xo)
             # weight_cache is static between outlier appends: re-pad it (e.g. a [N,129] buffer loaded from a checkpoint)
             # once, not on every forward
             wc = self.weight_cache
@@ -245,12 +336,29 @@ class MixLinear_GEMM(nn.Module):
             if self._wo_key != key:
                 self._wo_ready, self._wo_key = _gemm_ready(wc), key
             wo = self._wo_ready
-        if n and (xo is None or wo is None or xo.shape[1] != n or wo.shape[1] != n):
-            raise RuntimeError("MixLinear_GEMM: outlier operands do not match `ind`")
+            if wo is None or wo.shape[1] != n:
+                raise RuntimeError("MixLinear_GEMM: outlier operands do not match `ind`")
+            # capacity = the padded width both operands really have; the count itself is read from device memory
+            cap = min(_pad16(n), xo.stride(0), wo.stride(0))
+            if getattr(cache, "n_dev", None) is not None and self._n_dev is cache.n_dev and cap > n:
+                n_dev, n_cap = self._n_dev, cap
+            else:
+                n_dev, n_cap = None, n
         wpk = self._packed_weight()
-        return _backend.FusedLinear(cache.q_xcache, wpk if wpk is not None else self.q_weight, cache.x_scale, self.scale_col,
-                                    xo, wo, n, self.bias, M, self.out_features, self.in_features, bit=self.bit, act=act, addend=addend,
-                                    x_packed=bool(getattr(cache, "q_xcache_packed", False)), w_packed=wpk is not None)
+        qx = cache.q_xcache
+        w = wpk if wpk is not None else self.q_weight
+        want = _fmt_of(w)
+        if _fmt_of(qx) != want and hasattr(_backend, "PackOperand"):
+            # the producer of q_xcache (e.g. the reference's own fused norm through the mixlib shim) used another layout
+            if _fmt_of(qx) != FMT_PLAIN:
+                qx = _backend.UnpackOperand(qx, M)
+            if want != FMT_PLAIN:
+                qx = _backend.PackOperand(qx[:M].contiguous(), want)
+        if n:
+            return _backend.FusedLinear(qx, w, cache.x_scale, self.scale_col, _wide(xo, n_cap), _wide(wo, n_cap), n_cap, self.bias, M, self.out_features, self.in_features, bit=self.bit,
+                                        act=act, addend=addend, n_out_dev=n_dev)
+        return _backend.FusedLinear(qx, w, cache.x_scale, self.scale_col, None, None, 0, self.bias, M, self.out_features,
+                                    self.in_features, bit=self.bit, act=act, addend=addend)
 
     # ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -276,12 +384,19 @@ class MixLinear_GEMM(nn.Module):
             if self.add_outliers:
                 flag = cache.flag
                 flag.zero_()
-            packed = self._packed_weight() is not None
-            cache.q_xcache, xo = _backend.QuantFused(inputs, self.ind if n else None, cache.x_scale, self.bit, self._sigma_f,
-                                                     flag=flag, packed=packed)
-            cache.q_xcache_packed = packed
+            fmt = self.x_fmt()
+            ind_buf, n_dev = self._ind_dev()
+            if hasattr(_backend, "PackOperand"):
+                cache.q_xcache, xo = _backend.QuantFused(inputs, ind_buf, cache.x_scale, self.bit, self._sigma_f, flag=flag,
+                                                         n_dev=n_dev, fmt=fmt)
+            else:                                            # host stand-in used by the CPU tests (no packed layouts)
+                cache.q_xcache, xo = _backend.QuantFused(inputs, self.ind if n else None, cache.x_scale, self.bit, self._sigma_f,
+                                                         flag=flag)
             if n:
-                cache.activation_outliers = xo
+                cache.activation_outliers = xo[:, :n]
+            cache.n_dev = n_dev
+        elif getattr(cache, "n_dev", None) is not self._n_dev:
+            cache.n_dev = None                               # whoever filled the cache did not use this layer's device count
         cache.ind = self.ind
 
         if self.add_outliers:
@@ -293,24 +408,27 @@ class MixLinear_GEMM(nn.Module):
                 ind = self.FindOutliers(inputs)
                 cache.new_ind = ind
                 self._append_outliers(cache, inputs, ind)
-                if self._packed_weight() is not None:
-                    cache.q_xcache = _backend.FindRowScalePacked(inputs, cache.x_scale, M, self.in_features, self.bit)
-                    cache.q_xcache_packed = True
+                fmt = self.x_fmt()
+                if fmt != FMT_PLAIN:
+                    cache.q_xcache = _backend.FindRowScalePacked(inputs, cache.x_scale, M, self.in_features, self.bit, fmt=fmt)
                 else:
                     cache.q_xcache = _backend.FindRowScale(inputs, cache.x_scale, M, self.in_features, self.bit)
-                    cache.q_xcache_packed = False
+                cache.n_dev = None
             self.cnt += 1
             if self.cnt >= self.cache.stop or self.ind.shape[0] > 128:
                 self.add_outliers = False
 
         y1 = self._gemm(cache, M, ACT_NONE)
+        if COMPACT_WEIGHTS and not self.add_outliers:
+            self.compact_weights_()
         return y1.reshape(cache.shape)
 
     @torch.no_grad()
     def forward_without_preconditionFusedSilu(self, x, cache, mul=None):
         """gate_proj path (linear.py:292-376): reuse the activation quantised for up_proj, SiLU in the epilogue.
-        `mul` (an extension): an fp16 [..., N] tensor multiplied in after the SiLU, i.e. silu(gate(x)) * up(x) leaves the GEMM
-        directly and the `gate_output *= up_output` pass of modules/fused/mlp.py:61-63 disappears."""
+        `mul` (an extension): an fp16 [..., N] tensor multiplied in after the SiLU and the bias, i.e.
+        (silu(gate(x)) + bias) * up(x) leaves the GEMM directly and the `gate_output *= up_output` pass of
+        modules/fused/mlp.py:61-63 disappears."""
         inputs = x.reshape(-1, x.shape[-1])
         M = inputs.shape[0]
         if not self.forward_without_precondition_len == cache.ind.shape[0]:
@@ -318,19 +436,31 @@ class MixLinear_GEMM(nn.Module):
                 ind = cache.new_ind
                 weight_cache = _backend.DequantWeightCols(self.q_weight, self.scale_col, ind, self.bit)
                 if self._wstore is None:
-                    self._wstore = _ColStore(self.out_features, self.q_weight.device,
+                    self._wstore = _ColStore(self.out_features, weight_cache.device,
                                              self.weight_cache if (self.weight_cache is not None and self.ind.shape[0]) else None)
                 self._wstore.append(weight_cache)
                 self.weight_cache = self._wstore.view() if self._wstore.n else weight_cache
                 self.ind = cache.ind
                 self.forward_without_precondition_len = self.ind.shape[0]
+                self._silu_calls = 0
         if self.bit == 4 and not self.ind.shape[0]:
             raise RuntimeError("int4 mod should have outliers !")
+        if getattr(cache, "n_dev", None) is not None:
+            self._n_dev = cache.n_dev                        # the count of the layer whose activation this one shares
         if mul is not None:
             y1 = self._gemm(cache, M, ACT_SILU_MUL, addend=mul.reshape(-1, self.out_features))
         else:
             y1 = self._gemm(cache, M, ACT_SILU)
+        self._silu_calls += 1
+        if COMPACT_WEIGHTS and self._silu_calls >= self.cache.stop:
+            self.compact_weights_()
         return y1.reshape(cache.shape)
+
+
+def _wide(t, cap):
+    """View of the first `cap` columns of the storage behind a [R,n] matrix whose row stride is >= cap (the pad may hold
+    anything: the kernels mask columns beyond the device-resident count)."""
+    return t.as_strided((t.shape[0], cap), (t.stride(0), 1), t.storage_offset())
 
 
 # north_star name for the same operator

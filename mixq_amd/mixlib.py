@@ -15,7 +15,8 @@ from __future__ import annotations
 import torch
 
 from . import _capi
-from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, X_PACKED, W_PACKED
+from ._capi import (ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, X_PACKED, W_PACKED, X_F16X64,
+                    W_F16X64)
 
 
 def _dev_check(*ts):
@@ -42,8 +43,32 @@ def _rows(t, what):
 
 
 def _is_zero_addend(addend):
-    """The reference passes MixLibCache.zeros (all zero, row stride 36864 != N) when there are no outliers."""
-    return addend is None or getattr(addend, "_mixq_all_zero", False) or (addend.dim() == 2 and addend.stride(0) == 0)
+    """The reference passes MixLibCache.zeros (all zero, row stride 36864 != N) when there are no outliers.  Recognised by
+    identity only (the `_mixq_all_zero` tag MixLibCache puts on it): a caller's own stride-0 broadcast addend is real data
+    and goes to the kernel with lda = 0."""
+    return addend is None or getattr(addend, "_mixq_all_zero", False)
+
+
+def _check_ind(ind, what):
+    if ind.dtype != torch.int32:
+        raise RuntimeError(f"{what}: `ind` must be int32 (got {ind.dtype})")
+    return ind if ind.is_contiguous() else ind.contiguous()
+
+
+# ---- storage format of a quantised operand travels WITH the tensor -------------------------------------------------
+# (a separate flag on the shared MixLibCache would describe whatever layer wrote it last, not the tensor handed over)
+def set_fmt(t, fmt):
+    t._mixq_fmt = fmt
+    return t
+
+
+def fmt_of(t):
+    return getattr(t, "_mixq_fmt", FMT_PLAIN)
+
+
+def _layout_bits(x_fmt, w_fmt):
+    return ({FMT_PLAIN: 0, FMT_P16X64: X_PACKED, FMT_F16X64: X_F16X64}[x_fmt] |
+            {FMT_PLAIN: 0, FMT_P16X64: W_PACKED, FMT_F16X64: W_F16X64}[w_fmt])
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -71,14 +96,15 @@ def FindRowScale(x, x_scale, M, K, bit=8):
 def ExtractOutliersAndSetToZeros(ind, x):
     """mixlib.ExtractOutliersAndSetToZeros(ind, x) -> x_out [M,n]; zeroes columns `ind` of x IN PLACE (linear.py:189,205)."""
     _dev_check(ind, x)
-    if x.dtype != torch.float16 or ind.dtype != torch.int32:
-        raise RuntimeError("ExtractOutliersAndSetToZeros: x must be float16 and ind int32")
+    if x.dtype != torch.float16:
+        raise RuntimeError("ExtractOutliersAndSetToZeros: x must be float16")
+    ind = _check_ind(ind, "ExtractOutliersAndSetToZeros")
     xp, ldx = _rows(x, "x")
     M, K = x.shape
     n = ind.numel()
     out = torch.empty((M, n), dtype=torch.float16, device=x.device)
     if n:
-        _capi.call("mixq_extract_outliers_zero", xp, ind.contiguous().data_ptr(), n, out.data_ptr(), M, K, ldx, n, _stream())
+        _capi.call("mixq_extract_outliers_zero", xp, ind.data_ptr(), n, out.data_ptr(), M, K, ldx, n, _stream())
     return out
 
 
@@ -92,7 +118,8 @@ def _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, bit, act):
         ap, lda = _rows(addend, "addend")
     fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"
     _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(),
-               None, 0, None, 0, 0, None, ap, lda, None, y.data_ptr(), N, M, N, K, act, 0, _stream())
+               None, 0, None, 0, 0, None, ap, lda, None, y.data_ptr(), N, M, N, K, act, _layout_bits(fmt_of(q_x), fmt_of(q_w)),
+               _stream())
     return y
 
 
@@ -116,9 +143,84 @@ def int4FusedDequantizeSilu(q_x, q_w, x_scale, scale_col, addend, M, N, K_half):
     return _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, 2 * K_half, 4, ACT_SILU)
 
 
+_META_FUNCS = None
+
+
+def _meta_funcs():
+    """torch functions that only read metadata of a tensor: they do not force a pending product to be computed."""
+    global _META_FUNCS
+    if _META_FUNCS is None:
+        T = torch.Tensor
+        fs = {T.size, T.dim, T.numel, T.stride, T.element_size, T.is_contiguous, T.nelement, T.ndimension, T.storage_offset,
+              T.is_floating_point, T.is_complex, T.get_device, T.__len__}
+        for prop in ("shape", "dtype", "device", "ndim", "is_cuda", "layout", "requires_grad", "grad_fn", "is_leaf", "is_sparse",
+                     "is_quantized", "is_meta", "names"):
+            fs.add(getattr(T, prop).__get__)
+        _META_FUNCS = fs
+    return _META_FUNCS
+
+
+class PendingGemmI32(torch.Tensor):
+    """The int32 [M,N] tensor `mixlib.gemm` returns, with the product itself deferred.
+
+    On gfx950 torch reports capability major 9, so the UNCHANGED reference takes its `arch == 9` branch
+    (linear.py:86,234-241,320-327): `y = mixlib.gemm(...)` followed by `mixlib.dequantizeInt8[Silu](y, x_scale, scale_col,
+    addend, 8, M, N)`.  Run literally, that is a 4*M*N-byte int32 round trip through HBM plus a second kernel.  Here `gemm`
+    only allocates the result and remembers its operands; `dequantizeInt8[Silu]` recognises the handle and launches the ONE
+    fused kernel (same arithmetic: exact int32 accumulator, fp32 epilogue, one rounding).  Any other use of the tensor - any
+    torch function that is not a pure metadata query - first computes the int32 product into its storage, so code that
+    really wants the integers gets them."""
+
+    @staticmethod
+    def __new__(cls, q_x, q_w, M, N, K):
+        t = torch.Tensor._make_subclass(cls, torch.empty((M, N), dtype=torch.int32, device=q_x.device))
+        t._mixq_args = (q_x, q_w, M, N, K)
+        t._mixq_done = False
+        return t
+
+    def _materialize(self):
+        if getattr(self, "_mixq_done", True):
+            return
+        self._mixq_done = True
+        with torch._C.DisableTorchFunctionSubclass():
+            q_x, q_w, M, N, K = self._mixq_args
+            _capi.call("mixq_gemm_i8", q_x.data_ptr(), q_w.data_ptr(), self.data_ptr(), N, M, N, K, _stream())
+        self._mixq_args = None
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func not in _meta_funcs():
+            for a in list(args) + list(kwargs.values()):
+                if isinstance(a, PendingGemmI32):
+                    a._materialize()
+                elif isinstance(a, (list, tuple)):
+                    for b in a:
+                        if isinstance(b, PendingGemmI32):
+                            b._materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+_lazy_gemm = True
+
+
+def set_lazy_gemm(enabled):
+    """False: `gemm` computes its int32 result at once (the literal unfused pair); True (default): deferred, see PendingGemmI32."""
+    global _lazy_gemm
+    prev, _lazy_gemm = _lazy_gemm, bool(enabled)
+    return prev
+
+
 def gemm(q_x, q_w, M, N, K):
-    """mixlib.gemm(q_x, q_w, M, N, K) -> int32 [M,N] (linear.py:235)."""
+    """mixlib.gemm(q_x, q_w, M, N, K) -> int32 [M,N] (linear.py:235,321)."""
     _dev_check(q_x, q_w)
+    if fmt_of(q_x) != FMT_PLAIN or fmt_of(q_w) != FMT_PLAIN:
+        raise RuntimeError("mixlib.gemm: the raw int32 GEMM takes plain row-major operands")
+    if K % 64 or N % 4:
+        raise _capi.MixqError("mixq_gemm_i8", _capi.MIXQ_ESHAPE)
+    if _lazy_gemm and M > 0 and N > 0:
+        return PendingGemmI32(q_x, q_w, M, N, K)
     y = torch.empty((M, N), dtype=torch.int32, device=q_x.device)
     _capi.call("mixq_gemm_i8", q_x.data_ptr(), q_w.data_ptr(), y.data_ptr(), N, M, N, K, _stream())
     return y
@@ -126,6 +228,9 @@ def gemm(q_x, q_w, M, N, K):
 
 def _dequant(y32, x_scale, scale_col, addend, bit, M, N, act):
     _dev_check(y32, x_scale, scale_col)
+    if isinstance(y32, PendingGemmI32) and not y32._mixq_done and tuple(y32._mixq_args[2:4]) == (M, N):
+        q_x, q_w, _, _, K = y32._mixq_args                  # the product was never needed on its own: one fused kernel
+        return _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, 8, act)
     y = torch.empty((M, N), dtype=torch.float16, device=y32.device)
     if _is_zero_addend(addend):
         ap, lda = None, 0
@@ -150,12 +255,14 @@ def dequantizeInt8Silu(y32, x_scale, scale_col, addend, bit, M, N):
 def unpack_int4_to_fp16(q_w, ind):
     """mixlib.unpack_int4_to_fp16(q_w, ind) -> fp16 [N,n] sign-extended int4 weight columns (linear.py:20-22)."""
     _dev_check(q_w, ind)
+    ind = _check_ind(ind, "unpack_int4_to_fp16")
+    if not q_w.is_contiguous():
+        raise RuntimeError("unpack_int4_to_fp16: q_w must be contiguous")
     N, Kh = q_w.shape
     n = ind.numel()
     out = torch.empty((N, n), dtype=torch.float16, device=q_w.device)
     if n:
-        _capi.call("mixq_dequant_weight_cols", q_w.data_ptr(), None, ind.contiguous().data_ptr(), n, out.data_ptr(), N,
-                   2 * Kh, n, 4, _stream())
+        _capi.call("mixq_dequant_weight_cols", q_w.data_ptr(), None, ind.data_ptr(), n, out.data_ptr(), N, 2 * Kh, n, 4, _stream())
     return out
 
 
@@ -166,31 +273,58 @@ def packed_rows(rows):
     return (rows + 15) // 16 * 16
 
 
-def PackP16x64(q):
-    """Re-tile a plain [R,KB] int8/uint8 operand into the P16x64 tile-major layout (include/mixq_hip.h).  Returns a
-    [roundup(R,16), KB] tensor of the same dtype holding the packed bytes (NOT addressable as a matrix)."""
+def PackOperand(q, fmt=FMT_P16X64):
+    """Re-tile a plain [R,KB] int8/uint8 operand into a packed layout (include/mixq_hip.h).  Returns a [roundup(R,16), KB]
+    tensor of the same dtype holding the packed bytes (NOT addressable as a matrix), tagged with its format."""
     _dev_check(q)
     if q.dim() != 2 or not q.is_contiguous() or q.element_size() != 1:
-        raise RuntimeError("PackP16x64: expected a contiguous 2-D int8/uint8 tensor")
+        raise RuntimeError("PackOperand: expected a contiguous 2-D int8/uint8 tensor")
     R, KB = q.shape
     out = torch.empty((packed_rows(R), KB), dtype=q.dtype, device=q.device)
-    _capi.call("mixq_pack_p16x64", q.data_ptr(), out.data_ptr(), R, KB, _stream())
+    _capi.call("mixq_pack_operand", q.data_ptr(), out.data_ptr(), R, KB, fmt, _stream())
+    return set_fmt(out, fmt)
+
+
+def PackP16x64(q):
+    return PackOperand(q, FMT_P16X64)
+
+
+def UnpackOperand(packed, R, fmt=None):
+    """Inverse of PackOperand: the plain [R,KB] matrix of a packed image."""
+    _dev_check(packed)
+    fmt = fmt_of(packed) if fmt is None else fmt
+    if fmt not in (FMT_P16X64, FMT_F16X64):
+        raise RuntimeError("UnpackOperand: the tensor carries no packed-format tag; pass fmt")
+    KB = packed.shape[1]
+    out = torch.empty((R, KB), dtype=packed.dtype, device=packed.device)
+    _capi.call("mixq_unpack_operand", packed.data_ptr(), out.data_ptr(), R, KB, fmt, _stream())
     return out
 
 
-def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, packed=False):
+def _want_fmt(packed, fmt):
+    if fmt is not None:
+        return fmt
+    return FMT_P16X64 if packed else FMT_PLAIN
+
+
+def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, packed=False, fmt=None):
     """(i)+(ii) in one pass over X: extract/zero the known outlier columns `ind`, per-row scale into x_scale[0:M],
-    quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n]).  With packed=True q_x is
-    emitted directly in the P16x64 layout ([roundup(M,16), KB] bytes)."""
+    quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n]).  With fmt = FMT_P16X64 /
+    FMT_F16X64 (or packed=True: P16x64) q_x is emitted directly in that layout ([roundup(M,16), KB] bytes) and tagged.
+    `n_dev` (device int32[1]) overrides the count: `ind` then is a buffer of capacity ind.numel()."""
     _dev_check(x, x_scale, ind)
+    fmt = _want_fmt(packed, fmt)
     xp, ldx = _rows(x, "x")
     M, K = x.shape
+    if x.dtype != torch.float16:
+        raise RuntimeError("QuantFused: x must be float16")
     if x_scale.numel() < M:
         raise RuntimeError(f"QuantFused: x_scale holds {x_scale.numel()} rows, the batch has {M} (MixLibCache.inputdim too small)")
     n = 0 if ind is None else ind.numel()
-    q = torch.empty((packed_rows(M) if packed else M, K if bit == 8 else K // 2),
+    q = torch.empty((packed_rows(M) if fmt else M, K if bit == 8 else K // 2),
                     dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
     if n:
+        ind = _check_ind(ind, "QuantFused")
         if x_out is None:
             ldo = (n + 15) // 16 * 16
             x_out = torch.empty((M, ldo), dtype=torch.float16, device=x.device)
@@ -199,19 +333,19 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
     else:
         op, ldo, ip = None, 0, None
     _capi.call("mixq_quant_fused", xp, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K, ldx,
-               ldo, bit, float(sigma), FMT_P16X64 if packed else FMT_PLAIN, _stream())
-    return q, (x_out[:, :n] if n else None)
+               ldo, bit, float(sigma), fmt, _stream())
+    return set_fmt(q, fmt), (x_out[:, :n] if n else None)
 
 
-def FindRowScalePacked(x, x_scale, M, K, bit=8):
-    """FindRowScale emitting the P16x64 layout."""
+def FindRowScalePacked(x, x_scale, M, K, bit=8, fmt=FMT_P16X64):
+    """FindRowScale emitting a packed layout."""
     _dev_check(x, x_scale)
     xp, ldx = _rows(x, "x")
     if x_scale.numel() < M:
         raise RuntimeError(f"FindRowScalePacked: x_scale holds {x_scale.numel()} rows, the batch has {M}")
     q = torch.empty((packed_rows(M), K if bit == 8 else K // 2), dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
-    _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, FMT_P16X64, _stream())
-    return q
+    _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, fmt, _stream())
+    return set_fmt(q, fmt)
 
 
 def DetectOutlierCols(x, sigma, scratch=None):
@@ -233,6 +367,9 @@ def DetectOutlierCols(x, sigma, scratch=None):
 def DequantWeightCols(q_w, scale_col, ind, bit, out=None):
     """`q_weight[:,ind].to(fp16) * scale_col.T` (linear.py:207) / the int4 twin (linear.py:209-210) as one kernel."""
     _dev_check(q_w, scale_col, ind)
+    ind = _check_ind(ind, "DequantWeightCols")
+    if fmt_of(q_w) != FMT_PLAIN or q_w.dim() != 2 or not q_w.is_contiguous():
+        raise RuntimeError("DequantWeightCols: q_w must be the plain, contiguous [N,KB] matrix")
     N = q_w.shape[0]
     K = q_w.shape[1] * (1 if bit == 8 else 2)
     n = ind.numel()
@@ -240,17 +377,21 @@ def DequantWeightCols(q_w, scale_col, ind, bit, out=None):
         out = torch.empty((N, n), dtype=torch.float16, device=q_w.device)
     op, ldo = _rows(out, "out")
     if n:
-        _capi.call("mixq_dequant_weight_cols", q_w.data_ptr(), scale_col.data_ptr(), ind.contiguous().data_ptr(), n, op, N, K,
-                   ldo, bit, _stream())
+        _capi.call("mixq_dequant_weight_cols", q_w.data_ptr(), scale_col.data_ptr(), ind.data_ptr(), n, op, N, K, ldo, bit, _stream())
     return out
 
 
 def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K, bit=8, act=ACT_NONE, n_out_dev=None,
-                addend=None, out=None, x_packed=False, w_packed=False):
-    """(iii)+(iv): int8/int4 MFMA GEMM + dequant + fp16 outlier correction + addend + act + bias -> fp16 [M,N]."""
+                addend=None, out=None, x_packed=None, w_packed=None):
+    """(iii)+(iv): int8/int4 MFMA GEMM + dequant + fp16 outlier correction + addend + act + bias -> fp16 [M,N].
+    The operand layouts come from the tensors' own format tags (set_fmt / the packing and quantising functions above);
+    x_packed / w_packed = True/False force P16x64 / plain for untagged buffers.  `n_out_dev` (device int32[1]) overrides the
+    outlier count: n_out then is the capacity of x_out / w_out (columns >= the device count are ignored, whatever they hold)."""
     _dev_check(q_x, q_w, x_scale, scale_col)
     if x_scale.numel() < M or scale_col.numel() < N:
         raise RuntimeError("FusedLinear: x_scale / scale_col are shorter than M / N")
+    x_fmt = fmt_of(q_x) if x_packed is None else (FMT_P16X64 if x_packed else FMT_PLAIN)
+    w_fmt = fmt_of(q_w) if w_packed is None else (FMT_P16X64 if w_packed else FMT_PLAIN)
     y = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=q_x.device)
     if n_out and x_out is not None and w_out is not None:
         xop, ldxo = _rows(x_out, "x_out")
@@ -267,11 +408,11 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
     elif _is_zero_addend(addend):
         ap, lda = None, 0
     else:
+        _dev_check(addend)
         ap, lda = _rows(addend, "addend")
     fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"
     _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(), xop, ldxo, wop, ldwo, n_out,
-               _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act,
-               (X_PACKED if x_packed else 0) | (W_PACKED if w_packed else 0), _stream())
+               _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act, _layout_bits(x_fmt, w_fmt), _stream())
     return y
 
 
@@ -289,9 +430,11 @@ def layernorm_forward_cuda(x, weight, out, eps):
     return out
 
 
-def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=None, packed=False):
-    """RMSNorm fused with the next linear's extract + zero + scale + quantise.  Returns (q_x, x_out_view[M,n])."""
+def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=None, packed=False, fmt=None, n_dev=None):
+    """RMSNorm fused with the next linear's extract + zero + scale + quantise.  Returns (q_x, x_out_view[M,n]); q_x carries
+    its format tag."""
     _dev_check(x, weight, out, x_scale, ind)
+    fmt = _want_fmt(packed, fmt)
     K = x.shape[-1]
     x2, o2 = x.reshape(-1, K), out.reshape(-1, K)
     xp, ldx = _rows(x2, "x")
@@ -300,16 +443,17 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
     if x_scale.numel() < M:
         raise RuntimeError(f"RMSNormQuantFused: x_scale holds {x_scale.numel()} rows, the batch has {M}")
     n = 0 if ind is None else ind.numel()
-    q = torch.empty((packed_rows(M) if packed else M, K if bit == 8 else K // 2),
+    q = torch.empty((packed_rows(M) if fmt else M, K if bit == 8 else K // 2),
                     dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
     if n:
+        ind = _check_ind(ind, "RMSNormQuantFused")
         x_out = torch.empty((M, (n + 15) // 16 * 16), dtype=torch.float16, device=x.device)
         xop, ldxo, ip = x_out.data_ptr(), x_out.stride(0), ind.data_ptr()
     else:
         x_out, xop, ldxo, ip = None, None, 0, None
-    _capi.call("mixq_rmsnorm_quant_fused", xp, weight.data_ptr(), op, ip, n, None, x_scale.data_ptr(), q.data_ptr(), xop,
-               _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), FMT_P16X64 if packed else FMT_PLAIN, _stream())
-    return q, (x_out[:, :n] if n else None)
+    _capi.call("mixq_rmsnorm_quant_fused", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), xop,
+               _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), fmt, _stream())
+    return set_fmt(q, fmt), (x_out[:, :n] if n else None)
 
 
 def layernorm_forward_cuda_extract_outliers(x, weight, out, eps, ind, x_scale):

@@ -257,12 +257,16 @@ void orc_linear_fused(const void* qx, const void* qw, const uint16_t* sx, const 
             float o = 0.f;
             for (int j = 0; j < n_out; ++j) o += h2f(xo[(size_t)m * ldxo + j]) * h2f(wo[(size_t)n * ldwo + j]);
             v += o;
-            if (act == 2) v = silu_f(v) * h2f(addend[(size_t)m * lda + n]);   /* MIXQ_ACT_SILU_MUL: addend is the multiplier */
-            else {
+            if (act == 2) {   /* MIXQ_ACT_SILU_MUL: (silu(z) + bias) * multiplier - the bias lands BEFORE the product, as in
+                               * linear.py:372-373 (`y1 += self.bias`) followed by mlp.py:61 (`gate_output *= up_output`) */
+                v = silu_f(v);
+                if (bias) v += h2f(bias[n]);
+                v *= h2f(addend[(size_t)m * lda + n]);
+            } else {
                 if (addend) v += h2f(addend[(size_t)m * lda + n]);
                 if (act == 1) v = silu_f(v);
+                if (bias) v += h2f(bias[n]);
             }
-            if (bias) v += h2f(bias[n]);
             y[(size_t)m * ldy + n] = f2h(v);
         }
         free(arow);
