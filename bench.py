@@ -8,15 +8,22 @@ step    : ONE full forward of MixLinear_GEMM over one 512-token batch already re
           (i)+(ii) fused extract/zero/absmax/quantise kernel  +  (iii)+(iv) int8 MFMA GEMM with fused dequant,
           fp16 outlier tail and (absent for Llama) bias.  Each step gets its own pristine activation buffer (the
           operator zeroes outlier columns in place, as the reference does), so no restore copy sits in the timed region.
-N GPUs  : weak scaling, one process per GPU, every rank runs the same K steps on its own batches; no data-path
-          collective, one RCCL all_gather of {elapsed, flops} at the end.  value = sum of FLOPs over ranks / max time.
+timing  : the K steps are ONE hipGraph; barrier + synchronize on both sides of the timed region; the clock is a pair of HIP
+          events on the launch stream (the host wall time around the same region is reported beside it); MAX over ranks.
+N GPUs  : one process per GPU, no data-path collective, one all_gather of {elapsed, flops} at the end.
+          --scaling weak (default): every rank runs the same K steps on its own 512-token batches;
+          --scaling strong: the 512 rows are split over the ranks (bench.shard_rows), weights replicated.
+          value = sum of FLOPs over ranks / max time.  `python bench.py --gpus N` launches its N ranks itself; under
+          `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it uses the ranks it was given.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W]     (N > 1: launched by torch.distributed.run)
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--shape K,N] [--batch M]
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,15 +38,20 @@ OUTLIER_FRAC = 0.01
 SIGMA = 6
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--shape", default=None, help="K,N of the Linear (default 4096,11008); e.g. 8192,28672 for BASELINE config 3")
+    ap.add_argument("--batch", type=int, default=None, help="token rows M (default 512)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: exercise the launch / rendezvous / gather path with synthetic per-rank timings (CPU, gloo)")
+    return ap.parse_args(argv)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -47,6 +59,31 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------
 def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, LOCAL_RANK -> device), rendezvous
+    on 127.0.0.1, pass rank 0's JSON line through, fail if any rank fails."""
+    port = free_port()
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MIXQ_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
 
 
 def init_dist(n_gpus, backend):
@@ -71,95 +108,142 @@ def barrier(world, device=None):
             dist.barrier()
 
 
-def gather_counters(elapsed_s, flops, world, device):
-    """All ranks contribute {elapsed seconds, FLOPs}; returns (max elapsed, total FLOPs).  The only collective of the
-    whole job (a few floats over xGMI); the data path itself shards by batch and exchanges nothing."""
+def gather_counters(elapsed_s, flops, world, device, per_rank=False):
+    """All ranks contribute {elapsed seconds, FLOPs}; returns (max elapsed, total FLOPs[, per-rank elapsed list]).  The only
+    collective of the whole job (a few floats over xGMI); the data path itself shards by batch and exchanges nothing."""
     if world == 1:
-        return elapsed_s, flops
+        return (elapsed_s, flops, [elapsed_s]) if per_rank else (elapsed_s, flops)
     import torch.distributed as dist
     mine = torch.tensor([elapsed_s, flops], dtype=torch.float64, device=device)
     allv = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine)
     allv = torch.stack(allv).cpu()
-    return float(allv[:, 0].max()), float(allv[:, 1].sum())
+    out = (float(allv[:, 0].max()), float(allv[:, 1].sum()))
+    return out + ([float(v) for v in allv[:, 0]],) if per_rank else out
 
 
 def shard_rows(total_rows, world, rank):
-    """Row range of `rank` when a fixed global batch is split (strong scaling helper; rows are independent)."""
+    """Row range of `rank` when a fixed global batch is split (strong scaling; token rows are independent)."""
     base, rem = divmod(total_rows, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rank_rows(total_rows, world, rank, scaling):
+    return shard_rows(total_rows, world, rank) if scaling == "strong" else (0, total_rows)
+
+
 # ---------------------------------------------------------------------------------------------------------------
-def build_layer(device, seed=0):
+def build_layer(device, rows, seed=0):
     from mixq_amd import MixLibCache, MixLinear_GEMM
     torch.manual_seed(seed)
     lin = torch.nn.Linear(K, N, bias=False).half()            # nn.Linear default init, as examples/benchbitsand.py:519
-    cache = MixLibCache(M, sigma=SIGMA, bit=8, device=device)
+    cache = MixLibCache(rows, sigma=SIGMA, bit=8, device=device)
     layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=device, name="up_proj")
     return lin, cache, layer
 
 
-def make_batches(count, device, rank):
+def make_batches(count, rows, device, rank):
     g = torch.Generator().manual_seed(1)
     cols = torch.randperm(K, generator=g)[: round(OUTLIER_FRAC * K)]
     gx = torch.Generator().manual_seed(100 + rank)
-    base = torch.randn(M, K, generator=gx).half()
+    base = torch.randn(rows, K, generator=gx).half()
     base[:, cols] *= 20
     base = base.to(device)
-    pristine = base.unsqueeze(0).repeat(count, 1, 1).contiguous()      # [count, M, K], one buffer per step
+    budget = 6 << 30                                                      # bytes of pristine inputs kept resident
+    count = max(1, min(count, budget // max(1, base.numel() * 2)))
+    pristine = base.unsqueeze(0).repeat(count, 1, 1).contiguous()        # [count, rows, K], one buffer per step (cycled if fewer)
     return cols, base, pristine
 
 
-def cpu_baseline():
-    """The reference's CPU path for this metric (BASELINE.json config 0 / north_star): fp16 torch.nn.Linear on the
-    host cores of this box, same shape, same init; bounded to ~10 s."""
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+def cpu_baseline(rows):
+    """The reference's CPU path for this metric (BASELINE.json config 0 / north_star): fp16 torch.nn.Linear on the host cores
+    of this box, same shape, same init.  The thread count is swept (all logical CPUs oversubscribe the fp16 GEMM badly on
+    SMT hosts) and the best is reported with its count; bounded to ~25 s in total."""
+    logical = os.cpu_count() or 1
     torch.manual_seed(0)
     lin = torch.nn.Linear(K, N, bias=False).half()
-    x = torch.randn(M, K).half()
+    x = torch.randn(rows, K).half()
+    cands = sorted({c for c in (logical, logical // 2, logical // 4, 32, 16, 8) if 1 <= c <= logical}, reverse=True)
+    results = {}
     with torch.no_grad():
-        for _ in range(2):
-            lin(x)
-        iters, t0 = 0, time.perf_counter()
-        while iters < 200 and (iters < 5 or time.perf_counter() - t0 < 10.0):
-            lin(x)
-            iters += 1
-        dt = time.perf_counter() - t0
-    tflops = 2.0 * M * N * K * iters / dt / 1e12
-    return {"value": round(tflops, 4), "unit": "TFLOPS", "cores": cores, "kind": "reference",
-            "sample": f"torch.nn.Linear({K},{N}).half() on CPU, M={M}, {iters} forwards after 2 warm-ups, {dt:.1f} s, "
-                      f"{torch.get_num_threads()} threads"}
+        for c in cands:
+            torch.set_num_threads(c)
+            for _ in range(2):
+                lin(x)
+            iters, t0 = 0, time.perf_counter()
+            while iters < 50 and (iters < 3 or time.perf_counter() - t0 < 3.0):
+                lin(x)
+                iters += 1
+            results[c] = (2.0 * rows * N * K * iters / (time.perf_counter() - t0) / 1e12, iters)
+    best = max(results, key=lambda c: results[c][0])
+    return {"value": round(results[best][0], 4), "unit": "TFLOPS", "cores": best, "kind": "reference",
+            "sample": f"torch.nn.Linear({K},{N}).half() on CPU, M={rows}, {results[best][1]} forwards after 2 warm-ups at {best} threads "
+                      f"(sweep over threads: " + ", ".join(f"{c}: {results[c][0]:.3f}" for c in cands) + f" TFLOPS; {logical} logical CPUs)"}
 
 
 def hbm_traffic_from_profile():
-    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/*hbm_traffic.json), or None."""
+    """(HBM bytes per GEMM launch, source file) from the committed rocprofv3 PMC passes (profiles/*hbm_traffic.json), or (None, None).
+    The counters need their own rocprofv3 --pmc passes (tools/profile_bench.sh), so the bench line carries the committed figure."""
     try:
-        best = None
+        best = src = None
         pdir = os.path.join(ROOT, "profiles")
         for f in sorted(os.listdir(pdir)):
             if f.endswith("hbm_traffic.json"):
-                best = json.load(open(os.path.join(pdir, f)))
-        return None if best is None else best.get("hbm_bytes_per_launch")
+                best, src = json.load(open(os.path.join(pdir, f))), "profiles/" + f
+        return (None, None) if best is None else (best.get("hbm_bytes_per_launch"), src)
     except Exception:
-        return None
+        return None, None
 
 
-def main():
-    args = parse()
+def dry_run(args):
+    """CPU rehearsal of the N-rank job: rendezvous, row sharding, barriers, the counter gather and the JSON line, with a
+    synthetic per-rank time instead of GPU work (tests/test_dist_gloo.py drives `--gpus 2 --backend gloo --dry-run`)."""
     rank, local_rank, world = init_dist(args.gpus, args.backend)
+    dev = torch.device("cpu")
+    lo, hi = rank_rows(M, world, rank, args.scaling)
+    barrier(world, dev)
+    elapsed = 1e-3 * (1.0 + 0.1 * rank)                                   # rank r "takes" 1 + 0.1 r ms for its rows
+    flops = 2.0 * (hi - lo) * N * K * args.steps
+    barrier(world, dev)
+    mx, tot, per = gather_counters(elapsed, flops, world, dev, per_rank=True)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "value": round(tot / mx / 1e12, 3), "unit": "TFLOPS",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
+                          "rows_per_rank": hi - lo, "per_rank_ms": [round(v * 1e3, 4) for v in per],
+                          "config": {"workload": "launch-path rehearsal", "M": M, "K": K, "N": N}}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    global M, K, N
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.shape:
+        K, N = (int(v) for v in args.shape.split(","))
+    if args.batch:
+        M = args.batch
+    if args.gpus > 1 and dist_env()[2] != args.gpus and not os.environ.get("MIXQ_BENCH_CHILD"):
+        return spawn_ranks(args.gpus, argv)                             # no launcher around us: be the launcher
+    if args.dry_run:
+        return dry_run(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: mixq_amd has no CPU path (the CPU numbers it prints are the baseline only)")
+    rank, local_rank, world = init_dist(args.gpus, args.backend)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from mixq_amd import _capi, mixlib
     info = _capi.device_info()                                  # loads libmixq_hip.so; raises if it is missing
 
-    lin, cache, layer = build_layer(device)
+    lo, hi = rank_rows(M, world, rank, args.scaling)
+    rows = hi - lo
+    lin, cache, layer = build_layer(device, rows)
     steps, warm = args.steps, args.warmup
-    cols, base, pristine = make_batches(steps, device, rank)
+    cols, base, pristine = make_batches(steps, rows, device, rank)
+    nbuf = pristine.shape[0]
 
     # outlier prediction warm-up: the first cache.stop (=2) forwards discover and freeze `ind` (host syncs allowed here)
     for _ in range(3):
@@ -173,13 +257,14 @@ def main():
     with torch.no_grad():
         xz = base.clone()
         q, xo = mixlib.QuantFused(xz, layer.ind, cache.x_scale, 8, SIGMA)
-        Xd = q.double() * cache.x_scale[:M].double()
+        Xd = q.double() * cache.x_scale[:rows].double()
         Xd[:, layer.ind.long()] = base[:, layer.ind.long()].double()
         ref = Xd @ (layer.q_weight.double() * layer.scale_col.double().T).T
         max_abs_err = float((layer(base.clone(), None, True).double() - ref).abs().max())
+        del Xd, ref
 
     def one_step(i):
-        return layer(pristine[i], None, True)
+        return layer(pristine[i % nbuf], None, True)
 
     side = torch.cuda.Stream(device=device)
     graph = None
@@ -197,75 +282,90 @@ def main():
             graph.replay()                                      # one untimed replay: graph upload, clocks
             torch.cuda.synchronize()
             pristine.copy_(base.unsqueeze(0).expand_as(pristine))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         barrier(world, device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        e0.record(side)
         if graph is not None:
             graph.replay()
         else:
             for i in range(steps):
                 one_step(i)
+        e1.record(side)
         torch.cuda.synchronize()
+        host_elapsed = time.perf_counter() - t0
         barrier(world, device)
-        elapsed = time.perf_counter() - t0
+        elapsed = e0.elapsed_time(e1) * 1e-3                    # seconds between the two events on the launch stream
 
         # ---- dominant kernel (the int8 MFMA GEMM + fused epilogue) alone, HIP events on the launch stream ------------
-        q_x, x_out = mixlib.QuantFused(base.clone(), layer.ind, cache.x_scale, 8, SIGMA, packed=True)
-        cache.q_xcache, cache.q_xcache_packed, cache.activation_outliers = q_x, True, x_out
+        ind_buf, n_dev = layer._ind_dev()
+        q_x, x_out = mixlib.QuantFused(base.clone(), ind_buf, cache.x_scale, 8, SIGMA, n_dev=n_dev, fmt=layer.x_fmt())
+        cache.q_xcache, cache.activation_outliers, cache.n_dev = q_x, (x_out[:, :n_ind] if n_ind else None), n_dev
         gsteps = max(20, min(steps, 200))
         for _ in range(5):
-            layer._gemm(cache, M, 0)
+            layer._gemm(cache, rows, 0)
         torch.cuda.synchronize()
         gg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gg, stream=side):
             for _ in range(gsteps):
-                layer._gemm(cache, M, 0)
+                layer._gemm(cache, rows, 0)
         torch.cuda.synchronize()
         gg.replay()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(side)
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record(side)
         gg.replay()
-        e1.record(side)
+        g1.record(side)
         torch.cuda.synchronize()
-        gemm_us = e0.elapsed_time(e1) * 1e3 / gsteps
+        gemm_us = g0.elapsed_time(g1) * 1e3 / gsteps
 
-    flops_step = 2.0 * M * N * K
-    max_elapsed, total_flops = gather_counters(elapsed, flops_step * steps, world, device)
+    flops_step = 2.0 * rows * N * K
+    max_elapsed, total_flops, per_rank = gather_counters(elapsed, flops_step * steps, world, device, per_rank=True)
+    max_host, _ = gather_counters(host_elapsed, 0.0, world, device)
     value = total_flops / max_elapsed / 1e12
     ms_per_step = max_elapsed * 1e3 / steps
     achieved = flops_step / (gemm_us * 1e-6) / 1e12
 
     if rank == 0:
+        fmt = layer.x_fmt()
+        traffic, traffic_src = hbm_traffic_from_profile()
+        shape_note = "Llama-2-7b up_proj shape" if (K, N) == (4096, 11008) else f"{K}->{N}"
         out = {
-            "metric": "effective int8 TFLOPS, W8A8O16 MixQ Linear forward (quantise + int8 MFMA GEMM + fused dequant/outlier "
-                      "epilogue), batch 512, 4096->11008",
+            "metric": f"effective int8 TFLOPS, W8A8O16 MixQ Linear forward (quantise + int8 MFMA GEMM + fused dequant/outlier "
+                      f"epilogue), batch {M}, {K}->{N}",
             "value": round(value, 2), "unit": "TFLOPS", "n_gpus": world, "steps": steps, "warmup": warm,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "MixLinear_GEMM W8A8O16 forward, Llama-2-7b up_proj shape", "M": M, "K": K, "N": N,
+            "config": {"workload": f"MixLinear_GEMM W8A8O16 forward, {shape_note}", "M": M, "K": K, "N": N,
                        "outlier_columns": n_ind, "outlier_predict": "frozen after 2 warm-up forwards", "sigma": SIGMA,
-                       "weights": "nn.Linear default init, quantised per output channel", "per_gpu_batch": M,
-                       "parallelism": f"batch-shard x{world} (independent replicas, no data-path collective)",
-                       "launch": "eager" if args.no_graph else f"one hipGraph of {steps} steps"},
+                       "weights": "nn.Linear default init, quantised per output channel", "per_gpu_batch": rows,
+                       "parallelism": f"batch-shard x{world} ({'independent replicas' if args.scaling == 'weak' else 'rows of one batch split'}, "
+                                      f"no data-path collective)",
+                       "launch": "eager" if args.no_graph else f"one hipGraph of {steps} steps",
+                       "operand_format": {0: "plain", 1: "P16x64", 2: "F16x64"}[fmt],
+                       "weight_bytes_resident": int(layer._wpk.numel() + (0 if layer._buffers['q_weight'] is None else layer._buffers['q_weight'].numel()))},
+            "timing": {"clock": "HIP events on the launch stream around the K steps", "host_wall_ms_per_step": round(max_host * 1e3 / steps, 5),
+                       "per_rank_ms_per_step": [round(v * 1e3 / steps, 5) for v in per_rank]},
             "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
             "max_abs_err_vs_dequant_linear": round(max_abs_err, 6),
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (int8 MFMA GEMM + fused epilogue)",
+            "roofline": {"bound": "mfma", "kernel": "int8 MFMA GEMM + fused epilogue (" +
+                                                    _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(rows, N, K, 8, fmt)] + ")",
                          "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": hbm_traffic_from_profile(),
+                         "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": flops_step,
-                         "algorithmic_bytes_per_launch": 2 * M * K // 2 + N * K + 2 * M * N,
-                         "gemm_config": _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config(M, N, K, 8)]},
+                         "algorithmic_bytes_per_launch": rows * K + N * K + 2 * rows * N},
             "device": info,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(rows)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

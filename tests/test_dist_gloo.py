@@ -1,5 +1,6 @@
 """The N > 1 path of bench.py on CPU: world_size 2 over gloo, rendezvous on 127.0.0.1.  The data path shards by batch
 and exchanges nothing; the only collective is the all_gather of {elapsed, FLOPs} (bench.gather_counters)."""
+import json
 import os
 import socket
 import subprocess
@@ -31,6 +32,7 @@ def _worker(rank, world, port, q):
     # every rank "measures" a different time for the same work; the job time is the max, the work is the sum
     elapsed, flops = (0.5 if rank == 0 else 0.8), 100.0 * (rank + 1)
     mx, tot = bench.gather_counters(elapsed, flops, w, dev)
+    assert bench.gather_counters(elapsed, flops, w, dev, per_rank=True)[2] == [0.5, 0.8]
     lo, hi = bench.shard_rows(513, w, rank)
     q.put((rank, mx, tot, lo, hi))
     bench.barrier(w, dev)
@@ -68,11 +70,52 @@ def test_single_process_counters_passthrough():
     assert bench.gather_counters(1.5, 7.0, 1, torch.device("cpu")) == (1.5, 7.0)
 
 
-def test_gpus_flag_requires_matching_world_size():
-    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
-                       text=True, timeout=300)
-    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+def _run_bench(*argv, env=None):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env or dict(os.environ), capture_output=True, text=True,
+                          timeout=600)
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launches_its_own_ranks_dry_run(scaling):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py spawns the 2 ranks itself (the driver's command form),
+    they rendezvous over gloo on 127.0.0.1, gather their counters and rank 0 prints ONE JSON line.  --dry-run replaces the
+    GPU work by a synthetic time per rank so the whole launch path runs on the CPU box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MIXQ_BENCH_CHILD")}
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "3", "--scaling", scaling, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["scaling"] == scaling
+    assert out["per_rank_ms"] == [1.0, 1.1]                              # max over ranks is what the value is computed with
+    rows = 256 if scaling == "strong" else 512
+    assert out["rows_per_rank"] == rows
+    total = 2.0 * 512 * 11008 * 4096 * 3 * (1 if scaling == "strong" else 2)
+    assert out["value"] == pytest.approx(total / 1.1e-3 / 1e12, rel=1e-3)
+
+
+def test_bench_dry_run_under_an_external_launcher_shape_flag():
+    """The torch.distributed.run form: WORLD_SIZE already equals --gpus, so bench.py must NOT spawn again.  World size 1 here
+    (a second level of processes is what the test above covers); --shape / --batch reach the job description."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = _run_bench("--gpus", "1", "--dry-run", "--shape", "8192,28672", "--batch", "64", "--steps", "2", env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["K"] == 8192 and out["config"]["N"] == 28672 and out["config"]["M"] == 64 and out["n_gpus"] == 1
+
+
+def test_self_launched_ranks_fail_loudly_without_gpus():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MIXQ_BENCH_CHILD")}
+    r = _run_bench("--gpus", "2", "--steps", "1", "--backend", "gloo", env=env)
+    assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
+
+
+def test_init_dist_rejects_a_mismatched_world_size():
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    with pytest.raises(SystemExit, match="WORLD_SIZE"):
+        bench.init_dist(2, "gloo")
 
 
 def test_bench_refuses_to_run_without_gpu():

@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--cfgs", default="all")
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--packed", default="0,1")
+    ap.add_argument("--packed", default="0,1,2", help="operand formats to try: 0 plain, 1 P16x64, 2 F16x64")
     ap.add_argument("--out", default="gpurun_out/sweep_gemm.json")
     ap.add_argument("--nout", type=int, default=0, help="outlier columns fed to the fp16 tail (timing; the error check ignores them)")
     args = ap.parse_args()
@@ -86,18 +86,25 @@ def main():
         sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
         ref = (ref32 * sx.double() * sw.double())
         flops = 2.0 * M * N * K
-        qxp = mixlib.PackP16x64(qx) if (K if args.bit == 8 else K // 2) % 64 == 0 else None
-        qwp = mixlib.PackP16x64(qw) if qxp is not None else None
+        can_pack = (K if args.bit == 8 else K // 2) % 64 == 0
+        packs = {0: (qx, qw)}
+        if can_pack:
+            packs[1] = (mixlib.PackOperand(qx, 1), mixlib.PackOperand(qw, 1))       # P16x64
+            packs[2] = (mixlib.PackOperand(qx, 2), mixlib.PackOperand(qw, 2))       # F16x64 (gemm_wreg.hip, decode32)
         xo = wo = None
         if args.nout:
             pad = (args.nout + 15) // 16 * 16
             xo = torch.zeros((M, pad), dtype=torch.float16, device=dev)[:, :args.nout]
             wo = torch.zeros((N, pad), dtype=torch.float16, device=dev)[:, :args.nout]
         for c, krot in [(c, int(kr)) for c in cfgs for kr in args.packed.split(",")]:
-            if krot and (qxp is None or "x128_" in names[c].split("_w")[0][-5:]):
+            if krot not in packs:
                 continue
-            ax, aw = (qxp, qwp) if krot else (qx, qw)
-            pk = dict(x_packed=bool(krot), w_packed=bool(krot))
+            if names[c].startswith("wr") != (krot == 2) and names[c] != "decode32":
+                continue                                   # the weights-in-registers tilings take F16x64 only, the others never
+            if names[c] == "decode32" and (krot == 0 or M > 32):
+                continue
+            ax, aw = packs[krot]
+            pk = {}
             rc = lib.mixq_gemm_set_config(c)
             assert rc == 0
             try:
@@ -118,8 +125,9 @@ def main():
             print(f"{shp} cfg{c:2d} packed={krot:1d} {names[c]:24s} err={err:.3e} rel={rel:.2e} eager={us:8.2f}us graph={usg:8.2f}us "
                   f"{tops:7.1f} TOPS ({100 * tops / PEAK_TOPS:4.1f}%)", flush=True)
         lib.mixq_gemm_set_config(-1)
-        auto = lib.mixq_gemm_pick_config(M, N, K, args.bit)
-        print(f"{shp}: auto pick = cfg{auto} {names[auto]}", flush=True)
+        for fmt in (1, 2):
+            auto = lib.mixq_gemm_pick_config_fmt(M, N, K, args.bit, fmt)
+            print(f"{shp}: auto pick (fmt {fmt}) = cfg{auto} {names[auto]}", flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(results, f, indent=1)

@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
-"""Time the fused extract+quantise kernel alone (graph replay, rotating pristine inputs)."""
+"""Time the fused extract+quantise kernel alone (graph replay, rotating pristine inputs) for every launch geometry
+(mixq_quant_set_config) and output format.  HBM bytes per launch: 2 M K read + M K bit/8 written (+ outlier columns)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mixq_amd import mixlib
+from mixq_amd import _capi, mixlib
 from tools.sweep_gemm import time_graph
 
-M, K = 512, 4096
 dev = "cuda"
-for n_out in (0, 41):
-    for packed in (False, True):
-        for bit in (8, 4):
-            x = torch.randn(64, M, K, device=dev).half()
-            ind = torch.randperm(K)[:n_out].to(torch.int32).to(dev) if n_out else None
-            xs = torch.zeros(M, 1, dtype=torch.float16, device=dev)
-            i = [0]
-            def f():
-                mixlib.QuantFused(x[i[0] % 64], ind, xs, bit, 6.0, packed=packed)
-                i[0] += 1
-            us = time_graph(f, 200, 20)
-            print(f"QuantFused M={M} K={K} bit={bit} n_out={n_out} packed={packed}: {us:.2f} us  ({(M*K*2 + M*K*bit/8)/us/1e6:.2f} TB/s)")
+lib = _capi.load()
+NAMES = ["r1 256x1", "64x1", "64x2", "64x4", "128x1", "128x2", "256x1", "256x2"]
+shapes = [(512, 4096)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for (M, K) in shapes:
+    nb = max(2, min(64, (1 << 30) // (M * K * 2)))
+    x = torch.randn(nb, M, K, device=dev).half()
+    for n_out in (0, round(0.01 * K)):
+        ind = torch.randperm(K)[:n_out].to(torch.int32).to(dev) if n_out else None
+        for fmt in (0, 2):
+            for bit in (8, 4):
+                row = []
+                for cfg in range(len(NAMES)):
+                    assert lib.mixq_quant_set_config(cfg) == 0
+                    xs = torch.zeros(M, 1, dtype=torch.float16, device=dev)
+                    i = [0]
+                    def f():
+                        mixlib.QuantFused(x[i[0] % nb], ind, xs, bit, 6.0, fmt=fmt)
+                        i[0] += 1
+                    us = time_graph(f, 200, 20)
+                    row.append(us)
+                lib.mixq_quant_set_config(-1)
+                best = min(range(len(row)), key=lambda c: row[c])
+                gbs = (M * K * 2 + M * K * bit / 8) / row[best] / 1e6
+                print(f"QuantFused M={M} K={K} bit={bit} n_out={n_out} fmt={fmt}: " + "  ".join(f"{NAMES[c]}={row[c]:.2f}" for c in range(len(row))) +
+                      f"  us | best {NAMES[best]} {row[best]:.2f} us = {gbs:.2f} TB/s", flush=True)
