@@ -49,22 +49,23 @@ extern "C" {
  * MIXQ_FMT_PLAIN  : row-major [R, KB] bytes (KB = K for int8, K/2 for nibble-packed int4) - the reference's layout.
  * MIXQ_FMT_P16X64 : tile-major "P16x64": [KB/64][rows16/16] blocks of 16 rows x 64 bytes (1 KiB each), rows16 =
  *                   roundup(R,16); inside a block row r (0..15) stores its four 16-byte chunks c at position
- *                   c ^ ((r>>2)&3).  A block is byte-for-byte the LDS image the GEMM's fragment reads expect, so one
+ *                   c ^ (-(r>>2) & 3).  A block is byte-for-byte the LDS image the GEMMs' fragment reads expect (conflict-free for
+ *                   the 32x32x32 and the 16x16x64 int8 MFMA operand shapes alike), a row's 64 bytes stay contiguous, so one
  *                   LDS-DMA instruction moves one contiguous KiB and a k-step of a tile is one contiguous run
  *                   (1.7x the operand-feed rate of 64-byte row segments on MI355X).  KB % 64 == 0. */
 #define MIXQ_FMT_PLAIN  0
 #define MIXQ_FMT_P16X64 1
-/* MIXQ_FMT_F16X64 : "fragment order": the same [KB/64][rows16/16] grid of 1 KiB blocks, but inside a block the four
- *                   16-byte k-chunks c are the slow index: byte c*256 + r*16 + b.  Lane l of a wave that loads 16 bytes at
- *                   block + 16 l holds row l & 15, k-chunk l >> 4 - one v_mfma_i32_16x16x64_i8 operand - so a weight
- *                   fragment is ONE fully coalesced global_load_dwordx4 with no LDS round trip, and an activation block
- *                   DMA-ed to LDS is read back by ds_read_b128 at lane * 16 without bank conflicts (gemm_wreg.hip). */
+/* MIXQ_FMT_F16X64 : "fragment order", the WEIGHT format of the weights-in-registers kernels (gemm_wreg.hip): the same
+ *                   [KB/64][rows16/16] grid of 1 KiB blocks, but inside a block the four 16-byte k-chunks c are the slow index:
+ *                   byte c*256 + r*16 + b.  Lane l of a wave that loads 16 bytes at block + 16 l holds row l & 15, k-chunk
+ *                   l >> 4 - one v_mfma_i32_16x16x64_i8 operand - so a weight fragment is ONE fully coalesced
+ *                   global_load_dwordx4 with no LDS round trip.  (Activations stay in P16X64: the quantise kernels write a
+ *                   row's 64 bytes contiguously.) */
 #define MIXQ_FMT_F16X64 2
 /* `layout` bits of the GEMM entry points */
 #define MIXQ_X_PACKED 1      /* q_x is MIXQ_FMT_P16X64 */
 #define MIXQ_W_PACKED 2      /* q_w is MIXQ_FMT_P16X64 */
-#define MIXQ_X_F16X64 4      /* q_x is MIXQ_FMT_F16X64 */
-#define MIXQ_W_F16X64 8      /* q_w is MIXQ_FMT_F16X64 */
+#define MIXQ_W_F16X64 8      /* q_w is MIXQ_FMT_F16X64 (requires MIXQ_X_PACKED) */
 
 typedef void* mixq_stream_t; /* hipStream_t */
 
@@ -79,7 +80,7 @@ int mixq_device_info(char* buf_host, int cap);
  *            inf / nan inputs is not specified - the reference does not define it either)
  *   x_scale  fp16 [M]   written in place (the reference passes its cache.x_scale[inputdim,1] buffer)
  *   q        bit=8: int8 [M,K];  bit=4: uint8 [M,K/2] nibble-packed.  K % 8 == 0 (bit 8) / K % 16 == 0 (bit 4).
- *   qfmt     MIXQ_FMT_PLAIN, or MIXQ_FMT_P16X64 / MIXQ_FMT_F16X64 to emit q directly in a tile-major layout (buffer of
+ *   qfmt     MIXQ_FMT_PLAIN, or MIXQ_FMT_P16X64 (what the GEMMs take) / MIXQ_FMT_F16X64 to emit q directly in a tile-major layout (buffer of
  *            roundup(M,16) * KB bytes; rows >= M are left untouched).
  */
 int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q,
@@ -134,7 +135,7 @@ int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col, const int
  *         n_out_dev: optional device int32 overriding n_out (<= n_out); ldxo, ldwo >= roundup(n_out,16), % 8 == 0
  *   addend fp16 [M,lda] or NULL;  bias fp16 [N] or NULL;  y fp16 [M,ldy]
  *   layout  MIXQ_X_PACKED | MIXQ_W_PACKED bits (0 = both operands plain row-major as in the reference), or
- *           MIXQ_X_F16X64 | MIXQ_W_F16X64 (both together: the weights-in-registers kernels take both operands that way)
+ *           MIXQ_X_PACKED | MIXQ_W_F16X64 (the weights-in-registers kernels: fragment-order weights, P16X64 activations)
  *   K % 64 == 0, N % 4 == 0, ldy % 4 == 0.
  */
 int mixq_gemm_i8_fused(const int8_t* q_x, const int8_t* q_w, const uint16_t* x_scale,

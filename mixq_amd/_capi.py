@@ -25,7 +25,6 @@ FMT_P16X64 = 1
 FMT_F16X64 = 2
 X_PACKED = 1
 W_PACKED = 2
-X_F16X64 = 4
 W_F16X64 = 8
 
 

@@ -12,6 +12,14 @@ Policy (reference `utils/module.py:2-12`, applied in `quantize/mixquant.py:163-2
   * with w_bit = 4, layers whose name contains down_proj / o_proj / fc_out stay 8-bit,
   * per architecture, some layers are weight-only W8A16 (GPT-J `fc_out`); an optional comma list adds more.
 
+Weight-only (W8A16) layers are the one place where the two sides store DIFFERENT bytes under the same key, shape and
+dtype: the reference's `q_weight` there is EETQ's CUTLASS-interleaved image (modules/linear.py:102-106), ours the plain
+int8 [K,N] matrix.  `quant_config.json` therefore records `"w8a16_layout"`: "plain" (written by save_quantized) or
+"eetq" (assumed when the key is missing, i.e. for a checkpoint the reference wrote); load_quantized converts "eetq" layers
+with mixq_amd.eetq.unprocess_weights, and save_quantized(..., w8a16_layout="eetq") writes the reference's form.  (EETQ is
+un-versioned and absent from the reference tree: the interleave is restated from the FasterTransformer routine it wraps -
+parity for these layers stays UNPINNED, see mixq_amd/eetq.py.)
+
 Nothing here touches the GPU by itself: quantisation uses torch ops on whatever device the layer lives on; the kernels
 are only reached through `MixLinear_GEMM.forward`.
 """
@@ -154,16 +162,28 @@ def shard_state_dict(state_dict, max_shard_size="10GB", weights_name="pytorch_mo
     return files, {"metadata": {"total_size": total}, "weight_map": weight_map}
 
 
-def save_quantized(root, save_dir, quant_config, safetensors=False, shard_size="10GB"):
+def _weight_only_prefixes(root):
+    return [name + "." if name else "" for name, m in root.named_modules() if isinstance(m, MixLinear_GEMM) and m.weight_only]
+
+
+def save_quantized(root, save_dir, quant_config, safetensors=False, shard_size="10GB", w8a16_layout="plain"):
     """Write `root.state_dict()` + `quant_config.json` in the reference's layout (`base.py:78-119`).  When `root` is a
-    Hugging Face model its config files are written too (as the reference's `save_pretrained(state_dict={})` does)."""
+    Hugging Face model its config files are written too (as the reference's `save_pretrained(state_dict={})` does).
+    `w8a16_layout`: how weight-only layers' q_weight is stored - "plain" (ours) or "eetq" (the reference's interleaved image)."""
+    if w8a16_layout not in ("plain", "eetq"):
+        raise ValueError("w8a16_layout must be 'plain' or 'eetq'")
     os.makedirs(save_dir, exist_ok=True)
     cfg = dict(quant_config)
     cfg.setdefault("version", "MIX")
+    cfg["w8a16_layout"] = w8a16_layout
     if hasattr(root, "save_pretrained") and hasattr(root, "config"):
         root.config.save_pretrained(save_dir)
     weights_name = "model.safetensors" if safetensors else "pytorch_model.bin"
     sd = {k: v.detach().cpu() for k, v in root.state_dict().items()}
+    if w8a16_layout == "eetq":
+        from . import eetq
+        for pre in _weight_only_prefixes(root):
+            sd[pre + "q_weight"] = eetq.preprocess_weights(sd[pre + "q_weight"])
     files, index = shard_state_dict(sd, shard_size, weights_name)
     for fn, shard in files.items():
         path = os.path.join(save_dir, fn)
@@ -218,6 +238,14 @@ def load_quantized(root, load_dir, cache, arch="LlamaForCausalLM", blocks=None, 
     quant_config = read_quant_config(load_dir)
     prepare_(root, quant_config, cache, arch, blocks, dev)
     sd = load_state_dict_files(load_dir)
+    layout = quant_config.get("w8a16_layout", "eetq")       # no key: a checkpoint written by the reference (EETQ's interleaved image)
+    if layout not in ("plain", "eetq"):
+        raise ValueError(f"quant_config.json: unknown w8a16_layout {layout!r}")
+    if layout == "eetq":
+        from . import eetq
+        for pre in _weight_only_prefixes(root):
+            if pre + "q_weight" in sd:
+                sd[pre + "q_weight"] = eetq.unprocess_weights(sd[pre + "q_weight"])
     root.load_state_dict(sd, strict=strict)
     return quant_config
 

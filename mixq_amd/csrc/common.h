@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <mutex>
+#include <unordered_map>
 #include "../../include/mixq_hip.h"
 
 typedef int      i32x4  __attribute__((ext_vector_type(4)));
@@ -23,6 +25,23 @@ static inline hipStream_t mixq_stream(mixq_stream_t s) { return reinterpret_cast
 static inline int mixq_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MIXQ_OK : static_cast<int>(e);
+}
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): hipFuncSetAttribute is per device, and one process may drive
+// several GPUs (north_star: "one process with per-device streams" is a legal variant), so the "already done" note is too.
+inline int mixq_ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, uint64_t> done;        // kernel -> bit mask of devices (< 64) already configured
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return MIXQ_ENODEV; }
+    const uint64_t bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lock(mu);
+    uint64_t& m = done[kernel];
+    if (m & bit) return MIXQ_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
+    m |= bit;
+    return MIXQ_OK;
 }
 
 __device__ __forceinline__ float h2f(uint16_t h) {
@@ -67,13 +86,16 @@ __device__ __forceinline__ int quant_exact(float x, float s, float rs) {
     return (s > 0.f) ? static_cast<int>(q0) : 0;
 }
 // Byte address of byte `kb` of row `row` in a packed operand ([KB/64][rows16/16] blocks of 16 rows x 64 bytes = 1 KiB):
-//   MIXQ_FMT_P16X64: row r of a block stores its four 16-byte chunks c at r*64 + (c ^ ((r>>2)&3))*16 (the LDS image of gemm.hip)
+//   MIXQ_FMT_P16X64: row r of a block stores its four 16-byte chunks c at r*64 + (c ^ (-(r>>2) & 3))*16: a row's 64 bytes stay
+//                    contiguous (the quantise kernels write them as such), and BOTH fragment shapes read the LDS image without bank
+//                    conflicts: 32x32x32 (row l&31, chunk 2s + (l>>5): gemm.hip) and 16x16x64 (row l&15, chunk l>>4: gemm_wreg.hip);
+//                    the round-1 swizzle (r>>2)&3 served only the first (tests/test_pack_properties.py checks both)
 //   MIXQ_FMT_F16X64: chunk-major "fragment order" c*256 + r*16 - lane l of a wave owns bytes [16 l, 16 l + 16) of a block,
 //                    which is row l&15, k-chunk l>>4: exactly one v_mfma_i32_16x16x64_i8 operand (gemm_wreg.hip)
 __device__ __forceinline__ size_t packed_offset(int fmt, int row, int kb, int rows16) {
     const int r = row & 15, c = (kb & 63) >> 4;
     const size_t blk = (static_cast<size_t>(kb >> 6) * (rows16 >> 4) + (row >> 4)) * 1024;
-    return blk + (fmt == MIXQ_FMT_F16X64 ? c * 256 + r * 16 : r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) + (kb & 15);
+    return blk + (fmt == MIXQ_FMT_F16X64 ? c * 256 + r * 16 : r * 64 + ((c ^ ((0 - (r >> 2)) & 3)) << 4)) + (kb & 15);
 }
 __device__ __forceinline__ int wave_id_uniform() {
     return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);

@@ -9,7 +9,7 @@
 //    KiB pieces at ~90-104 GB/s.  So the fast path takes operands in the tile-major "P16x64" layout
 //    (include/mixq_hip.h) whose 16-row x 64-byte blocks ARE the LDS image; plain row-major operands (the
 //    reference's layout) are still accepted, with the XOR swizzle applied on the DMA source address instead.
-//  * LDS rows are 64 bytes; the 16-byte chunk index is XOR-ed with ((row>>2)&3) so the ds_read_b128 fragment reads
+//  * LDS rows are 64 bytes; the 16-byte chunk index is XOR-ed with (-(row>>2) & 3) so the ds_read_b128 fragment reads
 //    of every 16-lane group hit 16 distinct bank slots (SQ_LDS_BANK_CONFLICT = 0 measured).
 //  * Wave specialisation: LOADERS dedicated wave(s) do nothing but issue the DMA and publish stages
 //    (counted s_waitcnt vmcnt + the k-step's single s_barrier); the WAVES_M x WAVES_N consumer waves only read
@@ -67,7 +67,7 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
 }
 
 // physical 16-byte chunk of logical chunk c in row r (an involution in c for fixed r)
-__device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 2) & 3); }
+__device__ __forceinline__ int swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 3); }
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   // 1-ulp rcp: below fp16 resolution
 
@@ -715,7 +715,6 @@ constexpr int NUM_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
 int g_forced_cfg = -1;
 unsigned long long* g_trace = nullptr;             // diagnostics: see mixq_gemm_set_trace
-bool g_attr_done[NUM_CFGS][3];
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -772,12 +771,7 @@ int launch_gemm(GemmArgs& a, int mode, hipStream_t st) {
     a.trace = g_trace;
     void (*k)(const GemmArgs) = mode == 0 ? g->k8 : (mode == 1 ? g->k4 : g->k32);
     const size_t shm = static_cast<size_t>(g->bm + g->bn) * BKB * g->nstage;
-    if (!g_attr_done[c][mode]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(shm));
-        if (e != hipSuccess) return static_cast<int>(e);
-        g_attr_done[c][mode] = true;
-    }
+    if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3(g->waves * 64), shm, st, a);
     return mixq_launch_status();
 }
@@ -787,11 +781,10 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
                       const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int K,
                       int act, int layout, int bit, mixq_stream_t stream)
 {
-    if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED | MIXQ_X_F16X64 | MIXQ_W_F16X64)) return MIXQ_EINVAL;
-    if ((layout & MIXQ_X_PACKED) && (layout & MIXQ_X_F16X64)) return MIXQ_EINVAL;
+    if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED | MIXQ_W_F16X64)) return MIXQ_EINVAL;
     if ((layout & MIXQ_W_PACKED) && (layout & MIXQ_W_F16X64)) return MIXQ_EINVAL;
-    const bool xf16 = layout & MIXQ_X_F16X64, wf16 = layout & MIXQ_W_F16X64;
-    if (xf16 != wf16) return MIXQ_EINVAL;                 // the fragment-order kernels take both operands in that layout
+    const bool wf16 = layout & MIXQ_W_F16X64;
+    if (wf16 && !(layout & MIXQ_X_PACKED)) return MIXQ_EINVAL;   // fragment-order weights go with P16X64 activations
     if (M < 0 || N < 0 || K <= 0 || n_out < 0) return MIXQ_EINVAL;
     if (M > 0 && N > 0 && (!q_x || !q_w || !x_scale || !scale_col || !y)) return MIXQ_EINVAL;
     if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU && act != MIXQ_ACT_SILU_MUL) return MIXQ_EINVAL;
@@ -816,14 +809,14 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     const int skinny_id = NUM_CFGS + sk_num, wr0 = skinny_id + 1;
     // small-batch form (gemm_skinny.hip): M <= 32, packed operands (either packed layout): a weight stream, no LDS staging
     {
-        const bool both_packed = (a.x_packed && a.w_packed) || xf16;
+        const bool both_packed = a.x_packed && (a.w_packed || wf16);
         if ((g_forced_cfg < 0 || g_forced_cfg == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed))
             return mixq_skinny_launch(bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
-                                      ldy, M, N, KB, act, xf16 ? 1 : 0, mixq_stream(stream));
+                                      ldy, M, N, KB, act, wf16 ? 1 : 0, mixq_stream(stream));
         if (g_forced_cfg == skinny_id) return MIXQ_EINVAL;
     }
-    // fragment-order operands: the weights-in-registers kernels (gemm_wreg.hip)
-    if (xf16) {
+    // fragment-order weights: the weights-in-registers kernels (gemm_wreg.hip)
+    if (wf16) {
         int c;
         if (g_forced_cfg >= wr0) c = g_forced_cfg - wr0;
         else if (g_forced_cfg >= 0) return MIXQ_EINVAL;  // a P16X64 / plain tiling was forced: wrong operand layout
@@ -921,7 +914,8 @@ extern "C" int mixq_gemm_pick_config(int M, int N, int K, int bit) {
     if (sk >= 0 && mixq_sk_usable(sk)) return NUM_CFGS + sk;
     return pick_config(M, N, KB, true);
 }
-// The config the automatic choice runs for operands in the packed format `fmt` (MIXQ_FMT_P16X64 / MIXQ_FMT_F16X64).
+// The config the automatic choice runs for weights in the packed format `fmt` (MIXQ_FMT_P16X64 / MIXQ_FMT_F16X64; the
+// activations are P16X64 either way).
 extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) {
     if (M <= 0 || N <= 0 || K <= 0 || (bit != 4 && bit != 8)) return MIXQ_EINVAL;
     const int KB = bit == 8 ? K : K / 2;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 2) & 3); }
+__device__ __forceinline__ int swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 3); }
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   // 1-ulp rcp: below fp16 resolution
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int MODE>
@@ -438,7 +438,6 @@ constexpr int NUM_SK = sizeof(g_sk) / sizeof(g_sk[0]);
 void* g_ws = nullptr;
 size_t g_ws_bytes = 0;
 int g_num_cu = 0;
-bool g_sk_attr[NUM_SK][2];
 
 }  // namespace
 
@@ -482,11 +481,7 @@ int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     a.flags = reinterpret_cast<int32_t*>(static_cast<char*>(g_ws) + static_cast<size_t>(g_num_cu) * g.bm * g.bn * 4);
     void (*k)(const SkArgs) = bit == 8 ? g.k8 : g.k4;
     const size_t shm = static_cast<size_t>(g.bm + g.bn) * BKB * g.nstage;
-    if (!g_sk_attr[c][bit == 8 ? 0 : 1]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
-        if (e != hipSuccess) return static_cast<int>(e);
-        g_sk_attr[c][bit == 8 ? 0 : 1] = true;
-    }
+    if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(a.G), dim3(g.waves * 64), shm, st, a);
     return mixq_launch_status();
 }

@@ -26,12 +26,12 @@ struct SkinnyArgs {
     const uint16_t* sx; const uint16_t* sw; const uint16_t* xo; const uint16_t* wo;
     const int32_t* n_out_dev; const uint16_t* addend; const uint16_t* bias; uint16_t* y;
     int M, N, KB, ldxo, ldwo, n_out, lda, ldy, act, xrows16, wrows16;
-    int f16;                                             // operands in MIXQ_FMT_F16X64 instead of MIXQ_FMT_P16X64
+    int wf16;                                            // weights in MIXQ_FMT_F16X64 instead of MIXQ_FMT_P16X64
 };
 
 constexpr int SKW = 8;                                   // waves per workgroup = k splits
 
-__device__ __forceinline__ int sk_swz(int r, int c) { return c ^ ((r >> 2) & 3); }
+__device__ __forceinline__ int sk_swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 3); }   // P16X64 chunk swizzle (common.h)
 __device__ __forceinline__ float sk_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 // UNROLL: k-steps whose loads are in flight together (x2 buffers); MINW: waves per SIMD the register budget must allow.
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(SKW * 64, MINW) void gemm_skinny_kernel(const Skinn
     int wr = n0 + lr; wr = wr < a.N ? wr : a.N - 1;                      // clamped rows are computed and dropped
     int xr = lr < a.M ? lr : a.M - 1;
     // P16X64: row r at r*64, chunk c at (c ^ swizzle)*16;  F16X64: chunk c at c*256, row r at r*16
-    const uint8_t* wp = a.qw + static_cast<size_t>(wr >> 4) * 1024 + (wr & 15) * (a.f16 ? 16 : 64);
-    const uint8_t* xp = a.qx + static_cast<size_t>(xr >> 4) * 1024 + (xr & 15) * (a.f16 ? 16 : 64);
-    const int wc0 = a.f16 ? lh * 256 : sk_swz(wr, lh) * 16, wc1 = a.f16 ? (2 + lh) * 256 : sk_swz(wr, 2 + lh) * 16;   // sub-steps 0 / 1: chunks lh / 2 + lh
-    const int xc0 = a.f16 ? lh * 256 : sk_swz(xr, lh) * 16, xc1 = a.f16 ? (2 + lh) * 256 : sk_swz(xr, 2 + lh) * 16;
+    const uint8_t* wp = a.qw + static_cast<size_t>(wr >> 4) * 1024 + (wr & 15) * (a.wf16 ? 16 : 64);
+    const uint8_t* xp = a.qx + static_cast<size_t>(xr >> 4) * 1024 + (xr & 15) * 64;
+    const int wc0 = a.wf16 ? lh * 256 : sk_swz(wr, lh) * 16, wc1 = a.wf16 ? (2 + lh) * 256 : sk_swz(wr, 2 + lh) * 16;   // sub-steps 0 / 1: chunks lh / 2 + lh
+    const int xc0 = sk_swz(xr, lh) * 16, xc1 = sk_swz(xr, 2 + lh) * 16;
     const size_t wks = static_cast<size_t>(a.wrows16) * 64, xks = static_cast<size_t>(a.xrows16) * 64;
 
     i32x16 acc, acc1;                                    // two chains: consecutive MFMAs never wait on each other
@@ -224,13 +224,13 @@ bool mixq_skinny_applies(int bit, int M, int N, int KB, bool x_packed, bool w_pa
 
 int mixq_skinny_launch(int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col, const uint16_t* x_out,
                        int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev, const uint16_t* addend,
-                       int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act, int f16, hipStream_t st)
+                       int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act, int wf16, hipStream_t st)
 {
     SkinnyArgs a;
     a.qx = static_cast<const uint8_t*>(q_x); a.qw = static_cast<const uint8_t*>(q_w);
     a.sx = x_scale; a.sw = scale_col; a.xo = x_out; a.wo = w_out; a.n_out_dev = n_out_dev; a.addend = addend; a.bias = bias; a.y = y;
     a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
-    a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15; a.f16 = f16;
+    a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15; a.wf16 = wf16;
     if (bit == 8) hipLaunchKernelGGL((gemm_skinny_kernel<4, 2, false>), dim3((N + 31) / 32), dim3(SKW * 64), 0, st, a);
     else          hipLaunchKernelGGL((gemm_skinny_kernel<4, 2, true>), dim3((N + 31) / 32), dim3(SKW * 64), 0, st, a);
     return mixq_launch_status();

@@ -448,7 +448,6 @@ const WoConfig g_wo[] = {
 };
 constexpr int NUM_WO_PICK = 3;
 constexpr int NUM_WO = sizeof(g_wo) / sizeof(g_wo[0]);
-bool g_wo_attr[NUM_WO];
 int g_wo_forced = -1;
 
 inline int wo_cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -496,11 +495,7 @@ extern "C" int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_pack
     const WoConfig& g = g_wo[c];
     a.tiles_m = wo_cdiv(M, g.bm); a.tiles_n = wo_cdiv(N, g.bn);
     const size_t shm = static_cast<size_t>(g.bn * 64 + g.bm * 128) * g.nstage;
-    if (!g_wo_attr[c]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(g.k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
-        if (e != hipSuccess) return static_cast<int>(e);
-        g_wo_attr[c] = true;
-    }
+    if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(g.k), shm)) return rc;
     hipLaunchKernelGGL(g.k, dim3(a.tiles_m * a.tiles_n), dim3(g.waves * 64), shm, mixq_stream(stream), a);
     return mixq_launch_status();
 }

@@ -12,9 +12,10 @@
 //     makes a fragment (16 rows x 64 bytes, lane l = row l&15, k-chunk l>>4: one v_mfma_i32_16x16x64_i8 A operand) ONE
 //     contiguous KiB: a single fully coalesced global_load_dwordx4 with a wave-uniform base, D k-steps deep in a
 //     register ring.  No barrier, no LDS, no duplication between waves for 60 % of the operand bytes.
-//   * only the activation tile (16*MB rows, shared by the 4 waves) is staged: 1 KiB blocks by LDS-DMA from dedicated
-//     loader wave(s) into an NSTAGE ring, read back with ds_read_b128 at lane*16 - in F16X64 a block IS the fragment,
-//     and lane-linear 16-byte reads are bank-conflict free by construction.  LDS traffic per k-step of the 128 x 192
+//   * only the activation tile (16*MB rows, shared by the 4 waves) is staged: 1 KiB P16X64 blocks by LDS-DMA from dedicated
+//     loader wave(s) into an NSTAGE ring, read back with ds_read_b128 (row l&15, chunk l>>4; the layout's swizzle makes the
+//     16x16x64 fragment conflict-free).  X stays in P16X64 - a row's 64 bytes contiguous - because the quantise kernel
+//     writes it row by row: fragment-order stores cost it 0.5-1.2 us (profiles/r02_quant_sweep.txt).  LDS traffic per k-step of the 128 x 192
 //     tile drops from 20 KB written + 40 KB read to 8 KB written + 32 KB read (~290 LDS cycles < 384 MFMA cycles).
 //   * a fragment of X is re-read in place right behind the last MFMA that used it (j-major MFMA order), so X needs MB
 //     fragment registers, not 2 MB.
@@ -32,7 +33,7 @@
 namespace {
 
 struct WrArgs {
-    const uint8_t* qx;  const uint8_t* qw;            // F16X64 images: [KB/64][blocks][1 KiB]
+    const uint8_t* qx;  const uint8_t* qw;            // [KB/64][blocks][1 KiB]: X in P16X64, W in F16X64
     const uint16_t* sx; const uint16_t* sw;
     const uint16_t* xo; const uint16_t* wo;
     const int32_t* n_out_dev;
@@ -160,31 +161,50 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         }
         const size_t wks = static_cast<size_t>(a.wblocks) * 1024;
         const int lane16 = lane * 16;
-        i32x4 wq[D][WNB];
+        // activation fragment (row lm, k-chunk lq) inside a P16X64 block: conflict-free by the layout's swizzle (common.h)
+        const int xoff = lm * 64 + ((lq ^ ((0 - (lm >> 2)) & 3)) << 4);
+        // Weight register ring: NSLOT = D + 1 slots.  k-step kt is consumed from slot kt % NSLOT while the loads of k-step kt + D
+        // go into slot (kt + D) % NSLOT - the slot the PREVIOUS k-step freed - so they can be issued anywhere inside the step,
+        // one behind every few MFMAs, instead of as a burst at its end (a VMEM issue blocks its wave while the address unit is
+        // busy, and the four waves, released by the same barrier, would all burst at the same moment).
+        constexpr int NSLOT = D + 1;
+        i32x4 wq[NSLOT][WNB];
         i32x4 xf[MB];
+#pragma unroll
+        for (int d = 0; d < NSLOT; ++d)
+#pragma unroll
+            for (int i = 0; i < WNB; ++i) {
+                wq[d][i] = i32x4{lane, lane, lane, lane};
+                if constexpr (ABL != 0) asm volatile("" : "+v"(wq[d][i]));
+            }
         if constexpr (ABL != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int i = 0; i < WNB; ++i) { wq[d][i] = i32x4{lane, lane, lane, lane}; asm volatile("" : "+v"(wq[d][i])); }
 #pragma unroll
             for (int j = 0; j < MB; ++j) { xf[j] = i32x4{lane, 1, lane, 1}; asm volatile("" : "+v"(xf[j])); }
         }
-        // The weight loads are inline asm with hand-counted waits: left to the compiler, the loop header of the unrolled k
-        // loop gets `s_waitcnt vmcnt(0)` (its counter model merges the preheader and latch states conservatively), which
-        // drains the whole register ring every D k-steps.  A load's destination is only meaningful after wwait() for its slot.
-        auto wload = [&](auto d_c) {
+        // The weight loads are inline asm with hand-counted waits: left to the compiler, the loop header of the unrolled k loop
+        // gets `s_waitcnt vmcnt(0)` (its counter model merges the preheader and latch states conservatively), which drains the
+        // whole register ring every group.  The destination is a READ-WRITE operand and the "do I load at all" test sits INSIDE
+        // the statement: the compiler sees one straight-line definition per slot and k-step, never a branch around a load whose
+        // merge it might resolve with a v_mov of a register the memory system has not written yet.  A slot's registers are only
+        // meaningful after wwait() for that slot.
+        auto wload1 = [&](auto d_c, int i, int cond) {
             constexpr int d = decltype(d_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
-#pragma unroll
-                for (int i = 0; i < WNB; ++i) {
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wq[d][i]) : "v"(lane16), "s"(wb[i]) : "memory");
-                    wb[i] += wks;
-                }
+                const int cs = __builtin_amdgcn_readfirstlane(cond);             // provably wave-uniform for the "s" constraint
+                asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\tglobal_load_dwordx4 %0, %1, %2\n1:"
+                             : "+v"(wq[d][i]) : "v"(lane16), "s"(wb[i]), "s"(cs) : "memory", "scc");
+                wb[i] += cond ? wks : 0;
             }
         };
-        // wait until at most `younger` loads issued after slot d's are outstanding (vmcnt retires in order); naming the
-        // slot's registers as read-write operands makes every MFMA that uses them depend on this statement
+        auto wload1_always = [&](auto d_c, int i) {
+            constexpr int d = decltype(d_c)::value;
+            if constexpr (ABL != 1 && ABL != 3) {
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(wq[d][i]) : "v"(lane16), "s"(wb[i]) : "memory");
+                wb[i] += wks;
+            }
+        };
+        // wait until at most CNT loads issued after slot d's are outstanding (vmcnt retires in order); naming the slot's registers
+        // as read-write operands makes every MFMA that uses them depend on this statement
         auto wwait = [&](auto d_c, auto cnt_c) {
             constexpr int d = decltype(d_c)::value, CNT = decltype(cnt_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
@@ -195,9 +215,31 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // the same with a run-time count (tail of the k loop): CNT in {0, WNB, 2 WNB, ...}, selected inside ONE statement
+        auto wwait_rt = [&](auto d_c, int younger) {
+            constexpr int d = decltype(d_c)::value;
+            if constexpr (ABL != 1 && ABL != 3) {
+                const int sel = __builtin_amdgcn_readfirstlane(younger >= D - 1 ? D - 1 : younger);   // k-steps requested after this one, capped at the ring depth
+#define MIXQ_WR_WAITS                                                                                                           \
+                "s_cmp_lt_u32 %[sel], 1\n\ts_cbranch_scc1 10f\n\ts_cmp_lt_u32 %[sel], 2\n\ts_cbranch_scc1 11f\n\t"               \
+                "s_cmp_lt_u32 %[sel], 3\n\ts_cbranch_scc1 12f\n\ts_cmp_lt_u32 %[sel], 4\n\ts_cbranch_scc1 13f\n\t"               \
+                "s_cmp_lt_u32 %[sel], 5\n\ts_cbranch_scc1 14f\n\ts_waitcnt vmcnt(%[c5])\n\ts_branch 19f\n"                         \
+                "10:\n\ts_waitcnt vmcnt(0)\n\ts_branch 19f\n11:\n\ts_waitcnt vmcnt(%[c1])\n\ts_branch 19f\n"                      \
+                "12:\n\ts_waitcnt vmcnt(%[c2])\n\ts_branch 19f\n13:\n\ts_waitcnt vmcnt(%[c3])\n\ts_branch 19f\n"                  \
+                "14:\n\ts_waitcnt vmcnt(%[c4])\n19:"
+#define MIXQ_WR_WAIT_IN [sel] "s"(sel), [c1] "i"(WNB), [c2] "i"(2 * WNB), [c3] "i"(3 * WNB), [c4] "i"(4 * WNB), [c5] "i"(5 * WNB)
+                if constexpr (WNB == 1) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]) : MIXQ_WR_WAIT_IN : "scc");
+                if constexpr (WNB == 2) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]) : MIXQ_WR_WAIT_IN : "scc");
+                if constexpr (WNB == 3) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]) : MIXQ_WR_WAIT_IN : "scc");
+                if constexpr (WNB == 4) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]), "+v"(wq[d][3]) : MIXQ_WR_WAIT_IN : "scc");
+#undef MIXQ_WR_WAITS
+#undef MIXQ_WR_WAIT_IN
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         auto xread = [&](int slot, int j) {
             if constexpr (ABL != 2 && ABL != 3)
-                xf[j] = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * 1024 + lane16);
+                xf[j] = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * 1024 + xoff);
         };
         uint32_t nib = 0xf0f0f0f0u;
         if constexpr (I4) asm volatile("s_mov_b32 %0, 0xf0f0f0f0" : "=s"(nib));
@@ -210,18 +252,28 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             for (int e = 0; e < 4; ++e) o[e] = static_cast<int>(static_cast<uint32_t>(v[e]) & nib);
             return o; };
 
-        // one k-step: MFMAs of ring slot d, X fragment j re-read from stage kt+1 right behind its last MFMA (REFILL), the
-        // weight loads of k-step kt+D into the slot just consumed (ISSUE)
-        auto step = [&](auto d_c, bool refill, bool issue, int rslot) {
-            constexpr int d = decltype(d_c)::value;
+        // one k-step: MFMAs of ring slot C, X fragment j re-read from stage kt+1 right behind its last MFMA (REFILL), weight load
+        // i of k-step kt+D issued into slot L = (C + D) % NSLOT behind MFMA group WPOS(i) (FULL: unconditionally)
+        auto step = [&](auto c_c, auto full_c, bool refill, int issue, int rslot) {
+            constexpr int C = decltype(c_c)::value, L = (C + D) % NSLOT;
+            constexpr bool FULL = decltype(full_c)::value;
+            using LC = std::integral_constant<int, L>;
+            auto loads_behind = [&](int j) {                                     // j: compile-time after unrolling
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) {
+                    const int pos = (WNB >= MB) ? (i % MB) : ((2 * i + 1) * MB) / (2 * WNB);      // spread evenly over the MB groups
+                    if (pos == j) { if constexpr (FULL) wload1_always(LC{}, i); else wload1(LC{}, i, issue); }
+                }
+            };
             if constexpr (!I4) {
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
 #pragma unroll
                     for (int i = 0; i < WNB; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[d][i], xf[j], acc[j][i], 0, 0, 0);
+                        acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][i], xf[j], acc[j][i], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (refill) xread(rslot, j);
+                    loads_behind(j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -229,7 +281,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 // split identically on both operands so the k pairing is preserved; the factor 256 leaves in the epilogue
                 i32x4 wl[WNB], wh[WNB];
 #pragma unroll
-                for (int i = 0; i < WNB; ++i) { wl[i] = lo4(wq[d][i]); wh[i] = hi4(wq[d][i]); }
+                for (int i = 0; i < WNB; ++i) { wl[i] = lo4(wq[C][i]); wh[i] = hi4(wq[C][i]); }
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
                     const i32x4 xl = lo4(xf[j]), xh = hi4(xf[j]);
@@ -238,9 +290,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
                     for (int i = 0; i < WNB; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wh[i], xh, acc[j][i], 0, 0, 0);
                     if (refill) xread(rslot, j);
+                    loads_behind(j);
                 }
             }
-            if (issue) wload(d_c);
         };
 
         // ---- prologue ------------------------------------------------------------------------------------------------
@@ -255,64 +307,63 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             const int n = nw0 + i * 16 + lq * 4;                                 // N % 4 == 0: 4 columns are all in or all out
             swp[i] = *reinterpret_cast<const u32x2_u*>(a.sw + (n < a.N ? n : a.N - 4));
         }
-        auto prologue_w = [&](auto d_c) { if (decltype(d_c)::value < nk) wload(d_c); };
+        auto prologue_w = [&](auto d_c) {
+#pragma unroll
+            for (int i = 0; i < WNB; ++i) wload1(d_c, i, decltype(d_c)::value < nk ? 1 : 0);
+        };
         prologue_w(std::integral_constant<int, 0>{});
         if constexpr (D > 1) prologue_w(std::integral_constant<int, 1>{});
         if constexpr (D > 2) prologue_w(std::integral_constant<int, 2>{});
         if constexpr (D > 3) prologue_w(std::integral_constant<int, 3>{});
         if constexpr (D > 4) prologue_w(std::integral_constant<int, 4>{});
         if constexpr (D > 5) prologue_w(std::integral_constant<int, 5>{});
-        static_assert(D <= 6, "extend the prologue");
+        static_assert(D >= 2 && D <= 6, "extend the prologue / the run-time wait table");
         __builtin_amdgcn_s_barrier();                                            // B0
         stamp(1);
         // every scalar (kernel-argument) load has long returned; telling the compiler's counter model so keeps the loop
-        // header from merging "SMEM pending" with the LDS reads in flight into an lgkmcnt(0) per D k-steps
+        // header from merging "SMEM pending" with the LDS reads in flight into an lgkmcnt(0) per group
         __builtin_amdgcn_s_waitcnt(0xC07F);                                      // lgkmcnt(0)
 #pragma unroll
         for (int j = 0; j < MB; ++j) xread(0, j);
 
-        // ---- k loop: unrolled by D so ring slots are compile-time registers -------------------------------------------
+        // ---- k loop: unrolled by NSLOT so ring slots are compile-time registers ----------------------------------------
         int kt = 0, slot1 = 1 % NSTAGE;                                          // ring slot of stage kt+1
-        auto one = [&](auto d_c, auto full_c) {
+        auto one = [&](auto c_c, auto full_c) {
             constexpr bool FULL = decltype(full_c)::value;                       // FULL: stage kt+1 and k-step kt+D exist
             if constexpr (FULL) {
-                wwait(d_c, std::integral_constant<int, WNB * (D - 1)>{});        // the D-1 younger slots stay in flight
+                wwait(c_c, std::integral_constant<int, WNB * (D - 1)>{});        // the D-1 younger k-steps stay in flight
                 __builtin_amdgcn_s_barrier();                                    // stage kt+1 landed; stage kt-2's slot is free
-                step(d_c, true, true, slot1);
+                step(c_c, full_c, true, 1, slot1);
             } else {
-                const int younger = nk - 1 - kt;                                 // k-steps whose weights were requested after this one's
-                if (D > 1 && younger >= D - 1)      wwait(d_c, std::integral_constant<int, WNB * (D - 1)>{});
-                else if (D > 2 && younger == D - 2) wwait(d_c, std::integral_constant<int, WNB * (D > 2 ? D - 2 : 0)>{});
-                else if (D > 3 && younger == D - 3) wwait(d_c, std::integral_constant<int, WNB * (D > 3 ? D - 3 : 0)>{});
-                else if (D > 4 && younger == D - 4) wwait(d_c, std::integral_constant<int, WNB * (D > 4 ? D - 4 : 0)>{});
-                else if (D > 5 && younger == D - 5) wwait(d_c, std::integral_constant<int, WNB * (D > 5 ? D - 5 : 0)>{});
-                else                                wwait(d_c, std::integral_constant<int, 0>{});
+                wwait_rt(c_c, nk - 1 - kt);
                 const bool more = kt + 1 < nk;
                 if (more) __builtin_amdgcn_s_barrier();
-                step(d_c, more, kt + D < nk, slot1);
+                step(c_c, full_c, more, kt + D < nk ? 1 : 0, slot1);
             }
             slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
             ++kt;
         };
         auto group = [&](auto full_c) {
             one(std::integral_constant<int, 0>{}, full_c);
-            if constexpr (D > 1) one(std::integral_constant<int, 1>{}, full_c);
-            if constexpr (D > 2) one(std::integral_constant<int, 2>{}, full_c);
-            if constexpr (D > 3) one(std::integral_constant<int, 3>{}, full_c);
-            if constexpr (D > 4) one(std::integral_constant<int, 4>{}, full_c);
-            if constexpr (D > 5) one(std::integral_constant<int, 5>{}, full_c);
+            one(std::integral_constant<int, 1>{}, full_c);
+            one(std::integral_constant<int, 2>{}, full_c);
+            if constexpr (NSLOT > 3) one(std::integral_constant<int, 3>{}, full_c);
+            if constexpr (NSLOT > 4) one(std::integral_constant<int, 4>{}, full_c);
+            if constexpr (NSLOT > 5) one(std::integral_constant<int, 5>{}, full_c);
+            if constexpr (NSLOT > 6) one(std::integral_constant<int, 6>{}, full_c);
         };
-        while (kt + 2 * D <= nk) group(std::true_type{});                        // every k-step of the group has kt + D < nk
-        while (kt < nk) {                                                        // at most 2 D - 1 k-steps, guarded individually
-            // (a group is entered at ring slot 0, so slot d holds k-step kt + d here as well)
+        while (kt + NSLOT + D <= nk) group(std::true_type{});                    // every k-step of the group has kt + D < nk
+        while (kt < nk) {                                                        // fewer than NSLOT + D k-steps, guarded individually
+            // (a group is entered at ring slot 0, so slot c holds k-step kt + c here as well)
             const int k0 = kt;
-            auto tail_one = [&](auto d_c) { if (k0 + decltype(d_c)::value < nk) one(d_c, std::false_type{}); };
+            auto tail_one = [&](auto c_c) { if (k0 + decltype(c_c)::value < nk) one(c_c, std::false_type{}); };
             tail_one(std::integral_constant<int, 0>{});
-            if constexpr (D > 1) tail_one(std::integral_constant<int, 1>{});
-            if constexpr (D > 2) tail_one(std::integral_constant<int, 2>{});
-            if constexpr (D > 3) tail_one(std::integral_constant<int, 3>{});
-            if constexpr (D > 4) tail_one(std::integral_constant<int, 4>{});
-            if constexpr (D > 5) tail_one(std::integral_constant<int, 5>{});
+            tail_one(std::integral_constant<int, 1>{});
+            tail_one(std::integral_constant<int, 2>{});
+            if constexpr (NSLOT > 3) tail_one(std::integral_constant<int, 3>{});
+            if constexpr (NSLOT > 4) tail_one(std::integral_constant<int, 4>{});
+            if constexpr (NSLOT > 5) tail_one(std::integral_constant<int, 5>{});
+            if constexpr (NSLOT > 6) tail_one(std::integral_constant<int, 6>{});
         }
         stamp(2);
     }
@@ -335,8 +386,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
         };
 
-        // fp16 outlier tail operands: 16 x 32 fragments, lane = row lm, columns kk*32 + lq*8 .. +8.  Two register sets.
-        u32x4 xoq[2][MB], woq[2][WNB];
+        // fp16 outlier tail operands: 16 x 32 fragments, lane = row lm, columns kk*32 + lq*8 .. +8.  TD register sets: with two,
+        // the operands of tail k-step kk+1 are in flight behind the MFMAs of kk; the fattest tiles only have room for one.
+        constexpr int TD = (MB * WNB * 4 + 2 * (MB + WNB) * 4 + 40 > 256) ? 1 : 2;
+        u32x4 xoq[TD][MB], woq[TD][WNB];
         auto tail_load = [&](int P, int kk) {              // P: constant after unrolling
             const int kb = kk * 32 + lq * 8;
             const bool in = kb < kpad;                     // chunks past the padded width are not addressable: zeros
@@ -351,7 +404,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 woq[P][i] = in ? *reinterpret_cast<const u32x4*>(a.wo + static_cast<size_t>(wr) * a.ldwo + kb) : u32x4{0, 0, 0, 0};
             }
         };
-        if (ksteps > 0) tail_load(0, 0);
+        if (TD > 1 && ksteps > 0) tail_load(0, 0);
         __builtin_amdgcn_s_barrier();                                            // every wave is done reading the ring
         stamp(6);
 
@@ -390,13 +443,17 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     fa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, woq[P][i]),
                                                                       __builtin_bit_cast(f16x8, xoq[P][j]), fa[j][i], 0, 0, 0);
         };
-        if (ksteps > 1) tail_load(1, 1);
-        for (int kk0 = 0; kk0 < ksteps; kk0 += 2) {
-            tail_mma(0, kk0);
-            if (kk0 + 2 < ksteps) tail_load(0, kk0 + 2);
-            if (kk0 + 1 < ksteps) {
-                tail_mma(1, kk0 + 1);
-                if (kk0 + 3 < ksteps) tail_load(1, kk0 + 3);
+        if constexpr (TD == 1) {
+            for (int kk = 0; kk < ksteps; ++kk) { tail_load(0, kk); tail_mma(0, kk); }
+        } else {
+            if (ksteps > 1) tail_load(TD - 1, 1);
+            for (int kk0 = 0; kk0 < ksteps; kk0 += 2) {
+                tail_mma(0, kk0);
+                if (kk0 + 2 < ksteps) tail_load(0, kk0 + 2);
+                if (kk0 + 1 < ksteps) {
+                    tail_mma(TD - 1, kk0 + 1);
+                    if (kk0 + 3 < ksteps) tail_load(TD - 1, kk0 + 3);
+                }
             }
         }
 
@@ -476,16 +533,18 @@ struct WrConfig {
     void (*k8)(const WrArgs);
     void (*k4)(const WrArgs);
 };
+// (the int4 form expands nibbles in registers: 2 (MB + WNB) more fragment registers, so its weight ring is at most 4 deep)
 #define MIXQ_WR(MBv, WNBv, NS, Dv, LD, ABL, TAG)                                                                        \
-    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, false, LD, ABL>, gemm_wreg_kernel<MBv, WNBv, NS, Dv, true, LD, ABL> }
+    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, false, LD, ABL>,                                 \
+      gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), true, LD, ABL> }
 
 const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 8, 4, 1, 0, "128x192_s8_d4_l1"),     // 0: the metric shape's tile: 232 tiles at 512 x 11008
     MIXQ_WR(8, 3, 8, 4, 2, 0, "128x192_s8_d4_l2"),     // 1
-    MIXQ_WR(8, 3, 6, 3, 1, 0, "128x192_s6_d3_l1"),     // 2
+    MIXQ_WR(8, 3, 8, 3, 1, 0, "128x192_s8_d3_l1"),     // 2
     MIXQ_WR(8, 3, 8, 6, 1, 0, "128x192_s8_d6_l1"),     // 3
     MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 4
-    MIXQ_WR(8, 4, 8, 3, 1, 0, "128x256_s8_d3_l1"),     // 5
+    MIXQ_WR(8, 4, 8, 3, 1, 0, "128x256_s8_d3_l1"),     // 5 (int4: ring depth 2)
     MIXQ_WR(4, 2, 8, 4, 1, 0, "64x128_s8_d4_l1"),      // 6: N = 4096 at M = 512 is exactly 256 such tiles
     MIXQ_WR(4, 3, 8, 4, 1, 0, "64x192_s8_d4_l1"),      // 7: N = 6144
     MIXQ_WR(4, 4, 8, 4, 1, 0, "64x256_s8_d4_l1"),      // 8
@@ -496,8 +555,6 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 8, 4, 1, 3, "128x192_abl3_mfma"),    // 13: cfg 0, MFMA + epilogue only
 };
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
-constexpr int WR_MAX_DEV = 16;
-bool g_wr_attr[NUM_WR][2][WR_MAX_DEV];
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -542,14 +599,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     void (*k)(const WrArgs) = bit == 8 ? g.k8 : g.k4;
     const size_t ring = static_cast<size_t>(g.nstage) * g.mb * 1024, stg = static_cast<size_t>(bm) * (bn * 2 + 16);
     const size_t shm = ring > stg ? ring : stg;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WR_MAX_DEV) { (void)hipGetLastError(); return MIXQ_ENODEV; }
-    bool& done = g_wr_attr[c][bit == 8 ? 0 : 1][dev];
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
-        if (e != hipSuccess) return static_cast<int>(e);
-        done = true;
-    }
+    if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3((WR_CW + g.loaders) * 64), shm, st, a);
     return mixq_launch_status();
 }

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(QT) void repack_kernel(const uint8_t* __restrict__ 
     const int rb = rem >> 6;
     int r, c;
     if (fmt == MIXQ_FMT_F16X64) { c = (rem >> 4) & 3; r = rem & 15; }
-    else                        { r = (rem >> 2) & 15; c = (rem & 3) ^ ((r >> 2) & 3); }
+    else                        { r = (rem >> 2) & 15; c = (rem & 3) ^ ((0 - (r >> 2)) & 3); }
     const int row = rb * 16 + r;
     const size_t plain = static_cast<size_t>(row) * KB + kb * 64 + c * 16;
     if constexpr (UNPACK) {

@@ -6,10 +6,12 @@ The reference does `from EETQ import quant_weights, preprocess_weights, w8_a16_g
 UNPINNED; the quantisation rule restated here is the published one it wraps (FasterTransformer's symmetric per-column
 int8: scale = colabsmax / 128, q = clip(round_half_away(w / scale), -128, 127)).
 
-Difference from EETQ, by design: `q_weight` stays the plain row-major int8 [K,N] matrix (EETQ's *unprocessed* tensor);
-the CUTLASS-specific interleaving EETQ bakes into the checkpoint has no meaning on CDNA4.  The kernel's own tile-major
-copy is built on the device on first use (`mixlib.PackW8A16`).  `sys.modules["EETQ"] = mixq_amd.eetq` makes
-reference-style code run.
+Difference from EETQ, by design: in memory `q_weight` is the plain row-major int8 [K,N] matrix (EETQ's *unprocessed*
+tensor): the CUTLASS-specific interleaving EETQ bakes into its checkpoints has no meaning on CDNA4, and the kernel's own
+tile-major copy is built on the device on first use (`mixlib.PackW8A16`).  On DISK either layout is handled:
+`preprocess_weights` / `unprocess_weights` restate EETQ's interleave and its inverse, and mixq_amd.checkpoint records
+which one a checkpoint holds (`quant_config.json: "w8a16_layout"`), converting reference checkpoints on load.
+`sys.modules["EETQ"] = mixq_amd.eetq` makes reference-style code run.
 """
 import torch
 
@@ -40,9 +42,48 @@ def quant_weights(weight, dtype=torch.int8, return_unprocessed_quantized_tensor=
     return q, scale.to(weight.dtype)
 
 
+_PERM16 = (0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15)
+
+
 def preprocess_weights(q_weight, *args, **kwargs):
-    """EETQ permutes for its CUTLASS kernels here; the gfx950 kernel re-tiles on first use instead."""
-    return q_weight
+    """EETQ's `preprocess_weights`: the plain int8 [K,N] matrix -> the CUTLASS mixed-GEMM image EETQ bakes into its checkpoints
+    (what `quant_weights(..., return_unprocessed_quantized_tensor=False)` returns and the reference stores as `q_weight`,
+    modules/linear.py:102-106).  Restated from the published FasterTransformer routine EETQ wraps
+    (`preprocess_weights_for_mixed_gemm`, int8, sm75-sm90): (1) inside every 16 k-rows the order 0 1 8 9 2 3 10 11 4 5 12 13
+    6 7 14 15 (the ldmatrix/IMMA fragment order), (2) transpose to column-major [N,K], (3) interleave column pairs per
+    64-element k tile: [N/2][K/64][2][64], (4) +128 (offset binary) and swap bytes 1 and 2 of every 4.  PARITY UNPINNED: EETQ is
+    not part of the reference tree and pins no version; the gfx950 kernels never read this image - it exists so reference
+    weight-only checkpoints can be loaded (`unprocess_weights`) and written."""
+    q = q_weight
+    if q.dtype != torch.int8 or q.dim() != 2:
+        raise ValueError("preprocess_weights: expected an int8 [K,N] tensor")
+    K, N = q.shape
+    if K % 64 or N % 2:
+        raise ValueError("preprocess_weights: K must be a multiple of 64 and N even (the CUTLASS tile interleave)")
+    dev = q.device
+    rows = (torch.arange(K, device=dev) // 16) * 16 + torch.tensor(_PERM16, device=dev).repeat(K // 16)
+    t = q[rows].t().contiguous()                                          # (1), (2): [N,K]
+    t = t.reshape(N // 2, 2, K // 64, 64).permute(0, 2, 1, 3).contiguous()    # (3)
+    u = (t.to(torch.int16) + 128).to(torch.uint8).reshape(-1, 4)[:, [0, 2, 1, 3]].contiguous()   # (4)
+    return u.view(torch.int8).reshape(K, N)
+
+
+def unprocess_weights(processed):
+    """Inverse of `preprocess_weights`: a reference checkpoint's weight-only `q_weight` -> the plain int8 [K,N] matrix."""
+    p = processed
+    if p.dtype != torch.int8 or p.dim() != 2:
+        raise ValueError("unprocess_weights: expected an int8 [K,N] tensor")
+    K, N = p.shape
+    if K % 64 or N % 2:
+        raise ValueError("unprocess_weights: K must be a multiple of 64 and N even")
+    dev = p.device
+    u = p.contiguous().view(torch.uint8).reshape(-1, 4)[:, [0, 2, 1, 3]]
+    t = (u.to(torch.int16) - 128).to(torch.int8).reshape(N // 2, K // 64, 2, 64).permute(0, 2, 1, 3).reshape(N, K)
+    q_perm = t.t().contiguous()                                           # rows still in fragment order
+    rows = (torch.arange(K, device=dev) // 16) * 16 + torch.tensor(_PERM16, device=dev).repeat(K // 16)
+    q = torch.empty_like(q_perm)
+    q[rows] = q_perm
+    return q
 
 
 def packed_weight(q_weight):

@@ -283,7 +283,7 @@ class MixLinear_GEMM(nn.Module):
     def x_fmt(self):
         """Layout this layer wants its quantised activation in (what a fused norm in front of it should emit)."""
         wpk = self._packed_weight()
-        return _fmt_of(wpk) if wpk is not None else FMT_PLAIN
+        return FMT_P16X64 if wpk is not None else FMT_PLAIN         # (fragment-order weights go with P16X64 activations too)
 
     def _packed_weight(self):
         """q_weight in the tile-major layout the GEMM streams fastest (include/mixq_hip.h); rebuilt when the buffer is
@@ -347,7 +347,7 @@ class MixLinear_GEMM(nn.Module):
         wpk = self._packed_weight()
         qx = cache.q_xcache
         w = wpk if wpk is not None else self.q_weight
-        want = _fmt_of(w)
+        want = self.x_fmt()
         if _fmt_of(qx) != want and hasattr(_backend, "PackOperand"):
             # the producer of q_xcache (e.g. the reference's own fused norm through the mixlib shim) used another layout
             if _fmt_of(qx) != FMT_PLAIN:

@@ -15,8 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import _capi
-from ._capi import (ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, X_PACKED, W_PACKED, X_F16X64,
-                    W_F16X64)
+from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, X_PACKED, W_PACKED, W_F16X64
 
 
 def _dev_check(*ts):
@@ -67,8 +66,9 @@ def fmt_of(t):
 
 
 def _layout_bits(x_fmt, w_fmt):
-    return ({FMT_PLAIN: 0, FMT_P16X64: X_PACKED, FMT_F16X64: X_F16X64}[x_fmt] |
-            {FMT_PLAIN: 0, FMT_P16X64: W_PACKED, FMT_F16X64: W_F16X64}[w_fmt])
+    if x_fmt == FMT_F16X64:
+        raise RuntimeError("mixq_amd.mixlib: F16X64 is a weight format; the GEMMs take activations plain or in P16X64")
+    return ({FMT_PLAIN: 0, FMT_P16X64: X_PACKED}[x_fmt] | {FMT_PLAIN: 0, FMT_P16X64: W_PACKED, FMT_F16X64: W_F16X64}[w_fmt])
 
 
 # ------------------------------------------------------------------------------------------------------------

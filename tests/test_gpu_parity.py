@@ -217,8 +217,9 @@ def _fused_case(M, N, K, bit, seed, n_out, bias, addend, act):
 
 
 def _run_fused(c, packed, n_dev_cap=0):
-    """packed: 0 / False plain, 1 / True P16x64, 2 F16x64.  n_dev_cap > 0: hand the kernel outlier operands of that CAPACITY
-    (poison beyond the real count) with the count itself in device memory."""
+    """packed: 0 / False plain, 1 / True P16x64, 2 = weights F16x64 (fragment order) with P16x64 activations: the operand pair of
+    the weights-in-registers kernels.  n_dev_cap > 0: hand the kernel outlier operands of that CAPACITY (poison beyond the
+    real count) with the count itself in device memory."""
     M, N, K, bit = c["M"], c["N"], c["K"], c["bit"]
     fmt = int(packed)
     n_out = int(c["ind"].size)
@@ -235,7 +236,7 @@ def _run_fused(c, packed, n_dev_cap=0):
             n_dev = torch.tensor([n_out], dtype=torch.int32, device=DEV)
     qx, qw = t(c["qx"]), t(c["qw"])
     if fmt:
-        qx, qw = mixlib.PackOperand(qx, fmt), mixlib.PackOperand(qw, fmt)
+        qx, qw = mixlib.PackOperand(qx, 1), mixlib.PackOperand(qw, fmt)
     sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV); sx[:, 0] = t(c["sx"])
     return mixlib.FusedLinear(qx, qw, sx, t(c["sw"]), xo, wo, cap, None if c["bias"] is None else t(c["bias"]), M, N, K, bit=bit,
                               act=c["act"], addend=None if c["addend"] is None else t(c["addend"]), n_out_dev=n_dev)
@@ -382,7 +383,7 @@ def test_full_size_int32_checksum_and_rows(K, N):
     sw = torch.full((1, N), 2.0 ** -6, dtype=torch.float16, device=DEV)
     want = (y.to(torch.float64) * 2.0 ** -12).to(torch.float16)
     for fmt in (1, 2):
-        yp = mixlib.FusedLinear(mixlib.PackOperand(qx.to(DEV), fmt), mixlib.PackOperand(qw.to(DEV), fmt), sx, sw, None, None, 0, None, M, N, K)
+        yp = mixlib.FusedLinear(mixlib.PackOperand(qx.to(DEV), 1), mixlib.PackOperand(qw.to(DEV), fmt), sx, sw, None, None, 0, None, M, N, K)
         assert torch.equal(yp, want), fmt
 
 
@@ -799,7 +800,7 @@ def test_randomized_shapes_all_tilings_bit_exact():
             assert lib.mixq_gemm_set_config(cfg) == 0
             for rep in range(3):
                 keep.append(torch.empty((case * 3 + rep + 1) * 1_000_003, dtype=torch.uint8, device=DEV))   # shift addresses
-                qxp, qwp = mixlib.PackOperand(t(qx), fmt), mixlib.PackOperand(t(qw), fmt)
+                qxp, qwp = mixlib.PackOperand(t(qx), 1), mixlib.PackOperand(t(qw), fmt)
                 y = n(mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K))
                 assert np.array_equal(bits(y), bits(want16)), (names[cfg], M, N, K, rep)
             if len(keep) > 24:
@@ -1176,7 +1177,7 @@ def test_wreg_kernel_under_graph_replay_and_cold_buffers():
         for cfg in _wr_configs():
             assert lib.mixq_gemm_set_config(cfg) == 0
             keep.append(torch.empty((len(keep) + 1) * 2_000_003, dtype=torch.uint8, device=DEV))
-            qxp, qwp = mixlib.PackOperand(qx, 2), mixlib.PackOperand(qw, 2)
+            qxp, qwp = mixlib.PackOperand(qx, 1), mixlib.PackOperand(qw, 2)
             out = torch.empty((M, N), dtype=torch.float16, device=DEV)
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):
@@ -1324,3 +1325,43 @@ def test_packed_only_weights_state_dict_and_memory():
     assert layer._buffers["q_weight"] is None
     got = mixlib.DequantWeightCols(layer.q_weight, layer.scale_col, torch.tensor([3, 500], dtype=torch.int32, device=DEV), 8)
     assert np.array_equal(bits(n(got)), bits(O.dequant_weight_cols(n(q0), n(layer.scale_col), np.array([3, 500], np.int32), 8)))
+
+
+def test_wreg_every_k_step_count_every_tiling():
+    """The weights-in-registers k loop is unrolled by the ring depth with hand-counted vmcnt waits and a guarded tail: every number
+    of k-steps from 1 to 24 (and a few long ones) through every tiling, int8 and int4, exact against the integer product."""
+    lib = _capi.load()
+    names = _capi.gemm_config_names()
+    rng = np.random.default_rng(11)
+    M, N = 80, 136
+    sx = torch.full((M, 1), 2.0 ** -7, dtype=torch.float16, device=DEV)
+    sw = torch.full((1, N), 2.0 ** -7, dtype=torch.float16, device=DEV)
+    try:
+        for nk in list(range(1, 25)) + [31, 47, 64, 65]:
+            K = 64 * nk
+            qx = rng.integers(-127, 128, size=(M, K), dtype=np.int8)
+            qw = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+            want16 = ((qx.astype(np.int64) @ qw.astype(np.int64).T).astype(np.float64) * 2.0 ** -14).astype(np.float16)
+            qxp, qwp = mixlib.PackOperand(t(qx), 1), mixlib.PackOperand(t(qw), 2)
+            # int4: K/2 bytes per row hold K nibbles; the same byte images read as nibble pairs give another exact problem
+            lo = lambda b: np.where((b & 0xF) >= 8, (b & 0xF).astype(np.int64) - 16, (b & 0xF).astype(np.int64))
+            hi = lambda b: np.where((b >> 4) >= 8, (b >> 4).astype(np.int64) - 16, (b >> 4).astype(np.int64))
+            bx, bw = qx.view(np.uint8), qw.view(np.uint8)
+            want4 = ((lo(bx) @ lo(bw).T + hi(bx) @ hi(bw).T).astype(np.float64) * 2.0 ** -6).astype(np.float16)
+            sx4 = torch.full((M, 1), 2.0 ** -3, dtype=torch.float16, device=DEV)
+            sw4 = torch.full((1, N), 2.0 ** -3, dtype=torch.float16, device=DEV)
+            for cfg in _wr_configs():
+                assert lib.mixq_gemm_set_config(cfg) == 0
+                y = n(mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K))
+                assert np.array_equal(bits(y), bits(want16)), (names[cfg], nk, "int8")
+                y4 = n(_i4_call(qxp, qwp, sx4, sw4, M, N, K))
+                assert np.array_equal(bits(y4), bits(want4)), (names[cfg], nk, "int4")
+    finally:
+        lib.mixq_gemm_set_config(-1)
+
+
+def _i4_call(qxp, qwp, sx4, sw4, M, N, K):
+    """The packed int8 images re-read as nibble-packed int4 operands of logical depth 2K (the tag travels with the view)."""
+    a, b = qxp.view(torch.uint8), qwp.view(torch.uint8)
+    mixlib.set_fmt(a, 1); mixlib.set_fmt(b, 2)
+    return mixlib.FusedLinear(a, b, sx4, sw4, None, None, 0, None, M, N, 2 * K, bit=4)

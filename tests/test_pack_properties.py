@@ -10,7 +10,7 @@ from oracle import oracle as O
 
 def p16x64_reference(q):
     """Straight restatement of the P16x64 layout of include/mixq_hip.h: [KB/64][rows16/16] blocks of 16 rows x 64 B,
-    the four 16-byte chunks of row r stored at position c ^ ((r>>2)&3); rows >= R zero."""
+    the four 16-byte chunks of row r stored at position c ^ (-(r>>2) & 3); rows >= R zero."""
     R, KB = q.shape
     rows16 = (R + 15) // 16 * 16
     out = np.zeros(rows16 * KB, dtype=np.uint8)
@@ -19,7 +19,7 @@ def p16x64_reference(q):
         for kb in range(KB // 64):
             base = (kb * (rows16 // 16) + row // 16) * 1024 + (row % 16) * 64
             for c in range(4):
-                pc = c ^ (((row % 16) >> 2) & 3)
+                pc = c ^ ((-((row % 16) >> 2)) & 3)
                 out[base + pc * 16: base + pc * 16 + 16] = src[row, kb * 64 + c * 16: kb * 64 + c * 16 + 16]
     return out
 
@@ -31,7 +31,7 @@ def p16x64_unpack(buf, R, KB):
         for kb in range(KB // 64):
             base = (kb * (rows16 // 16) + row // 16) * 1024 + (row % 16) * 64
             for c in range(4):
-                pc = c ^ (((row % 16) >> 2) & 3)
+                pc = c ^ ((-((row % 16) >> 2)) & 3)
                 out[row, kb * 64 + c * 16: kb * 64 + c * 16 + 16] = buf[base + pc * 16: base + pc * 16 + 16]
     return out
 
@@ -117,8 +117,13 @@ def test_p16x64_layout_is_a_bijection(rows, kblocks, seed):
     # lands on 16 distinct 16-byte bank slots of the 256-byte LDS bank row
     for group in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
         for c in range(4):
-            slots = {((r * 64 + ((c ^ ((r >> 2) & 3)) * 16)) // 16) % 16 for r in group}
+            slots = {((r * 64 + ((c ^ ((-(r >> 2)) & 3)) * 16)) // 16) % 16 for r in group}
             assert len(slots) == 16
+    # ... and so does the 16x16x64 fragment of gemm_wreg.hip: lane l reads row l & 15, chunk l >> 4 of ONE block
+    for group in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+                  [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59], [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63]):
+        slots = {(((l & 15) * 64 + (((l >> 4) ^ ((-((l & 15) >> 2)) & 3)) * 16)) // 16) % 16 for l in group}
+        assert len(slots) == 16
 
 
 @settings(max_examples=40, deadline=None)

@@ -77,7 +77,7 @@ def test_eetq_surface_w8_a16_gemm():
     torch.manual_seed(1)
     w = (torch.randn(128, 32) * 0.1).half()
     q, s = eetq.quant_weights(w, torch.int8, False)
-    assert eetq.preprocess_weights(q) is q
+    assert torch.equal(eetq.unprocess_weights(eetq.preprocess_weights(q)), q)
     x = torch.randn(3, 5, 128).half()
     y = eetq.w8_a16_gemm(x, q, s)
     assert y.shape == (3, 5, 32)
@@ -104,3 +104,72 @@ def test_gptj_policy_quantises_fc_out_weight_only(tmp_path):
         assert torch.equal(v, fresh.state_dict()[k])
     x = torch.randn(4, 256).half()
     assert torch.equal(m.fc_out(x), fresh.fc_out(x))
+
+
+def _ft_preprocess_int8(qn):
+    """Independent, loop-for-loop restatement of FasterTransformer's published preprocess_weights_for_mixed_gemm for int8 on
+    sm75-sm90 (the routine EETQ's preprocess_weights wraps): permute_B_rows_for_mixed_gemm, subbyte_transpose,
+    interleave_column_major_tensor (64 rows per tile, 2 columns interleaved), add_bias_and_interleave_int8s_inplace."""
+    K, N = qn.shape
+    a = np.zeros_like(qn)
+    for base in range(0, K, 16):
+        for tr in range(16):
+            a[base + tr] = qn[base + 8 * ((tr % 4) // 2) + tr % 2 + 2 * (tr // 4)]
+    tv = a.T.copy().view(np.uint32).reshape(-1)                       # column-major [N,K], 4 k-elements per word
+    nvr = K // 4
+    out = np.zeros_like(tv)
+    for rc in range(N):
+        for bvr in range(0, nvr, 16):
+            for vr in range(bvr, min(nvr, bvr + 16)):
+                out[(rc // 2) * nvr * 2 + 2 * bvr + 16 * (rc % 2) + vr % 16] = tv[rc * nvr + vr]
+    b = (out.view(np.int8).astype(np.int16) + 128).astype(np.uint8)
+    for i in range(0, b.size, 4):
+        b[i + 1], b[i + 2] = b[i + 2], b[i + 1]
+    return b.view(np.int8).reshape(K, N)
+
+
+def test_eetq_interleave_matches_the_published_routine_and_inverts():
+    torch.manual_seed(0)
+    for K, N in [(64, 2), (128, 12), (256, 64)]:
+        q = torch.randint(-128, 128, (K, N), dtype=torch.int8)
+        p = eetq.preprocess_weights(q)
+        assert p.shape == q.shape and p.dtype == torch.int8
+        assert np.array_equal(p.numpy(), _ft_preprocess_int8(q.numpy()))
+        assert torch.equal(eetq.unprocess_weights(p), q)
+    with pytest.raises(ValueError):
+        eetq.preprocess_weights(torch.zeros(100, 8, dtype=torch.int8))
+
+
+def test_weight_only_checkpoint_in_the_references_layout(tmp_path):
+    """A weight-only layer's q_weight is EETQ's interleaved image in a reference checkpoint and the plain matrix in ours, under the
+    same key / shape / dtype: quant_config.json says which; a missing key means "written by the reference"."""
+    import json
+    from mixq_amd import checkpoint as ck
+    from mixq_amd import MixLibCache
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc_out = torch.nn.Linear(128, 64, bias=True)
+    torch.manual_seed(0)
+    m = Blk().half()
+    cache = MixLibCache(8, device="cpu")
+    m.fc_out = MixLinear_GEMM.from_linear(m.fc_out, 8, weight_only=True, cache=cache, dev="cpu", name="fc_out")
+    plain = m.fc_out.q_weight.clone()
+    for layout in ("plain", "eetq"):
+        d = tmp_path / layout
+        ck.save_quantized(m, str(d), {"w_bit": 8}, w8a16_layout=layout)
+        cfg = json.load(open(d / "quant_config.json"))
+        assert cfg["w8a16_layout"] == layout
+        on_disk = ck.load_state_dict_files(str(d))["fc_out.q_weight"]
+        assert torch.equal(on_disk, plain if layout == "plain" else eetq.preprocess_weights(plain))
+        if layout == "eetq":                                           # what the reference itself writes: no key at all
+            cfg.pop("w8a16_layout")
+            json.dump(cfg, open(d / "quant_config.json", "w"))
+        fresh = Blk().half()
+        fresh.fc_out = MixLinear_GEMM(128, 64, True, "cpu", bit=8, weight_only=True, cache=cache)
+        sd = ck.load_state_dict_files(str(d))
+        if cfg.get("w8a16_layout", "eetq") == "eetq":
+            sd["fc_out.q_weight"] = eetq.unprocess_weights(sd["fc_out.q_weight"])
+        fresh.load_state_dict(sd)
+        assert torch.equal(fresh.fc_out.q_weight, plain)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Tripwire for the hand-counted weight loads of gemm_wreg.hip (cdna_hip_programming.md section 5.7 item 1: the compiler does not
+know an inline-asm load's destination is in flight, so a spill, copy or re-use of that register before the matching wait
+would read garbage).  Compiles the file with -save-temps and, per kernel, collects every VGPR an asm global_load writes and
+flags any COMPILER instruction that copies or spills one of them: v_mov_b32 / v_mov_b64 / v_accvgpr_write reading it, any
+scratch_* naming it.  (MFMAs read them legitimately, behind the s_waitcnt statements that name them.)  Exit code 1 on a hit."""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "mixq_amd", "csrc", "gemm_wreg.hip")
+
+
+def regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-save-temps", "-o", "x.o"], cwd=td,
+                              stderr=subprocess.DEVNULL)
+        text = open(os.path.join(td, "gemm_wreg-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    bad = 0
+    for m in re.finditer(r"^(_ZN\S*gemm_wreg_kernel\S*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        lines = body.split("\n")
+        loaded, in_asm = set(), False
+        for ln in lines:
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"): in_asm = True
+            elif t.startswith(";;#ASMEND"): in_asm = False
+            elif in_asm and t.startswith("global_load_dwordx4"):
+                loaded |= regs(t.split()[1].rstrip(","))
+        # the k loop and its tail: from the first hand-placed wait to the last one
+        first = last = None
+        in_asm = seen_load = False
+        for i, ln in enumerate(lines):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"): in_asm = True
+            elif t.startswith(";;#ASMEND"): in_asm = False
+            elif in_asm and t.startswith("global_load_dwordx4"): seen_load = True
+            elif in_asm and t.startswith("s_waitcnt vmcnt") and seen_load:       # (the loader wave's own waits come before any ring load)
+                if first is None: first = i            # (the prologue gives every slot a defined value BEFORE its first load: harmless copies)
+                if any("sched_barrier" in x for x in lines[i:i + 4]): last = i    # a ring wait (the trace drain at the very end is not)
+        hits, in_asm, in_loop = [], False, False
+        for i, ln in enumerate(lines):
+            if re.match(r"^\.LBB\d+_\d+:", ln) or "Loop Header" in ln:
+                # basic blocks the compiler marks as part of a loop: the unrolled k loop and its guarded tail.  (Blocks outside
+                # loops re-use the same physical registers for other values on other paths; text alone cannot tell those apart.)
+                in_loop = ("Loop Header" in ln) or ("in Loop:" in ln) or (in_loop and "=>This" in ln)
+            if "Loop Header" in ln: in_loop = True
+            if first is None or last is None or i < first or i > last or not in_loop:
+                t = ln.strip()
+                if t.startswith(";;#ASMSTART"): in_asm = True
+                elif t.startswith(";;#ASMEND"): in_asm = False
+                continue
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"): in_asm = True; continue
+            if t.startswith(";;#ASMEND"): in_asm = False; continue
+            if in_asm or not t or t.startswith((";", ".")): continue
+            op = t.split()[0]
+            toks = [x.strip(",") for x in t.split()[1:]]
+            if op.startswith("scratch_"):
+                if any(regs(x) & loaded for x in toks): hits.append((i, t))
+            elif op.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr_write")):
+                if any(regs(x) & loaded for x in toks[1:]): hits.append((i, t))          # a SOURCE in the ring
+        sc = re.search(r"; ScratchSize: (\d+)", body)
+        tag = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)", name).groups()
+        abl = tag[6] != "0"
+        print(f"MB={tag[0]} WNB={tag[1]} NSTAGE={tag[2]} D={tag[3]} I4={tag[4]} L={tag[5]} ABL={tag[6]}: ring registers {len(loaded)}, "
+              f"suspicious {len(hits)}" + ("  (ablation build: ignored)" if abl and hits else ""))
+        for i, t in hits[:6]:
+            print("     line", i, t)
+        if hits and not abl:
+            bad += 1
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--cfgs", default="all")
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--packed", default="0,1,2", help="operand formats to try: 0 plain, 1 P16x64, 2 F16x64")
+    ap.add_argument("--packed", default="0,1,2", help="operand formats to try: 0 plain, 1 P16x64, 2 weights F16x64 + activations P16x64")
     ap.add_argument("--out", default="gpurun_out/sweep_gemm.json")
     ap.add_argument("--nout", type=int, default=0, help="outlier columns fed to the fp16 tail (timing; the error check ignores them)")
     args = ap.parse_args()
@@ -90,7 +90,7 @@ def main():
         packs = {0: (qx, qw)}
         if can_pack:
             packs[1] = (mixlib.PackOperand(qx, 1), mixlib.PackOperand(qw, 1))       # P16x64
-            packs[2] = (mixlib.PackOperand(qx, 2), mixlib.PackOperand(qw, 2))       # F16x64 (gemm_wreg.hip, decode32)
+            packs[2] = (packs[1][0], mixlib.PackOperand(qw, 2))                     # weights F16x64 (gemm_wreg.hip, decode32)
         xo = wo = None
         if args.nout:
             pad = (args.nout + 15) // 16 * 16

@@ -16,7 +16,7 @@ for (M, K) in shapes:
     x = torch.randn(nb, M, K, device=dev).half()
     for n_out in (0, round(0.01 * K)):
         ind = torch.randperm(K)[:n_out].to(torch.int32).to(dev) if n_out else None
-        for fmt in (0, 2):
+        for fmt in (0, 1, 2):
             for bit in (8, 4):
                 row = []
                 for cfg in range(len(NAMES)):
