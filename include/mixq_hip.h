@@ -224,6 +224,9 @@ int mixq_quant_set_config(int cfg);
  * done, 3 epilogue arithmetic done, 4 stores issued, 5 stores retired, 6/7 inside the epilogue; 8 + i = s_memtime
  * at the same points.  buf needs 128 bytes per workgroup (tools/trace_gemm.py). */
 int mixq_gemm_set_trace(unsigned long long* buf);
+/* Tuning: the weights-in-registers kernels start the K walk of N tile t at k-step (t * krot) mod (K/64) and wrap around (integer
+ * accumulation is order-independent: results are bit-identical for every value).  0 = every tile starts at k = 0. */
+int mixq_gemm_set_krot(int krot);
 /* Diagnostics: exhaustive self-test of the division-free quantiser used by the quantise kernels (q = rint(x / s) for all
  * finite fp16 x and all finite fp16 s > 0, ~2e9 pairs, ~1 s): adds the number of disagreements with the IEEE-division form
  * to *mismatches_dev (a zeroed device counter).  bit = 8 or 4. */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mixq_dequant": [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "mixq_gemm_set_config": [_I],
     "mixq_gemm_set_trace": [_P],
+    "mixq_gemm_set_krot": [_I],
     "mixq_selftest_quant_exact": [_P, _I, _P],
     "mixq_gemm_num_configs": [],
     "mixq_pack_p16x64": [_P, _P, _I, _I, _P],

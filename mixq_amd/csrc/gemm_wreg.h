@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 int mixq_wr_num_configs();
+int mixq_wr_set_krot(int v);                 // k-step rotation between neighbouring N tiles (tuning; results do not depend on it)
 const char* mixq_wr_config_name(int c);
 // config for (M, N, KB) or -1 when the data-parallel kernels of gemm.hip should run instead
 int mixq_wr_pick(int bit, int M, int N, int KB);

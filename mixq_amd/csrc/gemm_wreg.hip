@@ -43,6 +43,7 @@ struct WrArgs {
     int ldxo, ldwo, n_out, lda, ldy, act;
     int tiles_m, tiles_n;
     int xblocks, wblocks;                             // 16-row blocks per k-step of each operand
+    int krot;                                         // k-step rotation between neighbouring N tiles (0: every tile starts at k = 0)
     unsigned long long* trace;
 };
 
@@ -58,7 +59,8 @@ __device__ __forceinline__ float wr_silu(float v) { return v * __builtin_amdgcn_
 
 // MB: 16-row activation blocks per tile (BM = 16 MB), WNB: 16-row weight blocks per wave (BN = 64 WNB), NSTAGE: X ring depth,
 // D: weight register ring depth (k-steps), I4: nibble-packed operands, LOADERS: DMA waves, ABL (tuning): 0 normal,
-// 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only.
+// 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only, 4 weight loads issued but never waited for, 5 the loader
+// never waits for its DMA, 6 no k-loop barriers (4-6: timing probes, results are garbage).
 template <int MB, int WNB, int NSTAGE, int D, bool I4, int LOADERS, int ABL>
 __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const WrArgs a)
 {
@@ -85,6 +87,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
     const int nk = a.KB >> 6;
+    // Integer accumulation is exact in any order, so a tile may walk K from any starting k-step and wrap around.  Tiles of one
+    // weight panel (same tn) start together - they share the panel's bytes in their XCD's L2 - while neighbouring panels start
+    // krot k-steps apart, so the CUs of an XCD are not all asking the L2 for the same activation slab at the same moment.
+    const int rot = nk > 1 ? (tn * a.krot) % nk : 0;
     auto stamp = [&](int slot) {
         if (a.trace && tid == 0) {
             a.trace[blockIdx.x * 16 + slot] = wall_clock64();
@@ -109,11 +115,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             dsto[i] = p * 1024;
         }
         const size_t xks = static_cast<size_t>(a.xblocks) * 1024;
+        int xk = rot;                                    // k-step the next stage reads
+        size_t xoff = static_cast<size_t>(rot) * xks;
         auto stage = [&](int slot) {
             if constexpr (ABL != 2 && ABL != 3) {
 #pragma unroll
-                for (int i = 0; i < LOADS; ++i) { wr_glds16(src[i], lds + slot * STAGE_BYTES + dsto[i]); src[i] += xks; }
+                for (int i = 0; i < LOADS; ++i) wr_glds16(src[i] + xoff, lds + slot * STAGE_BYTES + dsto[i]);
             }
+            xoff += xks;
+            if (++xk == nk) { xk = 0; xoff = 0; }
         };
 #pragma unroll
         for (int s = 0; s < LOOK; ++s)
@@ -123,13 +133,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         int nxt = LOOK % NSTAGE, kt = 0;
         for (; kt + LOOK < nk; ++kt) {
             stage(nxt);
-            wr_wait_vmcnt<LOADS * NEWER>();                                      // stage kt+1 landed
-            __builtin_amdgcn_s_barrier();
+            if constexpr (ABL != 5) wr_wait_vmcnt<LOADS * NEWER>();              // stage kt+1 landed
+            if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
             nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
         }
         for (; kt + 1 < nk; ++kt) {
             wr_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
+            if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_s_barrier();                                            // the epilogue's two barriers
         __builtin_amdgcn_s_barrier();
@@ -160,6 +170,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             wb[i] = a.qw + static_cast<size_t>(rb) * 1024;
         }
         const size_t wks = static_cast<size_t>(a.wblocks) * 1024;
+        int wk = rot;                                    // k-step the next weight loads read
+        size_t woff = static_cast<size_t>(rot) * wks;
+        auto wadvance = [&](int cond) {                    // once per requested k-step (cond: wave-uniform 0 / 1)
+            if (cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
+        };
         const int lane16 = lane * 16;
         // activation fragment (row lm, k-chunk lq) inside a P16X64 block: conflict-free by the layout's swizzle (common.h)
         const int xoff = lm * 64 + ((lq ^ ((0 - (lm >> 2)) & 3)) << 4);
@@ -191,16 +206,20 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             constexpr int d = decltype(d_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
                 const int cs = __builtin_amdgcn_readfirstlane(cond);             // provably wave-uniform for the "s" constraint
+                const uint8_t* src = wb[i] + woff;
+                i32x4& dst = wq[d][i];                     // (named outside the statement: implicit capture does not look into asm operands)
+                const int l16 = lane16;
                 asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\tglobal_load_dwordx4 %0, %1, %2\n1:"
-                             : "+v"(wq[d][i]) : "v"(lane16), "s"(wb[i]), "s"(cs) : "memory", "scc");
-                wb[i] += cond ? wks : 0;
+                             : "+v"(dst) : "v"(l16), "s"(src), "s"(cs) : "memory", "scc");
             }
         };
         auto wload1_always = [&](auto d_c, int i) {
             constexpr int d = decltype(d_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(wq[d][i]) : "v"(lane16), "s"(wb[i]) : "memory");
-                wb[i] += wks;
+                const uint8_t* src = wb[i] + woff;
+                i32x4& dst = wq[d][i];
+                const int l16 = lane16;
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(l16), "s"(src) : "memory");
             }
         };
         // wait until at most CNT loads issued after slot d's are outstanding (vmcnt retires in order); naming the slot's registers
@@ -293,6 +312,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     loads_behind(j);
                 }
             }
+            wadvance(FULL ? 1 : issue);
         };
 
         // ---- prologue ------------------------------------------------------------------------------------------------
@@ -310,6 +330,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         auto prologue_w = [&](auto d_c) {
 #pragma unroll
             for (int i = 0; i < WNB; ++i) wload1(d_c, i, decltype(d_c)::value < nk ? 1 : 0);
+            wadvance(decltype(d_c)::value < nk ? 1 : 0);
         };
         prologue_w(std::integral_constant<int, 0>{});
         if constexpr (D > 1) prologue_w(std::integral_constant<int, 1>{});
@@ -331,13 +352,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         auto one = [&](auto c_c, auto full_c) {
             constexpr bool FULL = decltype(full_c)::value;                       // FULL: stage kt+1 and k-step kt+D exist
             if constexpr (FULL) {
-                wwait(c_c, std::integral_constant<int, WNB * (D - 1)>{});        // the D-1 younger k-steps stay in flight
-                __builtin_amdgcn_s_barrier();                                    // stage kt+1 landed; stage kt-2's slot is free
+                if constexpr (ABL != 4) wwait(c_c, std::integral_constant<int, WNB * (D - 1)>{});   // the D-1 younger k-steps stay in flight
+                if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();            // stage kt+1 landed; stage kt-2's slot is free
                 step(c_c, full_c, true, 1, slot1);
             } else {
                 wwait_rt(c_c, nk - 1 - kt);
                 const bool more = kt + 1 < nk;
-                if (more) __builtin_amdgcn_s_barrier();
+                if (more && ABL != 6) __builtin_amdgcn_s_barrier();
                 step(c_c, full_c, more, kt + D < nk ? 1 : 0, slot1);
             }
             slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
@@ -553,27 +574,39 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 8, 4, 1, 1, "128x192_abl1_noW"),     // 11: cfg 0 without the weight loads
     MIXQ_WR(8, 3, 8, 4, 1, 2, "128x192_abl2_noX"),     // 12: cfg 0 without X traffic
     MIXQ_WR(8, 3, 8, 4, 1, 3, "128x192_abl3_mfma"),    // 13: cfg 0, MFMA + epilogue only
+    MIXQ_WR(8, 3, 8, 4, 1, 4, "128x192_abl4_nowwait"), // 14
+    MIXQ_WR(8, 3, 8, 4, 1, 5, "128x192_abl5_noxwait"), // 15
+    MIXQ_WR(8, 3, 8, 4, 1, 6, "128x192_abl6_nobar"),   // 16
+    MIXQ_WR(8, 3, 12, 4, 2, 0, "128x192_s12_d4_l2"),   // 17: deeper X ring
 };
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
+int g_wr_krot = 0;
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
 int mixq_wr_num_configs() { return NUM_WR; }
+int mixq_wr_set_krot(int v) { if (v < 0) return MIXQ_EINVAL; g_wr_krot = v; return MIXQ_OK; }
 const char* mixq_wr_config_name(int c) { return (c >= 0 && c < NUM_WR) ? g_wr[c].name : "?"; }
 
-// Estimated time ~ rounds over the 256 CUs x time per k-step of one tile (us, MI355X; tools/sweep_gemm.py).
+// Estimated time = rounds over the 256 CUs x (k-steps x time per k-step of one tile + the tile's fixed prologue / epilogue), both
+// fitted on an MI355X at M = 512 over the Llama-2-7b / 70b and Llama-3-8B shapes (tools/sweep_gemm.py, profiles/r02_sweep_shapes.txt):
+// per shape this picks the measured winner (64x128 at N = 4096, 64x192 at 6144, 128x128 at 8192, 128x192 at 10-12 k, 128x256 at
+// 14 k and 28 k).
 int mixq_wr_pick(int bit, int M, int N, int KB)
 {
-    (void)bit; (void)KB;
+    (void)bit;
     if (M <= 32) return 10;                              // (decode normally runs the weight-stream kernel of gemm_skinny.hip)
-    static const struct { int cfg; float tk; } cand[] = {{0, 0.30f}, {4, 0.22f}, {5, 0.38f}, {6, 0.13f}, {7, 0.17f}, {8, 0.21f}, {9, 0.15f}, {10, 0.09f}};
-    double best = 1e30; int bi = -1;
+    static const struct { int cfg; float tk, fixed; } cand[] = {
+        {0, 0.244f, 10.2f}, {4, 0.222f, 5.2f}, {5, 0.32f, 10.4f}, {6, 0.134f, 4.7f}, {7, 0.19f, 5.0f}, {8, 0.24f, 5.0f},
+        {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
+    const int nk = KB >> 6;
+    double best = 1e30; int bi = 0;
     for (const auto& c : cand) {
         const WrConfig& g = g_wr[c.cfg];
         const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
-        const double t = cdiv(tiles, 256) * static_cast<double>(c.tk);
+        const double t = cdiv(tiles, 256) * (nk * static_cast<double>(c.tk) + c.fixed);
         if (t < best * 0.999) { best = t; bi = c.cfg; }
     }
     return bi;
@@ -595,6 +628,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     const int bm = g.mb * 16, bn = g.wnb * 64;
     a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, bn);
     a.xblocks = (M + 15) >> 4; a.wblocks = (N + 15) >> 4;
+    a.krot = g_wr_krot;
     a.trace = trace;
     void (*k)(const WrArgs) = bit == 8 ? g.k8 : g.k4;
     const size_t ring = static_cast<size_t>(g.nstage) * g.mb * 1024, stg = static_cast<size_t>(bm) * (bn * 2 + 16);

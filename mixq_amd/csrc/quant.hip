@@ -396,9 +396,11 @@ int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int
     const int nchunk = K >> 3;
     int cfg = g_quant_cfg;
     if (cfg < 0) {
-        // chosen on an MI355X (tools/time_quant.py, profiles/r02_quant_sweep.txt): rows of up to 8 K elements live in one or
-        // two waves; longer rows spread over 256 threads so the per-lane register file still holds the row
-        cfg = nchunk <= 8 * 64 ? 2 : (nchunk <= 8 * 128 ? 5 : 7);
+        // measured on an MI355X (tools/time_quant.py, profiles/r02_quant_sweep.txt), M = 512, K = 4096, 41 outlier columns, us per
+        // launch in a graph: (256,1) 5.3 | (256,2) 5.4 | round-1 kernel 5.4 | (128,2) 6.6 | (128,1) 7.1 | (64,x) 9.2-9.4.  A row in ONE wave
+        // (no LDS reduction, no barrier) loses: its 64 elements per lane make the quantise arithmetic, not memory, the critical
+        // path.  256 threads per row it is; the gain over round 1 is the gather from global memory instead of an LDS row copy.
+        cfg = 6;
     }
     int rc = -100;
 #define MIXQ_Q2(TPR, RPB) rc = launch_quant_rows2<BIT, TPR, RPB>(x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, qfmt, st)

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--packed", default="0,1,2", help="operand formats to try: 0 plain, 1 P16x64, 2 weights F16x64 + activations P16x64")
     ap.add_argument("--out", default="gpurun_out/sweep_gemm.json")
+    ap.add_argument("--krot", default="0", help="k-step rotation(s) between neighbouring N tiles for the wr* tilings")
     ap.add_argument("--nout", type=int, default=0, help="outlier columns fed to the fp16 tail (timing; the error check ignores them)")
     args = ap.parse_args()
     dev = "cuda"
@@ -96,9 +97,10 @@ def main():
             pad = (args.nout + 15) // 16 * 16
             xo = torch.zeros((M, pad), dtype=torch.float16, device=dev)[:, :args.nout]
             wo = torch.zeros((N, pad), dtype=torch.float16, device=dev)[:, :args.nout]
-        for c, krot in [(c, int(kr)) for c in cfgs for kr in args.packed.split(",")]:
-            if krot not in packs:
+        for c, krot, rotv in [(c, int(kr), int(rv)) for c in cfgs for kr in args.packed.split(",") for rv in args.krot.split(",")]:
+            if krot not in packs or (rotv and not names[c].startswith("wr")):
                 continue
+            lib.mixq_gemm_set_krot(rotv)
             if names[c].startswith("wr") != (krot == 2) and names[c] != "decode32":
                 continue                                   # the weights-in-registers tilings take F16x64 only, the others never
             if names[c] == "decode32" and (krot == 0 or M > 32):
@@ -119,12 +121,13 @@ def main():
             us = time_fn(lambda: mixlib.FusedLinear(ax, aw, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out, **pk), args.iters)
             usg = time_graph(lambda: mixlib.FusedLinear(ax, aw, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out, **pk), args.iters)
             tops = flops / usg / 1e6
-            r = dict(shape=shp, cfg=c, krot=krot, name=names[c], bit=args.bit, max_abs_err=err, rel_err=rel, us_eager=us, us_graph=usg,
+            r = dict(shape=shp, cfg=c, krot=krot, rot=rotv, name=names[c], bit=args.bit, max_abs_err=err, rel_err=rel, us_eager=us, us_graph=usg,
                      tops=tops, frac=tops / PEAK_TOPS)
             results.append(r)
-            print(f"{shp} cfg{c:2d} packed={krot:1d} {names[c]:24s} err={err:.3e} rel={rel:.2e} eager={us:8.2f}us graph={usg:8.2f}us "
+            print(f"{shp} cfg{c:2d} packed={krot:1d} rot={rotv:2d} {names[c]:24s} err={err:.3e} rel={rel:.2e} eager={us:8.2f}us graph={usg:8.2f}us "
                   f"{tops:7.1f} TOPS ({100 * tops / PEAK_TOPS:4.1f}%)", flush=True)
         lib.mixq_gemm_set_config(-1)
+        lib.mixq_gemm_set_krot(0)
         for fmt in (1, 2):
             auto = lib.mixq_gemm_pick_config_fmt(M, N, K, args.bit, fmt)
             print(f"{shp}: auto pick (fmt {fmt}) = cfg{auto} {names[auto]}", flush=True)

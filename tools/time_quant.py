@@ -10,14 +10,16 @@ from tools.sweep_gemm import time_graph
 dev = "cuda"
 lib = _capi.load()
 NAMES = ["r1 256x1", "64x1", "64x2", "64x4", "128x1", "128x2", "256x1", "256x2"]
-shapes = [(512, 4096)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+COLD = "--cold" in sys.argv                       # rotate through ~1.7 GB of inputs (beyond the 256 MB MALL), as bench.py's steps do
+shapes = [(512, 4096)] if not args else [tuple(int(v) for v in a.split("x")) for a in args]
 for (M, K) in shapes:
-    nb = max(2, min(64, (1 << 30) // (M * K * 2)))
+    nb = max(2, min(400 if COLD else 64, ((1700 << 20) if COLD else (1 << 30)) // (M * K * 2)))
     x = torch.randn(nb, M, K, device=dev).half()
     for n_out in (0, round(0.01 * K)):
         ind = torch.randperm(K)[:n_out].to(torch.int32).to(dev) if n_out else None
-        for fmt in (0, 1, 2):
-            for bit in (8, 4):
+        for fmt in ((1,) if COLD else (0, 1, 2)):
+            for bit in ((8,) if COLD else (8, 4)):
                 row = []
                 for cfg in range(len(NAMES)):
                     assert lib.mixq_quant_set_config(cfg) == 0
@@ -26,7 +28,7 @@ for (M, K) in shapes:
                     def f():
                         mixlib.QuantFused(x[i[0] % nb], ind, xs, bit, 6.0, fmt=fmt)
                         i[0] += 1
-                    us = time_graph(f, 200, 20)
+                    us = time_graph(f, 400 if COLD else 200, 400 if COLD else 20)
                     row.append(us)
                 lib.mixq_quant_set_config(-1)
                 best = min(range(len(row)), key=lambda c: row[c])

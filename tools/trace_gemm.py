@@ -31,13 +31,14 @@ def main():
         qw = torch.randint(-127, 128, (N, KB), generator=g, dtype=torch.int8).to(dev)
         sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
         sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
-        qxp, qwp = mixlib.PackP16x64(qx), mixlib.PackP16x64(qw)
+        qxp = mixlib.PackOperand(qx, 1)
+        qw_by_fmt = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 2)}
         out = torch.empty(M, N, dtype=torch.float16, device=dev)
         trace = torch.zeros(16 * 4096, dtype=torch.int64, device=dev)
         for c in [int(v) for v in args.cfgs.split(",")]:
             assert lib.mixq_gemm_set_config(c) == 0
-            run = lambda: mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out,
-                                             x_packed=True, w_packed=True)
+            qwp = qw_by_fmt[2 if names[c].startswith("wr") else 1]
+            run = lambda: mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out)
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
@@ -67,8 +68,9 @@ def main():
                 "end (vs first entry)": t[:, 5] - t0,
             }
             mhz = (t[:, 10] - t[:, 9]) / ((t[:, 2] - t[:, 1]) / 100.0)
+            cyc = np.median(t[:, 10] - t[:, 9]) / (K if args.bit == 8 else K // 2) * 64
             print(f"{shp} bit={args.bit} cfg{c} {names[c]}: {t.shape[0]} workgroups; s_memtime ticks per us in the k loop: "
-                  f"{np.median(mhz):.0f}; microseconds min / median / p90 / max")
+                  f"{np.median(mhz):.0f} ({cyc:.0f} shader cycles per 64-byte k-step); microseconds min / median / p90 / max")
             for k, v in ph.items():
                 v = v / 100.0
                 print(f"  {k:22s} {v.min():7.2f} {np.median(v):7.2f} {np.percentile(v, 90):7.2f} {v.max():7.2f}")
