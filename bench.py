@@ -344,14 +344,14 @@ def main(argv=None):
                        "parallelism": f"batch-shard x{world} ({'independent replicas' if args.scaling == 'weak' else 'rows of one batch split'}, "
                                       f"no data-path collective)",
                        "launch": "eager" if args.no_graph else f"one hipGraph of {steps} steps",
-                       "operand_format": {0: "plain", 1: "P16x64", 2: "F16x64"}[fmt],
+                       "operand_format": {"activations": {0: "plain", 1: "P16x64"}[fmt], "weights": {0: "plain", 1: "P16x64", 2: "F16x64"}[mixlib.fmt_of(layer._wpk)]},
                        "weight_bytes_resident": int(layer._wpk.numel() + (0 if layer._buffers['q_weight'] is None else layer._buffers['q_weight'].numel()))},
             "timing": {"clock": "HIP events on the launch stream around the K steps", "host_wall_ms_per_step": round(max_host * 1e3 / steps, 5),
                        "per_rank_ms_per_step": [round(v * 1e3 / steps, 5) for v in per_rank]},
             "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
             "max_abs_err_vs_dequant_linear": round(max_abs_err, 6),
             "roofline": {"bound": "mfma", "kernel": "int8 MFMA GEMM + fused epilogue (" +
-                                                    _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(rows, N, K, 8, fmt)] + ")",
+                                                    _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(rows, N, K, 8, mixlib.fmt_of(layer._wpk))] + ")",
                          "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": flops_step,

@@ -216,8 +216,8 @@ int mixq_gemm_set_workspace(void* ws, long long bytes);
  * choice.  Returns MIXQ_EINVAL for an unknown id.  mixq_gemm_config_name writes the config's description. */
 int mixq_gemm_set_config(int cfg);
 /* Launch geometry of the extract + scale + quantise pass (mixq_quant_fused / mixq_find_row_scale): -1 automatic, 0 the
- * one-row-per-256-thread-workgroup kernel, 1..7 (threads per row, rows per workgroup) = (64,1) (64,2) (64,4) (128,1)
- * (128,2) (256,1) (256,2).  Every geometry produces identical bytes. */
+ * one-row-per-256-thread-workgroup kernel, 1..9 (threads per row, rows per workgroup) = (64,1) (64,2) (64,4) (128,1)
+ * (128,2) (256,1) (256,2) (512,1) (512,2).  Every geometry produces identical bytes. */
 int mixq_quant_set_config(int cfg);
 /* Diagnostics: when buf is non-null every workgroup of the data-parallel fused GEMM writes 16 x u64 to
  * buf[16 * workgroup + i]: i in 0..7 = the 100 MHz device wall clock at 0 entry, 1 first stage landed, 2 k loop

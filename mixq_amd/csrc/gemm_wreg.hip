@@ -71,8 +71,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
     constexpr int LOADS = MB / LOADERS;                  // DMA pieces per loader wave and stage
     constexpr int OPITCH = BN * 2 + 16;
+    constexpr int TQ = 2;                                // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS
+    constexpr int TAILX = NSTAGE * STAGE_BYTES;          // LDS offset of those blocks: behind the ring, [TQ][MB] x 1 KiB
     static_assert(LOADERS >= 1 && MB % LOADERS == 0, "pieces must divide evenly over the loader waves");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
+    static_assert((NSTAGE + TQ) * STAGE_BYTES <= 160 * 1024, "X ring + tail blocks must fit the 160 KiB of LDS");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
@@ -140,6 +143,30 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         for (; kt + 1 < nk; ++kt) {
             wr_wait_vmcnt<0>();
             if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
+        }
+        // The fp16 outlier tail's activation operand (X_out rows of this tile) is the same for the four consumer waves: like X it
+        // goes through LDS once - fragment-ordered 16 x 32 blocks of the first TQ tail k-steps (64 outlier columns), DMA-ed
+        // behind the ring while the consumers finish the k loop - instead of being fetched from L2 by each wave (4 x 8 KiB per
+        // tail k-step: as much traffic as two k-steps of the main loop, 0.6 us of a 27 us launch at 41 outlier columns).
+        if (a.xo && a.wo) {
+            int n_out_l = a.n_out;
+            if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out_l = nd < n_out_l ? nd : n_out_l; }
+            const int kpad_l = (n_out_l + 15) & ~15;
+            const int tsteps = (n_out_l + 31) >> 5;
+#pragma unroll
+            for (int kk = 0; kk < TQ; ++kk) {
+                if (kk < tsteps) {
+#pragma unroll
+                    for (int i = 0; i < LOADS; ++i) {
+                        const int p = lw + i * LOADERS;
+                        int xr = m0 + p * 16 + (lane & 15); xr = xr < a.M ? xr : a.M - 1;
+                        int col = kk * 32 + (lane >> 4) * 8; col = col < kpad_l ? col : 0;        // chunks past the padded width: any valid address (masked later)
+                        wr_glds16(reinterpret_cast<const uint8_t*>(a.xo + static_cast<size_t>(xr) * a.ldxo + col),
+                                  lds + TAILX + (kk * MB + p) * 1024);
+                    }
+                }
+            }
+            wr_wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();                                            // the epilogue's two barriers
         __builtin_amdgcn_s_barrier();
@@ -411,23 +438,42 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // the operands of tail k-step kk+1 are in flight behind the MFMAs of kk; the fattest tiles only have room for one.
         constexpr int TD = (MB * WNB * 4 + 2 * (MB + WNB) * 4 + 40 > 256) ? 1 : 2;
         u32x4 xoq[TD][MB], woq[TD][WNB];
-        auto tail_load = [&](int P, int kk) {              // P: constant after unrolling
+        auto tail_load_w = [&](int P, int kk) {            // P: constant after unrolling
             const int kb = kk * 32 + lq * 8;
             const bool in = kb < kpad;                     // chunks past the padded width are not addressable: zeros
-#pragma unroll
-            for (int j = 0; j < MB; ++j) {
-                int xr = m0 + j * 16 + lm; xr = xr < a.M ? xr : a.M - 1;
-                xoq[P][j] = in ? *reinterpret_cast<const u32x4*>(a.xo + static_cast<size_t>(xr) * a.ldxo + kb) : u32x4{0, 0, 0, 0};
-            }
 #pragma unroll
             for (int i = 0; i < WNB; ++i) {
                 int wr = nw0 + i * 16 + lm; wr = wr < a.N ? wr : a.N - 1;
                 woq[P][i] = in ? *reinterpret_cast<const u32x4*>(a.wo + static_cast<size_t>(wr) * a.ldwo + kb) : u32x4{0, 0, 0, 0};
             }
         };
-        if (TD > 1 && ksteps > 0) tail_load(0, 0);
-        __builtin_amdgcn_s_barrier();                                            // every wave is done reading the ring
+        auto tail_load_x = [&](int P, int kk) {            // k-steps < TQ: from the blocks the loader staged in LDS (valid after barrier 1)
+            const int kb = kk * 32 + lq * 8;
+            const bool in = kb < kpad;
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                if (kk < TQ) {
+                    xoq[P][j] = *reinterpret_cast<const u32x4*>(lds + TAILX + (kk * MB + j) * 1024 + lane * 16);
+                } else {
+                    int xr = m0 + j * 16 + lm; xr = xr < a.M ? xr : a.M - 1;
+                    xoq[P][j] = in ? *reinterpret_cast<const u32x4*>(a.xo + static_cast<size_t>(xr) * a.ldxo + kb) : u32x4{0, 0, 0, 0};
+                }
+            }
+        };
+        auto tail_load = [&](int P, int kk) { tail_load_w(P, kk); tail_load_x(P, kk); };
+        // both register sets are requested BEFORE the barrier and the dequantisation (the weight ring and the X fragments are dead:
+        // their registers hold the tail operands), so the tail's first two k-steps - all of it up to 64 outlier columns - expose
+        // no memory round trip of their own
+        // (every load of this wave has long landed - the weight ring was consumed, the scales were the first requests of the kernel;
+        // saying so through the builtin the compiler's counter model understands keeps it from draining the tail loads issued next
+        // with a vmcnt(0) in front of the dequantisation, whose scale operands it would otherwise believe to be still in flight)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                      // vmcnt(0)
+        if (TD > 1 && ksteps > 0) tail_load_w(0, 0);
+        if (TD > 1 && ksteps > 1) tail_load_w(1, 1);
+        __builtin_amdgcn_s_barrier();                                            // every wave is done reading the ring; X_out blocks landed
         stamp(6);
+        if (TD > 1 && ksteps > 0) tail_load_x(0, 0);
+        if (TD > 1 && ksteps > 1) tail_load_x(1, 1);
 
         f32x4 fa[MB][WNB];
         {
@@ -467,7 +513,6 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         if constexpr (TD == 1) {
             for (int kk = 0; kk < ksteps; ++kk) { tail_load(0, kk); tail_mma(0, kk); }
         } else {
-            if (ksteps > 1) tail_load(TD - 1, 1);
             for (int kk0 = 0; kk0 < ksteps; kk0 += 2) {
                 tail_mma(0, kk0);
                 if (kk0 + 2 < ksteps) tail_load(0, kk0 + 2);
@@ -530,14 +575,25 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         stamp(3);
     }
     if (staged) {
+        // all waves (loader included): 16 bytes per lane, 16 / 24 / 32 consecutive lanes cover one row segment of the tile.  Every
+        // LDS read of a lane is issued before its first store, so the copy-out costs ONE LDS round trip, not one per 16 bytes.
         constexpr int CPR = BN / 8;                                              // 16-byte chunks per tile row
-        for (int q = tid; q < BM * CPR; q += NT) {
+        constexpr int ITER = (BM * CPR + NT - 1) / NT;
+        u32x4 v[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * NT;
+            const int r = q / CPR, c = q - r * CPR;
+            if (q < BM * CPR) v[it] = *reinterpret_cast<const u32x4*>(lds + r * OPITCH + c * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * NT;
             const int r = q / CPR, c = q - r * CPR;
             const int m = m0 + r, n = n0 + c * 8;
-            if (m < a.M && n < a.N) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * OPITCH + c * 16);
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n));
-            }
+            // streaming (nt) store: Y is written once and not re-read by this kernel
+            if (q < BM * CPR && m < a.M && n < a.N)
+                __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n));
         }
     }
     if (a.trace) {
@@ -560,24 +616,24 @@ struct WrConfig {
       gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), true, LD, ABL> }
 
 const WrConfig g_wr[] = {
-    MIXQ_WR(8, 3, 8, 4, 1, 0, "128x192_s8_d4_l1"),     // 0: the metric shape's tile: 232 tiles at 512 x 11008
-    MIXQ_WR(8, 3, 8, 4, 2, 0, "128x192_s8_d4_l2"),     // 1
-    MIXQ_WR(8, 3, 8, 3, 1, 0, "128x192_s8_d3_l1"),     // 2
-    MIXQ_WR(8, 3, 8, 6, 1, 0, "128x192_s8_d6_l1"),     // 3
-    MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 4
-    MIXQ_WR(8, 4, 8, 3, 1, 0, "128x256_s8_d3_l1"),     // 5 (int4: ring depth 2)
-    MIXQ_WR(4, 2, 8, 4, 1, 0, "64x128_s8_d4_l1"),      // 6: N = 4096 at M = 512 is exactly 256 such tiles
-    MIXQ_WR(4, 3, 8, 4, 1, 0, "64x192_s8_d4_l1"),      // 7: N = 6144
-    MIXQ_WR(4, 4, 8, 4, 1, 0, "64x256_s8_d4_l1"),      // 8
+    // name = tile (activation rows x weight rows) _ X ring depth _ weight ring depth _ loader waves
+    MIXQ_WR(8, 3, 16, 4, 2, 0, "128x192_s16_d4_l2"),   // 0: the metric shape's tile: 232 tiles at 512 x 11008
+    MIXQ_WR(8, 3, 16, 3, 2, 0, "128x192_s16_d3_l2"),   // 1
+    MIXQ_WR(8, 3, 8, 4, 1, 0, "128x192_s8_d4_l1"),     // 2: the first form of this kernel (8-deep X ring, one loader)
+    MIXQ_WR(8, 3, 12, 4, 2, 0, "128x192_s12_d4_l2"),   // 3
+    MIXQ_WR(8, 2, 16, 4, 2, 0, "128x128_s16_d4_l2"),   // 4
+    MIXQ_WR(8, 4, 16, 3, 2, 0, "128x256_s16_d3_l2"),   // 5 (int4: weight ring depth 2)
+    MIXQ_WR(4, 2, 16, 4, 2, 0, "64x128_s16_d4_l2"),    // 6: N = 4096 at M = 512 is exactly 256 such tiles
+    MIXQ_WR(4, 3, 16, 4, 2, 0, "64x192_s16_d4_l2"),    // 7: N = 6144
+    MIXQ_WR(4, 4, 16, 4, 2, 0, "64x256_s16_d4_l2"),    // 8
     MIXQ_WR(8, 1, 8, 4, 1, 0, "128x64_s8_d4_l1"),      // 9
     MIXQ_WR(4, 1, 8, 4, 1, 0, "64x64_s8_d4_l1"),       // 10
-    MIXQ_WR(8, 3, 8, 4, 1, 1, "128x192_abl1_noW"),     // 11: cfg 0 without the weight loads
-    MIXQ_WR(8, 3, 8, 4, 1, 2, "128x192_abl2_noX"),     // 12: cfg 0 without X traffic
-    MIXQ_WR(8, 3, 8, 4, 1, 3, "128x192_abl3_mfma"),    // 13: cfg 0, MFMA + epilogue only
-    MIXQ_WR(8, 3, 8, 4, 1, 4, "128x192_abl4_nowwait"), // 14
-    MIXQ_WR(8, 3, 8, 4, 1, 5, "128x192_abl5_noxwait"), // 15
-    MIXQ_WR(8, 3, 8, 4, 1, 6, "128x192_abl6_nobar"),   // 16
-    MIXQ_WR(8, 3, 12, 4, 2, 0, "128x192_s12_d4_l2"),   // 17: deeper X ring
+    MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 11
+    MIXQ_WR(8, 4, 8, 3, 1, 0, "128x256_s8_d3_l1"),     // 12
+    MIXQ_WR(4, 2, 8, 4, 1, 0, "64x128_s8_d4_l1"),      // 13
+    MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // 14: cfg 0 without the weight loads
+    MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // 15: cfg 0 without X traffic
+    MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // 16: cfg 0, MFMA + epilogue only
 };
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
 int g_wr_krot = 0;
@@ -599,7 +655,7 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
     (void)bit;
     if (M <= 32) return 10;                              // (decode normally runs the weight-stream kernel of gemm_skinny.hip)
     static const struct { int cfg; float tk, fixed; } cand[] = {
-        {0, 0.244f, 10.2f}, {4, 0.222f, 5.2f}, {5, 0.32f, 10.4f}, {6, 0.134f, 4.7f}, {7, 0.19f, 5.0f}, {8, 0.24f, 5.0f},
+        {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f},
         {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
     const int nk = KB >> 6;
     double best = 1e30; int bi = 0;
@@ -631,7 +687,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     a.krot = g_wr_krot;
     a.trace = trace;
     void (*k)(const WrArgs) = bit == 8 ? g.k8 : g.k4;
-    const size_t ring = static_cast<size_t>(g.nstage) * g.mb * 1024, stg = static_cast<size_t>(bm) * (bn * 2 + 16);
+    const size_t ring = static_cast<size_t>(g.nstage + 2) * g.mb * 1024, stg = static_cast<size_t>(bm) * (bn * 2 + 16);   // ring + the tail's X_out blocks
     const size_t shm = ring > stg ? ring : stg;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3((WR_CW + g.loaders) * 64), shm, st, a);

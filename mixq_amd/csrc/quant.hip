@@ -180,7 +180,7 @@ template <int BIT, int TPR, int RPB, int NCH>
 __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
     uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int ldo,
-    int32_t* __restrict__ flag, int M, int K, float thr_scale, int rows16, int fmt)
+    int32_t* __restrict__ flag, int M, int K, float thr_scale, int rows16, int fmt, int dbg)
 {
     constexpr int NT = TPR * RPB, WPR = TPR / 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32] column bitmask, RPB * WPR floats
@@ -201,24 +201,30 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     }
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
-    const bool have_out = (n > 0) && ind != nullptr;
+    const bool have_out = (n > 0) && ind != nullptr && !(dbg & 4);
+    // The gather of the outlier values (ind[j] -> x[row][ind[j]]) is a second, dependent memory round trip.  Only the column
+    // bitmask has to exist before the row can be processed; the gathered values are REQUESTED here (up to GQ per thread, the rest
+    // in the tail loop) and only consumed - stored to x_out, their column zeroed in x - after the quantised row has been written,
+    // so that round trip runs beside the absmax / quantise work instead of in front of it.
+    constexpr int GQ = 2;
+    int gcol[GQ] = {-1, -1};
+    uint16_t gval[GQ] = {0, 0};
     if (have_out) {
         for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
-        int cmine = 0;
-        if (t < n) cmine = ind[t];                             // in flight across the barrier
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) { const int j = t + g * TPR; if (j < n) gcol[g] = ind[j]; }
         __syncthreads();
-        for (int j = tid; j < n; j += NT) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
+        if (rw == 0) {                                         // one row's threads build the mask for the whole workgroup
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0) atomicOr(&smem[gcol[g] >> 5], 1u << (gcol[g] & 31));
+            for (int j = t + GQ * TPR; j < n; j += TPR) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
+        }
         if (valid) {
-            for (int j = t; j < n; j += TPR) {
-                const int c = (j == t) ? cmine : ind[j];
-                const uint16_t v = xr[c];                      // same thread reads, then zeroes: ordered
-                if (x_out) x_out[static_cast<size_t>(row) * ldo + j] = v;
-                xr[c] = 0;                                     // reference zeroes the caller's tensor in place
-            }
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0 && !(dbg & 2)) gval[g] = xr[gcol[g]];
         }
         __syncthreads();
     }
-    if (x_out && valid) for (int j = (have_out ? n : 0) + t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = 0;
 
     uint32_t amax_acc = 0u;
 #pragma unroll
@@ -252,6 +258,22 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         const int c = t + i * TPR;
         if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
     }
+    if (have_out) {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+            if (gcol[g] >= 0) {
+                if (x_out && !(dbg & 8)) x_out[static_cast<size_t>(row) * ldo + t + g * TPR] = gval[g];
+                if (!(dbg & 1)) xr[gcol[g]] = 0;                                   // reference zeroes the caller's tensor in place (same thread read it: ordered)
+            }
+        }
+        for (int j = t + GQ * TPR; j < n; j += TPR) {              // more than GQ * TPR outlier columns: the plain dependent form
+            const int c = ind[j];
+            const uint16_t v = xr[c];
+            if (x_out) x_out[static_cast<size_t>(row) * ldo + j] = v;
+            xr[c] = 0;
+        }
+    }
+    if (x_out && !(dbg & 8)) for (int j = (have_out ? n : 0) + t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = 0;
 }
 
 
@@ -368,7 +390,8 @@ __global__ __launch_bounds__(QT) void repack_kernel(const uint8_t* __restrict__ 
 // Launch geometry of the extract + scale + quantise pass: 0 = the round-1 kernel (256 threads, one row per workgroup), 1.. =
 // quant_rows2_kernel as (threads per row, rows per workgroup); -1 = choose by shape.  Tuning / test knob: mixq_quant_set_config.
 int g_quant_cfg = -1;
-constexpr int NUM_QUANT_CFGS = 8;
+int g_quant_dbg = 0;                    // timing probes (bits: 1 no in-place zeroing, 2 no gather loads, 4 no outlier handling, 8 no x_out stores)
+constexpr int NUM_QUANT_CFGS = 10;
 
 template <int BIT, int TPR, int RPB>
 int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
@@ -378,7 +401,7 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
     const size_t shm = (static_cast<size_t>((K + 31) >> 5) + RPB * (TPR / 64)) * sizeof(uint32_t);
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g((M + RPB - 1) / RPB), b(TPR * RPB);
-#define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt)
+#define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt, g_quant_dbg)
     if      (nchunk <= 1 * TPR)  MIXQ_QLAUNCH2(1);
     else if (nchunk <= 2 * TPR)  MIXQ_QLAUNCH2(2);
     else if (nchunk <= 4 * TPR)  MIXQ_QLAUNCH2(4);
@@ -400,7 +423,7 @@ int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int
         // launch in a graph: (256,1) 5.3 | (256,2) 5.4 | round-1 kernel 5.4 | (128,2) 6.6 | (128,1) 7.1 | (64,x) 9.2-9.4.  A row in ONE wave
         // (no LDS reduction, no barrier) loses: its 64 elements per lane make the quantise arithmetic, not memory, the critical
         // path.  256 threads per row it is; the gain over round 1 is the gather from global memory instead of an LDS row copy.
-        cfg = 6;
+        cfg = nchunk >= 512 ? 8 : 6;                     // (512 threads per row from K = 4096 up: 5.3 vs 5.7 us)
     }
     int rc = -100;
 #define MIXQ_Q2(TPR, RPB) rc = launch_quant_rows2<BIT, TPR, RPB>(x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, qfmt, st)
@@ -412,6 +435,8 @@ int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int
         case 5: MIXQ_Q2(128, 2); break;
         case 6: MIXQ_Q2(256, 1); break;
         case 7: MIXQ_Q2(256, 2); break;
+        case 8: MIXQ_Q2(512, 1); break;
+        case 9: MIXQ_Q2(512, 2); break;
         default: break;
     }
 #undef MIXQ_Q2
@@ -573,6 +598,7 @@ extern "C" int mixq_unpack_operand(const void* src, void* dst, int R, int KB, in
 
 extern "C" int mixq_quant_set_config(int cfg)
 {
+    if (cfg >= 100) { g_quant_dbg = cfg - 100; return MIXQ_OK; }      // (tools/time_quant.py --probe: results are then wrong on purpose)
     if (cfg < -1 || cfg >= NUM_QUANT_CFGS) return MIXQ_EINVAL;
     g_quant_cfg = cfg;
     return MIXQ_OK;

@@ -293,9 +293,12 @@ class MixLinear_GEMM(nn.Module):
             return self._wpk                                             # compacted: the packed image is all there is
         if qw.shape[1] % 64 or not hasattr(_backend, "PackOperand"):
             return None
-        key = (qw.data_ptr(), qw._version, PACK_FMT)
+        # W4A4 stays with the LDS-staged kernel (P16X64 weights): its nibble expansion hides behind 32-cycle MFMAs there, not
+        # behind the 16-cycle ones of the weights-in-registers kernel (28.0 vs 32.4 us at the metric shape, interleaved A/B)
+        fmt = PACK_FMT if self.bit == 8 else FMT_P16X64
+        key = (qw.data_ptr(), qw._version, fmt)
         if self._wpk is None or self._wpk_key != key:
-            self._wpk = _backend.PackOperand(qw, PACK_FMT)
+            self._wpk = _backend.PackOperand(qw, fmt)
             self._wpk_key = key
         return self._wpk
 

@@ -822,7 +822,7 @@ def test_randomized_quantise_family_bit_exact():
         ncap = int(rng.choice([0, 1, 7, 41, 128, 200])) if K >= 256 else int(rng.choice([0, 1, 5]))
         ncap = min(ncap, K)
         packed = int(rng.choice([0, 1, 2])) if ((K if bit == 8 else K // 2) % 64 == 0) else 0
-        assert _capi.load().mixq_quant_set_config(int(rng.integers(-1, 8))) == 0            # every launch geometry, same bytes
+        assert _capi.load().mixq_quant_set_config(int(rng.integers(-1, 10))) == 0            # every launch geometry, same bytes
         x = rng.standard_normal((M, K)).astype(np.float16)
         ind = rng.choice(K, ncap, replace=False).astype(np.int32)
         x[:, ind] *= 20

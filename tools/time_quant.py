@@ -9,8 +9,9 @@ from tools.sweep_gemm import time_graph
 
 dev = "cuda"
 lib = _capi.load()
-NAMES = ["r1 256x1", "64x1", "64x2", "64x4", "128x1", "128x2", "256x1", "256x2"]
+NAMES = ["r1 256x1", "64x1", "64x2", "64x4", "128x1", "128x2", "256x1", "256x2", "512x1", "512x2"]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
+PROBE = "--probe" in sys.argv                   # timing probes of the (256,1) geometry: what the outlier handling costs, part by part
 COLD = "--cold" in sys.argv                       # rotate through ~1.7 GB of inputs (beyond the 256 MB MALL), as bench.py's steps do
 shapes = [(512, 4096)] if not args else [tuple(int(v) for v in a.split("x")) for a in args]
 for (M, K) in shapes:
@@ -35,3 +36,19 @@ for (M, K) in shapes:
                 gbs = (M * K * 2 + M * K * bit / 8) / row[best] / 1e6
                 print(f"QuantFused M={M} K={K} bit={bit} n_out={n_out} fmt={fmt}: " + "  ".join(f"{NAMES[c]}={row[c]:.2f}" for c in range(len(row))) +
                       f"  us | best {NAMES[best]} {row[best]:.2f} us = {gbs:.2f} TB/s", flush=True)
+
+if PROBE:
+    M, K = 512, 4096
+    x = torch.randn(64, M, K, device=dev).half()
+    ind = torch.randperm(K)[:41].to(torch.int32).to(dev)
+    xs = torch.zeros(M, 1, dtype=torch.float16, device=dev)
+    lib.mixq_quant_set_config(6)
+    for dbg, what in [(0, "full"), (1, "no in-place zeroing of x"), (2, "no gather loads"), (8, "no x_out stores"), (1 | 2 | 8, "mask only"), (4, "no outlier handling at all")]:
+        lib.mixq_quant_set_config(100 + dbg)
+        i = [0]
+        def f():
+            mixlib.QuantFused(x[i[0] % 64], ind, xs, 8, 6.0, fmt=1)
+            i[0] += 1
+        print(f"probe {what:32s} {time_graph(f, 200, 20):.2f} us", flush=True)
+    lib.mixq_quant_set_config(100)
+    lib.mixq_quant_set_config(-1)
