@@ -81,7 +81,7 @@ def run(K, N, bit, M, steps, dev):
         torch.cuda.synchronize()
         dt = e0.elapsed_time(e1) * 1e-3
     us = dt * 1e6 / steps
-    cfgname = _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(M, N, K, bit, layer.x_fmt())]
+    cfgname = _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(M, N, K, bit, getattr(layer._wpk, "_mixq_fmt", 0))]
     return us, 2.0 * M * N * K / us / 1e6, err, int(layer.ind.numel()), cfgname
 
 
