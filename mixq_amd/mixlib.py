@@ -74,6 +74,36 @@ def _layout_bits(x_fmt, w_fmt):
 # ------------------------------------------------------------------------------------------------------------
 # reference surface
 # ------------------------------------------------------------------------------------------------------------
+# ---- opt-in: packed operands behind the UNCHANGED reference operator -------------------------------------------------
+# The reference's forward treats `cache.q_xcache` and `self.q_weight` as opaque handles between mixlib calls (linear.py:190-283).
+# With set_packed_operands(True), FindRowScale hands back an [M, KB] view of a buffer that really holds the P16X64 image (the
+# tag rides on the returned tensor object) and the GEMM entry points use a fragment-order copy of every plain weight they are
+# given (cached per tensor: +1x the weight bytes) - the kernels of the native operator, behind the reference's own code.
+# Off by default: a caller that slices, copies or inspects q_x would lose the tag or read tile-major bytes.
+_packed_operands = False
+_wpacked = {}          # (data_ptr, version, shape) -> fragment-order copy of a plain weight
+
+
+def set_packed_operands(enabled):
+    global _packed_operands
+    prev, _packed_operands = _packed_operands, bool(enabled)
+    if not enabled:
+        _wpacked.clear()
+    return prev
+
+
+def _weight_for_gemm(q_w, bit):
+    if not _packed_operands or fmt_of(q_w) != FMT_PLAIN or q_w.dim() != 2 or q_w.shape[1] % 64 or not q_w.is_contiguous():
+        return q_w
+    key = (q_w.data_ptr(), q_w._version, tuple(q_w.shape))
+    p = _wpacked.get(key)
+    if p is None:
+        if len(_wpacked) > 1024:
+            _wpacked.clear()
+        p = _wpacked[key] = PackOperand(q_w, FMT_F16X64 if bit == 8 else FMT_P16X64)
+    return p
+
+
 def FindRowScale(x, x_scale, M, K, bit=8):
     """mixlib.FindRowScale(x, x_scale, M, K, bit) -> q_x  (linear.py:190-193).  Writes x_scale[0:M] in place."""
     _dev_check(x, x_scale)
@@ -83,12 +113,14 @@ def FindRowScale(x, x_scale, M, K, bit=8):
     xp, ldx = _rows(x2, "x")
     if x2.shape[0] < M or x2.shape[1] != K or x_scale.numel() < M:
         raise RuntimeError("FindRowScale: shape mismatch")
-    if bit == 8:
-        q = torch.empty((M, K), dtype=torch.int8, device=x.device)
-    elif bit == 4:
-        q = torch.empty((M, K // 2), dtype=torch.uint8, device=x.device)
-    else:
+    if bit not in (4, 8):
         raise RuntimeError("FindRowScale: bit must be 4 or 8")
+    KB, dt = (K, torch.int8) if bit == 8 else (K // 2, torch.uint8)
+    if _packed_operands and M > 0 and KB % 64 == 0:
+        buf = torch.empty((packed_rows(M), KB), dtype=dt, device=x.device)
+        _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), buf.data_ptr(), M, K, ldx, bit, FMT_P16X64, _stream())
+        return set_fmt(buf[:M], FMT_P16X64)              # same storage, same base pointer: an opaque handle of the reference's shape
+    q = torch.empty((M, KB), dtype=dt, device=x.device)
     _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, FMT_PLAIN, _stream())
     return q
 
@@ -110,6 +142,10 @@ def ExtractOutliersAndSetToZeros(ind, x):
 
 def _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, bit, act):
     _dev_check(q_x, q_w, x_scale, scale_col)
+    if fmt_of(q_x) != FMT_PLAIN:
+        q_w = _weight_for_gemm(q_w, bit)                 # (packed activations need packed weights: set_packed_operands)
+        if fmt_of(q_w) == FMT_PLAIN:
+            raise RuntimeError("mixq_amd.mixlib: packed q_x with a plain weight that cannot be packed (K % 64)")
     y = torch.empty((M, N), dtype=torch.float16, device=q_x.device)
     if _is_zero_addend(addend):
         ap, lda = None, 0
@@ -184,6 +220,8 @@ class PendingGemmI32(torch.Tensor):
         self._mixq_done = True
         with torch._C.DisableTorchFunctionSubclass():
             q_x, q_w, M, N, K = self._mixq_args
+            if fmt_of(q_x) != FMT_PLAIN:                     # set_packed_operands: the raw kernel wants the plain matrix back
+                q_x = UnpackOperand(q_x.as_strided((packed_rows(M), K), (K, 1), q_x.storage_offset()), M, fmt_of(q_x))
             _capi.call("mixq_gemm_i8", q_x.data_ptr(), q_w.data_ptr(), self.data_ptr(), N, M, N, K, _stream())
         self._mixq_args = None
 
@@ -215,7 +253,7 @@ def set_lazy_gemm(enabled):
 def gemm(q_x, q_w, M, N, K):
     """mixlib.gemm(q_x, q_w, M, N, K) -> int32 [M,N] (linear.py:235,321)."""
     _dev_check(q_x, q_w)
-    if fmt_of(q_x) != FMT_PLAIN or fmt_of(q_w) != FMT_PLAIN:
+    if fmt_of(q_w) != FMT_PLAIN or (fmt_of(q_x) != FMT_PLAIN and not _lazy_gemm):
         raise RuntimeError("mixlib.gemm: the raw int32 GEMM takes plain row-major operands")
     if K % 64 or N % 4:
         raise _capi.MixqError("mixq_gemm_i8", _capi.MIXQ_ESHAPE)

@@ -1365,3 +1365,35 @@ def _i4_call(qxp, qwp, sx4, sw4, M, N, K):
     a, b = qxp.view(torch.uint8), qwp.view(torch.uint8)
     mixlib.set_fmt(a, 1); mixlib.set_fmt(b, 2)
     return mixlib.FusedLinear(a, b, sx4, sw4, None, None, 0, None, M, N, 2 * K, bit=4)
+
+
+def test_packed_operands_behind_the_reference_call_sequence():
+    """mixlib.set_packed_operands(True): the reference's own sequence (linear.py:187-193, :234-283) with q_xcache an opaque
+    P16X64 handle of the reference's shape and the plain weight re-tiled (once) into fragment order - the native kernels behind
+    unchanged reference code.  Results equal the plain-operand run bit for bit; a consumer that really reads the integers
+    (PendingGemmI32 materialised) still gets the exact product."""
+    M, K, N = 100, 512, 384
+    c = _fused_case(M, N, K, 8, seed=21, n_out=7, bias=False, addend=False, act=0)
+    x = make_x(M, K, seed=22, outlier_cols=c["ind"])
+    q_weight, scale_col, ind = t(c["qw"]), t(c["sw"]), t(c["ind"])
+    wc = t(c["wo"])
+    def ref_sequence():
+        cache = MixLibCache(M, device=DEV)
+        inputs = t(x)
+        cache.activation_outliers = mixlib.ExtractOutliersAndSetToZeros(ind, inputs)
+        cache.q_xcache = mixlib.FindRowScale(inputs, cache.x_scale, M, K, 8)
+        assert tuple(cache.q_xcache.shape) == (M, K)
+        mm = torch.mm(cache.activation_outliers, wc.T)
+        y_a = mixlib.int8FusedDequantize(cache.q_xcache, q_weight, cache.x_scale, scale_col, mm, M, N, K)                  # arch != 9
+        y_b = mixlib.dequantizeInt8(mixlib.gemm(cache.q_xcache, q_weight, M, N, K), cache.x_scale, scale_col, mm, 8, M, N)   # arch == 9
+        y32 = mixlib.gemm(cache.q_xcache, q_weight, M, N, K)
+        return y_a, y_b, n(y32), cache.q_xcache
+    plain = ref_sequence()
+    prev = mixlib.set_packed_operands(True)
+    try:
+        fast = ref_sequence()
+        assert fmt_of(fast[3]) == 1 and fmt_of(plain[3]) == 0
+    finally:
+        mixlib.set_packed_operands(prev)
+    assert torch.equal(plain[0], fast[0]) and torch.equal(plain[1], fast[1]) and torch.equal(plain[0], plain[1])
+    assert np.array_equal(plain[2], fast[2]) and np.array_equal(fast[2], O.gemm_i8(n(plain[3]), c["qw"]))
