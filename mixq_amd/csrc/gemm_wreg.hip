@@ -60,7 +60,8 @@ __device__ __forceinline__ float wr_silu(float v) { return v * __builtin_amdgcn_
 // MB: 16-row activation blocks per tile (BM = 16 MB), WNB: 16-row weight blocks per wave (BN = 64 WNB), NSTAGE: X ring depth,
 // D: weight register ring depth (k-steps), I4: nibble-packed operands, LOADERS: DMA waves, ABL (tuning): 0 normal,
 // 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only, 4 weight loads issued but never waited for, 5 the loader
-// never waits for its DMA, 6 no k-loop barriers (4-6: timing probes, results are garbage).
+// never waits for its DMA, 6 no k-loop barriers (4-6: timing probes, results are garbage), 7 no stores of Y, 8 ordinary instead of
+// nt stores, 9 return at entry.
 template <int MB, int WNB, int NSTAGE, int D, bool I4, int LOADERS, int ABL>
 __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const WrArgs a)
 {
@@ -78,6 +79,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     static_assert((NSTAGE + TQ) * STAGE_BYTES <= 160 * 1024, "X ring + tail blocks must fit the 160 KiB of LDS");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if constexpr (ABL == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
 
     const int ntiles = a.tiles_m * a.tiles_n;
     int tile;
@@ -592,8 +594,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             const int r = q / CPR, c = q - r * CPR;
             const int m = m0 + r, n = n0 + c * 8;
             // streaming (nt) store: Y is written once and not re-read by this kernel
-            if (q < BM * CPR && m < a.M && n < a.N)
-                __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n));
+            if (q < BM * CPR && m < a.M && n < a.N && (ABL != 7 || a.act == 12345)) {
+                if constexpr (ABL == 8) *reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n) = v[it];
+                else __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n));
+            }
         }
     }
     if (a.trace) {
@@ -634,6 +638,9 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // 14: cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // 15: cfg 0 without X traffic
     MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // 16: cfg 0, MFMA + epilogue only
+    MIXQ_WR(8, 3, 16, 4, 2, 7, "128x192_abl7_nostore"),// 17: cfg 0 without the stores of Y
+    MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// 18: cfg 0 with ordinary (not nt) stores of Y
+    MIXQ_WR(8, 3, 16, 4, 2, 9, "128x192_abl9_empty"),  // 19: returns at entry: the launch floor of this grid and LDS footprint
 };
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
 int g_wr_krot = 0;

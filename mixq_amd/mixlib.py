@@ -257,6 +257,12 @@ def gemm(q_x, q_w, M, N, K):
         raise RuntimeError("mixlib.gemm: the raw int32 GEMM takes plain row-major operands")
     if K % 64 or N % 4:
         raise _capi.MixqError("mixq_gemm_i8", _capi.MIXQ_ESHAPE)
+    if q_x.dim() != 2 or q_w.dim() != 2 or q_x.shape[0] < M or q_x.shape[1] != K or q_w.shape[0] < N or q_w.shape[1] != K \
+            or q_x.element_size() != 1 or q_w.element_size() != 1:
+        # (the reference's arch == 9 route calls this for 4-bit layers too, linear.py:235, with nibble-packed [.,K/2] operands:
+        # a one-byte-per-value GEMM over them would read past both buffers)
+        raise RuntimeError(f"mixlib.gemm: operands must be one-byte [>=M,K] and [>=N,K] matrices (got {tuple(q_x.shape)}, "
+                           f"{tuple(q_w.shape)} for M,N,K = {M},{N},{K}); nibble-packed int4 operands go through int4FusedDequantize")
     if _lazy_gemm and M > 0 and N > 0:
         return PendingGemmI32(q_x, q_w, M, N, K)
     y = torch.empty((M, N), dtype=torch.int32, device=q_x.device)

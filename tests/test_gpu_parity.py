@@ -1196,6 +1196,23 @@ def test_wreg_kernel_under_graph_replay_and_cold_buffers():
         lib.mixq_gemm_set_config(-1)
 
 
+def test_gemm_shim_refuses_operands_that_do_not_match_m_n_k():
+    """The reference's arch == 9 route calls mixlib.gemm for 4-bit layers too (linear.py:235) with nibble-packed [., K/2] operands and
+    the full K: a byte GEMM over them would read past both buffers, so the shim raises instead of launching."""
+    M, N, K = 32, 64, 128
+    qx = torch.zeros((M, K // 2), dtype=torch.uint8, device="cuda")
+    qw = torch.zeros((N, K // 2), dtype=torch.uint8, device="cuda")
+    for lazy in (True, False):
+        prev = mixlib.set_lazy_gemm(lazy)
+        try:
+            with pytest.raises(RuntimeError, match="nibble-packed"):
+                mixlib.gemm(qx, qw, M, N, K)
+            with pytest.raises(RuntimeError, match="one-byte"):
+                mixlib.gemm(torch.zeros((M, K), dtype=torch.int32, device="cuda"), torch.zeros((N, K), dtype=torch.int8, device="cuda"), M, N, K)
+        finally:
+            mixlib.set_lazy_gemm(prev)
+
+
 @pytest.mark.parametrize("lazy", [True, False])
 def test_reference_arch9_route_at_the_metric_shape(lazy):
     """torch reports gfx950 as capability major 9, so the UNCHANGED reference forward takes linear.py:234-241:
