@@ -194,12 +194,15 @@ int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weight, uint16_t
  *   y[M,N] fp16 = x[M,K] fp16 * (q[K,N] int8 * scale_col[N] fp16) (+ bias[N] fp16), fp32 accumulation, one fp16 rounding.
  * The kernel streams the weights from a re-tiled copy: mixq_pack_w8a16 turns the checkpoint's row-major [K,N] int8
  * matrix (modules/linear.py:70-71; EETQ's *unprocessed* quantised tensor) into round16(N) * K bytes of offset-binary
- * P16x64 (rows = output channels) once per layer.
+ * (q + 128) MIXQ_FMT_F16X64 (rows = output channels) once per layer: the image the kernel's lanes load straight into their
+ * MFMA operand registers.
  *   K % 64 == 0, N % 4 == 0, ldx % 8 == 0, x 16-byte aligned, ldy % 4 == 0, y 8-byte aligned. */
 int mixq_pack_w8a16(const int8_t* q_weight_kn, uint8_t* packed, int K, int N, mixq_stream_t stream);
 int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_packed, const uint16_t* scale_col, const uint16_t* bias,
                     uint16_t* y, int ldy, int M, int N, int K, mixq_stream_t stream);
 int mixq_gemm_w8a16_set_config(int cfg);             /* tuning: force a tile config, -1 = automatic */
+int mixq_gemm_w8a16_num_configs(void);
+int mixq_gemm_w8a16_config_name(int cfg, char* buf, int cap);
 
 /* ---- stream-K workspace ---------------------------------------------------------------------------------
  * The stream-K form of the GEMM (opt-in through mixq_gemm_set_config) hands

@@ -74,6 +74,8 @@ SIGNATURES = {
     "mixq_pack_w8a16": [_P, _P, _I, _I, _P],
     "mixq_gemm_w8a16": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mixq_gemm_w8a16_set_config": [_I],
+    "mixq_gemm_w8a16_num_configs": [],
+    "mixq_gemm_w8a16_config_name": [_I, C.c_char_p, _I],
     "mixq_gemm_workspace_bytes": [],
     "mixq_gemm_set_workspace": [_P, C.c_longlong],
 }
@@ -147,6 +149,16 @@ def ensure_workspace(device=None):
         if rc != 0:
             raise MixqError("mixq_gemm_set_workspace", rc)
     return _workspace
+
+
+def w8a16_config_names():
+    lib = load()
+    out = []
+    for i in range(lib.mixq_gemm_w8a16_num_configs()):
+        buf = C.create_string_buffer(64)
+        lib.mixq_gemm_w8a16_config_name(i, buf, 64)
+        out.append(buf.value.decode())
+    return out
 
 
 def gemm_config_names():

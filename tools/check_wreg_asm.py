@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tripwire for the hand-counted weight loads of gemm_wreg.hip (cdna_hip_programming.md section 5.7 item 1: the compiler does not
+"""Tripwire for the hand-counted weight loads and LDS fragment reads of gemm_wreg.hip (cdna_hip_programming.md section 5.7 item 1: the compiler does not
 know an inline-asm load's destination is in flight, so a spill, copy or re-use of that register before the matching wait
 would read garbage).  Compiles the file with -save-temps and, per kernel, collects every VGPR an asm global_load writes and
 flags any COMPILER instruction that copies or spills one of them: v_mov_b32 / v_mov_b64 / v_accvgpr_write reading it, any
@@ -67,10 +67,32 @@ def main():
                 if any(regs(x) & loaded for x in toks): hits.append((i, t))
             elif op.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr_write")):
                 if any(regs(x) & loaded for x in toks[1:]): hits.append((i, t))          # a SOURCE in the ring
+        # activation fragments (asm ds_read_b128 + hand-counted lgkmcnt): LDS returns in order, so simulate the queue of outstanding
+        # destination registers through the kernel text and flag any compiler copy / spill that READS a register still in it
+        pending, in_asm, lds_hits = [], False, []
+        for i, ln in enumerate(lines):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"): in_asm = True; continue
+            if t.startswith(";;#ASMEND"): in_asm = False; continue
+            if not t or t.startswith((";", ".")): continue
+            op = t.split()[0]
+            toks = [x.strip(",") for x in t.split()[1:]]
+            if in_asm:
+                if op == "ds_read_b128": pending.append(regs(toks[0]))
+                elif op == "s_waitcnt":
+                    m2 = re.search(r"lgkmcnt\((\d+)\)", t)
+                    if m2: pending = pending[len(pending) - int(m2.group(1)):] if int(m2.group(1)) else []
+                continue
+            if op == "s_waitcnt" and "lgkmcnt(0)" in t: pending = []
+            inflight = set().union(*pending) if pending else set()
+            if not inflight: continue
+            if op.startswith("scratch_") and any(regs(x) & inflight for x in toks): lds_hits.append((i, t))
+            elif op.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr_write")) and any(regs(x) & inflight for x in toks[1:]): lds_hits.append((i, t))
+        hits += lds_hits
         sc = re.search(r"; ScratchSize: (\d+)", body)
         tag = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)", name).groups()
         abl = tag[6] != "0"
-        print(f"MB={tag[0]} WNB={tag[1]} NSTAGE={tag[2]} D={tag[3]} I4={tag[4]} L={tag[5]} ABL={tag[6]}: ring registers {len(loaded)}, "
+        print(f"MB={tag[0]} WNB={tag[1]} NSTAGE={tag[2]} D={tag[3]} I4={tag[4]} L={tag[5]} ABL={tag[6]}: ring registers {len(loaded)}, in-flight LDS copies {len(lds_hits)}, "
               f"suspicious {len(hits)}" + ("  (ablation build: ignored)" if abl and hits else ""))
         for i, t in hits[:6]:
             print("     line", i, t)
