@@ -619,7 +619,7 @@ def _w8a16_case(M, N, K, seed, bias):
 
 @pytest.mark.parametrize("M,N,K,bias", [(1, 64, 64, False), (7, 192, 128, True), (33, 100, 256, False), (128, 128, 512, True),
                                         (300, 1000, 1024, False), (512, 1536, 4096, True), (16, 4096, 4096, False), (64, 36, 192, True)])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5])
 def test_w8a16_linear_vs_oracle(M, N, K, bias, cfg):
     q, s, x, b = _w8a16_case(M, N, K, 7 * M + N + K, bias)
     lib = _capi.load()
@@ -637,6 +637,44 @@ def test_w8a16_linear_vs_oracle(M, N, K, bias, cfg):
                                       None if b is None else torch.from_numpy(b).float()).numpy()
     small = np.abs(gate) < 8
     assert np.abs(y.astype(np.float32) - gate)[small].max() <= GATE
+
+
+def _w8a16_real_configs():
+    return [i for i, nm in enumerate(_capi.w8a16_config_names()) if "abl" not in nm and "decode" not in nm]
+
+
+def test_w8a16_every_tiling_every_k_step_count():
+    """The weights-in-registers W8A16 kernel keeps D k-steps of weights and NSTAGE - 2 of activations in flight with hand-counted
+    waits; its guarded tail takes over for the last < NSLOT + D k-steps.  Every tiling x every k-step count 1..14 and a few long
+    ones, ragged M and N, against an fp32 matmul of the same dequantised operands on the device (fp32 accumulation order differs:
+    tolerance 2 fp16 ulp of the row's largest output) and, exactly, against a one-hot probe that reads single weights back."""
+    lib = _capi.load()
+    names = _capi.w8a16_config_names()
+    g = torch.Generator().manual_seed(11)
+    M, N = 150, 328
+    try:
+        for cfg in _w8a16_real_configs():
+            assert lib.mixq_gemm_w8a16_set_config(cfg) == 0
+            for nk in list(range(1, 15)) + [23, 40, 67]:
+                K = 64 * nk
+                q = torch.randint(-128, 128, (K, N), generator=g, dtype=torch.int8).to(DEV)
+                sc = (torch.rand(N, generator=g) * 0.01 + 0.001).half().to(DEV)
+                x = torch.randn(M, K, generator=g).half().to(DEV)
+                b = torch.randn(N, generator=g).half().to(DEV)
+                y = mixlib.W8A16Linear(x, mixlib.PackW8A16(q), sc, b, N, K).float()
+                ref = x.float() @ (q.float() * sc.float()) + b.float()
+                tol = 2.0 ** (torch.floor(torch.log2(ref.abs().amax(dim=1, keepdim=True).clamp_min(1.0))) - 9)
+                assert ((y - ref).abs() <= tol).all(), (names[cfg], nk, float((y - ref).abs().max()))
+            # exact probe: x = one-hot rows, unit scales -> y[m, n] = q[k(m), n] for k spread over all k-steps
+            K = 64 * 13
+            q = torch.randint(-128, 128, (K, N), generator=g, dtype=torch.int8).to(DEV)
+            ks = torch.arange(M) * 5 % K
+            x = torch.zeros(M, K, dtype=torch.float16, device=DEV)
+            x[torch.arange(M), ks] = 1
+            y = mixlib.W8A16Linear(x, mixlib.PackW8A16(q), torch.ones(N, dtype=torch.float16, device=DEV), None, N, K)
+            assert torch.equal(y.to(torch.int16).cpu(), q[ks.to(DEV)].to(torch.int16).cpu()), names[cfg]
+    finally:
+        lib.mixq_gemm_w8a16_set_config(-1)
 
 
 def test_w8a16_offset_binary_conversion_is_exact():

@@ -7,7 +7,11 @@ scratch_* naming it.  (MFMAs read them legitimately, behind the s_waitcnt statem
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "mixq_amd", "csrc", "gemm_wreg.hip")
+# (source file, kernel name, how to read the template arguments out of the mangled name)
+TARGETS = [
+    ("gemm_wreg.hip", "gemm_wreg_kernel", r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)", "MB={0} WNB={1} NSTAGE={2} D={3} I4={4} L={5} ABL={6}", 6),
+    ("gemm_w8a16.hip", "gemm_w8a16_kernel", r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)", "w8a16 MB={0} WNB={1} NSTAGE={2} D={3} L={4} ABL={5}", 5),
+]
 
 
 def regs(tok):
@@ -19,12 +23,20 @@ def regs(tok):
 
 
 def main():
+    bad = 0
+    for fname, kname, tag_re, tag_fmt, abl_idx in TARGETS:
+        bad += check(fname, kname, tag_re, tag_fmt, abl_idx)
+    return 1 if bad else 0
+
+
+def check(fname, kname, tag_re, tag_fmt, abl_idx):
+    src = os.path.join(ROOT, "mixq_amd", "csrc", fname)
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-save-temps", "-o", "x.o"], cwd=td,
                               stderr=subprocess.DEVNULL)
-        text = open(os.path.join(td, "gemm_wreg-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+        text = open(os.path.join(td, fname.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     bad = 0
-    for m in re.finditer(r"^(_ZN\S*gemm_wreg_kernel\S*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN\S*" + kname + r"\S*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
         name, body = m.group(1), m.group(2)
         lines = body.split("\n")
         loaded, in_asm = set(), False
@@ -90,15 +102,15 @@ def main():
             elif op.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr_write")) and any(regs(x) & inflight for x in toks[1:]): lds_hits.append((i, t))
         hits += lds_hits
         sc = re.search(r"; ScratchSize: (\d+)", body)
-        tag = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)", name).groups()
-        abl = tag[6] != "0"
-        print(f"MB={tag[0]} WNB={tag[1]} NSTAGE={tag[2]} D={tag[3]} I4={tag[4]} L={tag[5]} ABL={tag[6]}: ring registers {len(loaded)}, in-flight LDS copies {len(lds_hits)}, "
+        tag = re.search(tag_re, name).groups()
+        abl = tag[abl_idx] != "0"
+        print(f"{tag_fmt.format(*tag)}: ring registers {len(loaded)}, in-flight LDS copies {len(lds_hits)}, "
               f"suspicious {len(hits)}" + ("  (ablation build: ignored)" if abl and hits else ""))
         for i, t in hits[:6]:
             print("     line", i, t)
         if hits and not abl:
             bad += 1
-    return 1 if bad else 0
+    return bad
 
 
 if __name__ == "__main__":
