@@ -810,7 +810,9 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     // small-batch form (gemm_skinny.hip): M <= 32, packed operands (either packed layout): a weight stream, no LDS staging
     {
         const bool both_packed = a.x_packed && (a.w_packed || wf16);
-        if ((g_forced_cfg < 0 || g_forced_cfg == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed))
+        // (wide layers with fragment-order int8 weights: the 32 x 64 weights-in-registers tiling streams faster, gemm_wreg.hip)
+        const bool wide_wr = wf16 && bit == 8 && N >= 8192 && g_forced_cfg < 0;
+        if (!wide_wr && (g_forced_cfg < 0 || g_forced_cfg == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed))
             return mixq_skinny_launch(bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                                       ldy, M, N, KB, act, wf16 ? 1 : 0, mixq_stream(stream));
         if (g_forced_cfg == skinny_id) return MIXQ_EINVAL;
@@ -921,7 +923,8 @@ extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) 
     if (M <= 0 || N <= 0 || K <= 0 || (bit != 4 && bit != 8)) return MIXQ_EINVAL;
     const int KB = bit == 8 ? K : K / 2;
     const int dec = NUM_CFGS + mixq_sk_num_configs();
-    if (fmt != MIXQ_FMT_PLAIN && mixq_skinny_applies(bit, M, N, KB, true, true)) return dec;
+    const bool wide_wr = fmt == MIXQ_FMT_F16X64 && bit == 8 && N >= 8192;                 // as in gemm_fused_common
+    if (!wide_wr && fmt != MIXQ_FMT_PLAIN && mixq_skinny_applies(bit, M, N, KB, true, true)) return dec;
     if (fmt == MIXQ_FMT_F16X64) return dec + 1 + mixq_wr_pick(bit, M, N, KB);
     return mixq_gemm_pick_config(M, N, K, bit);
 }

@@ -444,8 +444,12 @@ int g_num_cu = 0;
 int mixq_sk_num_configs() { return NUM_SK; }
 const char* mixq_sk_config_name(int c) { return (c >= 0 && c < NUM_SK) ? g_sk[c].name : ""; }
 
-// Workspace layout: [G slots][BM*BN int32], then G int32 flags (zero on entry; every launch leaves them zero).
-size_t mixq_sk_workspace_need(int c, int G) { return static_cast<size_t>(G) * g_sk[c].bm * g_sk[c].bn * 4 + static_cast<size_t>(G) * 4; }
+// Workspace layout: SK_FLAG_BYTES of int32 flags (zero on entry; every launch leaves them zero), then [G slots][BM*BN int32].  The
+// flags sit at a FIXED place: behind the slots their offset would depend on the configuration's tile size, and one configuration's
+// partial tiles would land on another one's flag words (a finisher of the next launch of the smaller tiling then reads a slot before
+// its contributor wrote it).
+constexpr size_t SK_FLAG_BYTES = 4096;                   // up to 1024 workgroups
+size_t mixq_sk_workspace_need(int c, int G) { return SK_FLAG_BYTES + static_cast<size_t>(G) * g_sk[c].bm * g_sk[c].bn * 4; }
 
 bool mixq_sk_usable(int c) {
     if (c < 0 || c >= NUM_SK || !g_ws) return false;
@@ -477,8 +481,9 @@ int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     a.G = g_num_cu < a.total_units ? g_num_cu : a.total_units;
     if (const char* e = getenv("MIXQ_SK_G")) { const int g2 = atoi(e); if (g2 > 0 && g2 <= a.G) a.G = g2; }     // tuning only
     if (const char* e = getenv("MIXQ_SK_DBG")) a.dbg = atoi(e);
-    a.ws = static_cast<int32_t*>(g_ws);
-    a.flags = reinterpret_cast<int32_t*>(static_cast<char*>(g_ws) + static_cast<size_t>(g_num_cu) * g.bm * g.bn * 4);
+    a.flags = static_cast<int32_t*>(g_ws);
+    a.ws = reinterpret_cast<int32_t*>(static_cast<char*>(g_ws) + SK_FLAG_BYTES);
+    if (static_cast<size_t>(a.G) * 4 > SK_FLAG_BYTES) return MIXQ_EINVAL;
     void (*k)(const SkArgs) = bit == 8 ? g.k8 : g.k4;
     const size_t shm = static_cast<size_t>(g.bm + g.bn) * BKB * g.nstage;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;

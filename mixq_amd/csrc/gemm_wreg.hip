@@ -57,6 +57,11 @@ __device__ __forceinline__ void wr_glds16(const uint8_t* gsrc, uint8_t* lds_wave
 }
 __device__ __forceinline__ float wr_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) (ring slots are compile-time registers)
+template <int I, int N, class F> __device__ __forceinline__ void wr_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); wr_static_for<I + 1, N>(f); }
+}
+
 // MB: 16-row activation blocks per tile (BM = 16 MB), WNB: 16-row weight blocks per wave (BN = 64 WNB), NSTAGE: X ring depth,
 // D: weight register ring depth (k-steps), I4: nibble-packed operands, LOADERS: DMA waves, ABL (tuning): 0 normal,
 // 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only, 4 weight loads issued but never waited for, 5 the loader
@@ -268,20 +273,29 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             constexpr int d = decltype(d_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
                 const int sel = __builtin_amdgcn_readfirstlane(younger >= D - 1 ? D - 1 : younger);   // k-steps requested after this one, capped at the ring depth
+#define MIXQ_WR_W1(n, l) "s_cmp_lt_u32 %[sel], " #n "\n\ts_cbranch_scc1 " #l "f\n\t"
+#define MIXQ_WR_W2(l, c) #l ":\n\ts_waitcnt vmcnt(%[" #c "])\n\ts_branch 199f\n"
 #define MIXQ_WR_WAITS                                                                                                           \
-                "s_cmp_lt_u32 %[sel], 1\n\ts_cbranch_scc1 10f\n\ts_cmp_lt_u32 %[sel], 2\n\ts_cbranch_scc1 11f\n\t"               \
-                "s_cmp_lt_u32 %[sel], 3\n\ts_cbranch_scc1 12f\n\ts_cmp_lt_u32 %[sel], 4\n\ts_cbranch_scc1 13f\n\t"               \
-                "s_cmp_lt_u32 %[sel], 5\n\ts_cbranch_scc1 14f\n\ts_waitcnt vmcnt(%[c5])\n\ts_branch 19f\n"                         \
-                "10:\n\ts_waitcnt vmcnt(0)\n\ts_branch 19f\n11:\n\ts_waitcnt vmcnt(%[c1])\n\ts_branch 19f\n"                      \
-                "12:\n\ts_waitcnt vmcnt(%[c2])\n\ts_branch 19f\n13:\n\ts_waitcnt vmcnt(%[c3])\n\ts_branch 19f\n"                  \
-                "14:\n\ts_waitcnt vmcnt(%[c4])\n19:"
-#define MIXQ_WR_WAIT_IN [sel] "s"(sel), [c1] "i"(WNB), [c2] "i"(2 * WNB), [c3] "i"(3 * WNB), [c4] "i"(4 * WNB), [c5] "i"(5 * WNB)
+                MIXQ_WR_W1(1, 100) MIXQ_WR_W1(2, 101) MIXQ_WR_W1(3, 102) MIXQ_WR_W1(4, 103) MIXQ_WR_W1(5, 104) MIXQ_WR_W1(6, 105)            \
+                MIXQ_WR_W1(7, 106) MIXQ_WR_W1(8, 107) MIXQ_WR_W1(9, 108) MIXQ_WR_W1(10, 109) MIXQ_WR_W1(11, 110) MIXQ_WR_W1(12, 111)         \
+                MIXQ_WR_W1(13, 112) MIXQ_WR_W1(14, 113) MIXQ_WR_W1(15, 114) "s_waitcnt vmcnt(%[c15])\n\ts_branch 199f\n"                   \
+                "100:\n\ts_waitcnt vmcnt(0)\n\ts_branch 199f\n" MIXQ_WR_W2(101, c1) MIXQ_WR_W2(102, c2) MIXQ_WR_W2(103, c3)               \
+                MIXQ_WR_W2(104, c4) MIXQ_WR_W2(105, c5) MIXQ_WR_W2(106, c6) MIXQ_WR_W2(107, c7) MIXQ_WR_W2(108, c8) MIXQ_WR_W2(109, c9)      \
+                MIXQ_WR_W2(110, c10) MIXQ_WR_W2(111, c11) MIXQ_WR_W2(112, c12) MIXQ_WR_W2(113, c13) MIXQ_WR_W2(114, c14) "199:"
+#define MIXQ_WR_CL(v) ((v) < 64 ? (v) : 63)
+#define MIXQ_WR_WAIT_IN [sel] "s"(sel), [c1] "i"(MIXQ_WR_CL(WNB)), [c2] "i"(MIXQ_WR_CL(2 * WNB)), [c3] "i"(MIXQ_WR_CL(3 * WNB)),               \
+                [c4] "i"(MIXQ_WR_CL(4 * WNB)), [c5] "i"(MIXQ_WR_CL(5 * WNB)), [c6] "i"(MIXQ_WR_CL(6 * WNB)), [c7] "i"(MIXQ_WR_CL(7 * WNB)),      \
+                [c8] "i"(MIXQ_WR_CL(8 * WNB)), [c9] "i"(MIXQ_WR_CL(9 * WNB)), [c10] "i"(MIXQ_WR_CL(10 * WNB)), [c11] "i"(MIXQ_WR_CL(11 * WNB)), \
+                [c12] "i"(MIXQ_WR_CL(12 * WNB)), [c13] "i"(MIXQ_WR_CL(13 * WNB)), [c14] "i"(MIXQ_WR_CL(14 * WNB)), [c15] "i"(MIXQ_WR_CL(15 * WNB))
                 if constexpr (WNB == 1) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]) : MIXQ_WR_WAIT_IN : "scc");
                 if constexpr (WNB == 2) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]) : MIXQ_WR_WAIT_IN : "scc");
                 if constexpr (WNB == 3) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]) : MIXQ_WR_WAIT_IN : "scc");
                 if constexpr (WNB == 4) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]), "+v"(wq[d][3]) : MIXQ_WR_WAIT_IN : "scc");
 #undef MIXQ_WR_WAITS
 #undef MIXQ_WR_WAIT_IN
+#undef MIXQ_WR_W1
+#undef MIXQ_WR_W2
+#undef MIXQ_WR_CL
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -361,13 +375,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             for (int i = 0; i < WNB; ++i) wload1(d_c, i, decltype(d_c)::value < nk ? 1 : 0);
             wadvance(decltype(d_c)::value < nk ? 1 : 0);
         };
-        prologue_w(std::integral_constant<int, 0>{});
-        if constexpr (D > 1) prologue_w(std::integral_constant<int, 1>{});
-        if constexpr (D > 2) prologue_w(std::integral_constant<int, 2>{});
-        if constexpr (D > 3) prologue_w(std::integral_constant<int, 3>{});
-        if constexpr (D > 4) prologue_w(std::integral_constant<int, 4>{});
-        if constexpr (D > 5) prologue_w(std::integral_constant<int, 5>{});
-        static_assert(D >= 2 && D <= 6, "extend the prologue / the run-time wait table");
+        wr_static_for<0, D>(prologue_w);
+        static_assert(D >= 2 && D <= 16 && WNB * (D - 1) < 64, "weight ring depth: run-time wait table / vmcnt range");
         __builtin_amdgcn_s_barrier();                                            // B0
         stamp(1);
         // every scalar (kernel-argument) load has long returned; telling the compiler's counter model so keeps the loop
@@ -393,27 +402,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
             ++kt;
         };
-        auto group = [&](auto full_c) {
-            one(std::integral_constant<int, 0>{}, full_c);
-            one(std::integral_constant<int, 1>{}, full_c);
-            one(std::integral_constant<int, 2>{}, full_c);
-            if constexpr (NSLOT > 3) one(std::integral_constant<int, 3>{}, full_c);
-            if constexpr (NSLOT > 4) one(std::integral_constant<int, 4>{}, full_c);
-            if constexpr (NSLOT > 5) one(std::integral_constant<int, 5>{}, full_c);
-            if constexpr (NSLOT > 6) one(std::integral_constant<int, 6>{}, full_c);
-        };
+        auto group = [&](auto full_c) { wr_static_for<0, NSLOT>([&](auto c_c) { one(c_c, full_c); }); };
         while (kt + NSLOT + D <= nk) group(std::true_type{});                    // every k-step of the group has kt + D < nk
         while (kt < nk) {                                                        // fewer than NSLOT + D k-steps, guarded individually
             // (a group is entered at ring slot 0, so slot c holds k-step kt + c here as well)
             const int k0 = kt;
             auto tail_one = [&](auto c_c) { if (k0 + decltype(c_c)::value < nk) one(c_c, std::false_type{}); };
-            tail_one(std::integral_constant<int, 0>{});
-            tail_one(std::integral_constant<int, 1>{});
-            tail_one(std::integral_constant<int, 2>{});
-            if constexpr (NSLOT > 3) tail_one(std::integral_constant<int, 3>{});
-            if constexpr (NSLOT > 4) tail_one(std::integral_constant<int, 4>{});
-            if constexpr (NSLOT > 5) tail_one(std::integral_constant<int, 5>{});
-            if constexpr (NSLOT > 6) tail_one(std::integral_constant<int, 6>{});
+            wr_static_for<0, NSLOT>(tail_one);
         }
         stamp(2);
     }
@@ -641,6 +636,11 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 7, "128x192_abl7_nostore"),// 17: cfg 0 without the stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// 18: cfg 0 with ordinary (not nt) stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 9, "128x192_abl9_empty"),  // 19: returns at entry: the launch floor of this grid and LDS footprint
+    // small batches (M <= 32) of wide layers (N >= 8192): a weight stream, one 64-channel panel per workgroup.  12.4 us against
+    // the 17.4 us of gemm_skinny.hip's in-workgroup K split at 32 x 4096 -> 11008 with cold weights; deeper weight rings (10, 14
+    // k-steps) are slower (13.8, 14.0 us), narrow layers (N = 4096: 64 panels for 256 CUs) stay with gemm_skinny.hip
+    // (profiles/r02_decode.txt)
+    MIXQ_WR(2, 1, 8, 6, 1, 0, "32x64_s8_d6_l1"),       // 20
 };
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
 int g_wr_krot = 0;
@@ -660,7 +660,7 @@ const char* mixq_wr_config_name(int c) { return (c >= 0 && c < NUM_WR) ? g_wr[c]
 int mixq_wr_pick(int bit, int M, int N, int KB)
 {
     (void)bit;
-    if (M <= 32) return 10;                              // (decode normally runs the weight-stream kernel of gemm_skinny.hip)
+    if (M <= 32) return 20;                              // (narrow layers run the weight-stream kernel of gemm_skinny.hip instead)
     static const struct { int cfg; float tk, fixed; } cand[] = {
         {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f},
         {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};

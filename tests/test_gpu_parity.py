@@ -808,6 +808,31 @@ def test_skinny_is_the_automatic_choice_for_decode_and_refuses_large_batches():
     assert np.array_equal(bits(y_auto), bits(y_forced))
 
 
+@pytest.mark.parametrize("M", [1, 16, 32])
+def test_wide_layers_at_small_batch_take_the_32x64_weight_stream_tiling(M):
+    """M <= 32 with fragment-order int8 weights and N >= 8192 (up / gate projections): the weights-in-registers 32 x 64 tiling is the
+    automatic choice (12.4 us vs 17.4 us at 32 x 4096 -> 11008, profiles/r02_decode.txt); narrow layers and int4 stay with the
+    in-workgroup K split.  Same bits as the decode kernel and as the oracle-checked tiled kernel, outlier tail and bias included."""
+    lib = _capi.load()
+    names = _capi.gemm_config_names()
+    N, K = 8192 + 64, 640
+    assert names[lib.mixq_gemm_pick_config_fmt(M, N, K, 8, 2)] == "wr32x64_s8_d6_l1"
+    assert names[lib.mixq_gemm_pick_config_fmt(M, 4096, K, 8, 2)] == "decode32"
+    assert names[lib.mixq_gemm_pick_config_fmt(M, N, K, 4, 2)] == "decode32"
+    c = _fused_case(M, N, K, 8, seed=5 + M, n_out=41, bias=True, addend=False, act=0)
+    y_auto = n(_run_fused(c, 2, n_dev_cap=48))
+    try:
+        assert lib.mixq_gemm_set_config(_skinny_id()) == 0
+        y_dec = n(_run_fused(c, 2, n_dev_cap=48))
+        assert lib.mixq_gemm_set_config(names.index("wr64x64_s8_d4_l1")) == 0
+        y_t = n(_run_fused(c, 2, n_dev_cap=48))
+    finally:
+        lib.mixq_gemm_set_config(-1)
+    assert np.array_equal(bits(y_auto), bits(y_dec)) and np.array_equal(bits(y_auto), bits(y_t))
+    ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], bias=c["bias"], bit=8).astype(np.float32)
+    assert (np.abs(y_auto.astype(np.float32) - ref) <= ulp_tol(ref)).all()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # randomized exactness / race hunting: every real tiling, odd shapes, cold allocations, repeated launches
 # ---------------------------------------------------------------------------------------------------------------
