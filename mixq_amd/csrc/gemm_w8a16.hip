@@ -544,12 +544,16 @@ const WoConfig g_wo[] = {
     MIXQ_WO(4, 1, 8, 4, 1, 0, "64x64_s8_d4_l1"),       // 5
     MIXQ_WO(8, 3, 8, 4, 2, 0, "128x192_s8_d4_l2"),     // 6
     MIXQ_WO(8, 3, 6, 3, 1, 0, "128x192_s6_d3_l1"),     // 7
+    MIXQ_WO(2, 1, 8, 5, 1, 0, "32x64_s8_d5_l1"),       // 8: small batches of wide layers (see gemm_wreg.hip's 32x64 tiling)
     MIXQ_WO(8, 3, 8, 3, 2, 1, "128x192_abl1_noW"),     // tuning: cfg 0 without the weight loads
     MIXQ_WO(8, 3, 8, 3, 2, 2, "128x192_abl2_noX"),     // tuning: cfg 0 without X traffic
     MIXQ_WO(8, 3, 8, 3, 2, 3, "128x192_abl3_mfma"),    // tuning: MFMA + epilogue only
     MIXQ_WO(8, 3, 8, 3, 2, 4, "128x192_abl4_cvt"),     // tuning: MFMA + conversions
 };
 constexpr int NUM_WO_PICK = 6;
+// M <= 32: the 32 x 64 tiling (one 64-channel weight panel per workgroup, 5 k-steps of weights in flight per wave): 11.7 us against
+// 20.6 us for gemm_w8a16_skinny_kernel at 32 x 4096 -> 11008, 11.1 vs 11.5 us at 4096 -> 4096 (profiles/r02_decode.txt)
+constexpr int WO_SMALL = 8;
 constexpr int NUM_WO = sizeof(g_wo) / sizeof(g_wo[0]);
 int g_wo_forced = -1;
 
@@ -593,12 +597,12 @@ extern "C" int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_pack
     WoArgs a;
     a.x = x; a.w = w_packed; a.sw = scale_col; a.bias = bias; a.y = y;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldy = ldy; a.tiles_m = a.tiles_n = 0; a.wblocks = (N + 15) >> 4;
-    if ((g_wo_forced < 0 && M <= 32) || g_wo_forced == NUM_WO) {                 // small batch: the weight-stream form
+    if (g_wo_forced == NUM_WO) {                                                 // the in-workgroup K-split form: explicit only (slower, see WO_SMALL)
         if (M > 32) return MIXQ_EINVAL;
         hipLaunchKernelGGL(gemm_w8a16_skinny_kernel, dim3((N + 31) / 32), dim3(WSK * 64), 0, mixq_stream(stream), a);
         return mixq_launch_status();
     }
-    const int c = (g_wo_forced >= 0 && g_wo_forced < NUM_WO) ? g_wo_forced : pick_wo(M, N, K);
+    const int c = (g_wo_forced >= 0 && g_wo_forced < NUM_WO) ? g_wo_forced : (M <= 32 ? WO_SMALL : pick_wo(M, N, K));
     const WoConfig& g = g_wo[c];
     const int bm = g.mb * 16, bn = g.wnb * 64;
     a.tiles_m = wo_cdiv(M, bm); a.tiles_n = wo_cdiv(N, bn);

@@ -619,10 +619,14 @@ def _w8a16_case(M, N, K, seed, bias):
 
 @pytest.mark.parametrize("M,N,K,bias", [(1, 64, 64, False), (7, 192, 128, True), (33, 100, 256, False), (128, 128, 512, True),
                                         (300, 1000, 1024, False), (512, 1536, 4096, True), (16, 4096, 4096, False), (64, 36, 192, True)])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, "w8a16_32x64_s8_d5_l1", "w8a16_decode32"])
 def test_w8a16_linear_vs_oracle(M, N, K, bias, cfg):
     q, s, x, b = _w8a16_case(M, N, K, 7 * M + N + K, bias)
     lib = _capi.load()
+    if isinstance(cfg, str):
+        if cfg.endswith("decode32") and M > 32:
+            pytest.skip("the in-workgroup K-split kernel takes M <= 32")
+        cfg = _capi.w8a16_config_names().index(cfg)
     assert lib.mixq_gemm_w8a16_set_config(cfg) == 0
     try:
         wp = mixlib.PackW8A16(t(q))

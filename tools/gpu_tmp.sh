@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/ -m gpu -q --timeout 900 -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|AssertionError|launch" | head -20
-timeout 2400 python -m pytest tests/ -m gpu -q --timeout 900 -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|AssertionError|launch" | head -20
+timeout 2400 python -m pytest tests/ -m gpu -q --timeout 900 -p no:cacheprovider -x 2>&1 | tail -4
