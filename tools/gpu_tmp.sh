@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/ -m gpu -q --timeout 900 -p no:cacheprovider -x 2>&1 | tail -4
+timeout 1200 python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02w_configs.txt
+timeout 600 python tools/time_arch9.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02w_arch9.txt
