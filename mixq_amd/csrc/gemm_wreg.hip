@@ -66,7 +66,7 @@ template <int I, int N, class F> __device__ __forceinline__ void wr_static_for(F
 // D: weight register ring depth (k-steps), I4: nibble-packed operands, LOADERS: DMA waves, ABL (tuning): 0 normal,
 // 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only, 4 weight loads issued but never waited for, 5 the loader
 // never waits for its DMA, 6 no k-loop barriers (4-6: timing probes, results are garbage), 7 no stores of Y, 8 ordinary instead of
-// nt stores, 9 return at entry.
+// nt stores, 9 return at entry, 12 no prologue ramp in the loader.
 template <int MB, int WNB, int NSTAGE, int D, bool I4, int LOADERS, int ABL>
 __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const WrArgs a)
 {
@@ -135,12 +135,33 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             xoff += xks;
             if (++xk == nk) { xk = 0; xoff = 0; }
         };
+        // Deep rings start with a RAMP: all 232 workgroups asking for LOOK stages at once (14 x 8 KiB each at the metric tile) puts
+        // 26 MB of requests in front of everybody's first stage.  RP stages are requested up front, then two per k-step until the
+        // loader is LOOK stages ahead.  (slot of stage RP + 2 i + 1 was last read LOOK + 2 k-steps earlier: free, as in steady state)
+        constexpr int RP = (LOOK > 6 && ABL != 12) ? 4 : LOOK;
+        int nxt, kt = 0;
+        if (RP < LOOK && nk >= 2 * LOOK) {
 #pragma unroll
-        for (int s = 0; s < LOOK; ++s)
-            if (s < nk) stage(s);
-        if (NEWER < nk) wr_wait_vmcnt<LOADS * NEWER>(); else wr_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                                            // B0: stage 0 landed
-        int nxt = LOOK % NSTAGE, kt = 0;
+            for (int s = 0; s < RP; ++s) stage(s);
+            wr_wait_vmcnt<LOADS * (RP - 1)>();
+            __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
+            wr_static_for<0, LOOK - RP>([&](auto i_c) {
+                constexpr int i = decltype(i_c)::value;
+                stage((RP + 2 * i) % NSTAGE);
+                stage((RP + 2 * i + 1) % NSTAGE);
+                wr_wait_vmcnt<LOADS * (RP + i)>();                               // stage i + 1 landed: RP + i younger stages may be in flight
+                if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
+            });
+            kt = LOOK - RP;
+            nxt = (2 * LOOK - RP) % NSTAGE;
+        } else {
+#pragma unroll
+            for (int s = 0; s < LOOK; ++s)
+                if (s < nk) stage(s);
+            if (NEWER < nk) wr_wait_vmcnt<LOADS * NEWER>(); else wr_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
+            nxt = LOOK % NSTAGE;
+        }
         for (; kt + LOOK < nk; ++kt) {
             stage(nxt);
             if constexpr (ABL != 5) wr_wait_vmcnt<LOADS * NEWER>();              // stage kt+1 landed
@@ -641,6 +662,7 @@ const WrConfig g_wr[] = {
     // k-steps) are slower (13.8, 14.0 us), narrow layers (N = 4096: 64 panels for 256 CUs) stay with gemm_skinny.hip
     // (profiles/r02_decode.txt)
     MIXQ_WR(2, 1, 8, 6, 1, 0, "32x64_s8_d6_l1"),       // 20
+    MIXQ_WR(8, 3, 16, 4, 2, 12, "128x192_abl12_noramp"),// 21: cfg 0 with all LOOK stages requested at once (the form before the ramp)
 };
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
 int g_wr_krot = 0;
