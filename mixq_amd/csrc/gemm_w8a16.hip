@@ -47,6 +47,10 @@ __device__ __forceinline__ int wo_xpos(int t, int q) { return q ^ ((t >> 1) & 5)
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
+template <int I, int N, class F> __device__ __forceinline__ void wo_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); wo_static_for<I + 1, N>(f); }
+}
+
 // 4 offset-binary bytes -> 4 halves (two dwords)
 __device__ __forceinline__ void cvt_u8x4(uint32_t d, uint32_t& o0, uint32_t& o1) {
     const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, d, 0x04010400u);      // (0x64, b1, 0x64, b0)
@@ -58,7 +62,7 @@ __device__ __forceinline__ void cvt_u8x4(uint32_t d, uint32_t& o0, uint32_t& o1)
 
 // MB: 16-row token blocks per tile (BM = 16 MB), WNB: 16-channel weight blocks per wave (BN = 64 WNB), NSTAGE: X ring depth,
 // D: weight register ring depth (k-steps), LOADERS: DMA waves.  ABL (tuning only): 0 normal, 1 no weight loads, 2 no X traffic,
-// 3 MFMA only, 4 MFMA + conversions (results of 1-4 are garbage).
+// 3 MFMA only, 4 MFMA + conversions (results of 1-4 are garbage), 5 no prologue ramp in the loader.
 template <int MB, int WNB, int NSTAGE, int D, int LOADERS, int ABL = 0>
 __global__ __launch_bounds__((WO_CW + LOADERS) * 64) void gemm_w8a16_kernel(const WoArgs a)
 {
@@ -68,7 +72,7 @@ __global__ __launch_bounds__((WO_CW + LOADERS) * 64) void gemm_w8a16_kernel(cons
     constexpr int PIECES = MB * 2, LOADS = PIECES / LOADERS;
     constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
     constexpr int OPITCH = BN * 2 + 16;
-    constexpr bool NOW = ABL == 1 || ABL >= 3, NOX = ABL >= 2;
+    constexpr bool NOW = ABL == 1 || ABL == 3 || ABL == 4, NOX = ABL >= 2 && ABL <= 4;
     static_assert(LOADERS >= 1 && PIECES % LOADERS == 0, "pieces must divide evenly over the loader waves");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
     static_assert(NSTAGE * STAGE_BYTES <= 160 * 1024 && BM * OPITCH <= NSTAGE * STAGE_BYTES, "LDS: ring and staging tile");
@@ -110,12 +114,32 @@ __global__ __launch_bounds__((WO_CW + LOADERS) * 64) void gemm_w8a16_kernel(cons
             }
             koff += 128;
         };
+        // ramp (as in gemm_wreg.hip): RP stages up front, then two per k-step until the loader is LOOK stages ahead, instead of every
+        // workgroup asking for LOOK x 16 MB KiB at once in front of its first stage
+        constexpr int RP = (LOOK > 4 && ABL != 5) ? 3 : LOOK;
+        int nxt, kt = 0;
+        if (RP < LOOK && nk >= 2 * LOOK) {
 #pragma unroll
-        for (int s = 0; s < LOOK; ++s)
-            if (s < nk) stage(s);
-        if (NEWER < nk) wo_wait_vmcnt<LOADS * NEWER>(); else wo_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                                            // B0: stage 0 landed
-        int nxt = LOOK % NSTAGE, kt = 0;
+            for (int s = 0; s < RP; ++s) stage(s);
+            wo_wait_vmcnt<LOADS * (RP - 1)>();
+            __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
+            wo_static_for<0, LOOK - RP>([&](auto i_c) {
+                constexpr int i = decltype(i_c)::value;
+                stage((RP + 2 * i) % NSTAGE);
+                stage((RP + 2 * i + 1) % NSTAGE);
+                wo_wait_vmcnt<LOADS * (RP + i)>();                               // stage i + 1 landed: RP + i younger stages may be in flight
+                __builtin_amdgcn_s_barrier();
+            });
+            kt = LOOK - RP;
+            nxt = (2 * LOOK - RP) % NSTAGE;
+        } else {
+#pragma unroll
+            for (int s = 0; s < LOOK; ++s)
+                if (s < nk) stage(s);
+            if (NEWER < nk) wo_wait_vmcnt<LOADS * NEWER>(); else wo_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
+            nxt = LOOK % NSTAGE;
+        }
         for (; kt + LOOK < nk; ++kt) {
             stage(nxt);
             wo_wait_vmcnt<LOADS * NEWER>();                                      // stage kt+1 landed
@@ -165,9 +189,9 @@ __global__ __launch_bounds__((WO_CW + LOADERS) * 64) void gemm_w8a16_kernel(cons
 #pragma unroll
             for (int i = 0; i < WNB; ++i) {
                 wq[d][i] = i32x4{lane, lane, lane, lane};
-                if constexpr (ABL != 0) asm volatile("" : "+v"(wq[d][i]));
+                if constexpr (ABL >= 1 && ABL <= 4) asm volatile("" : "+v"(wq[d][i]));
             }
-        if constexpr (ABL != 0) {
+        if constexpr (ABL >= 1 && ABL <= 4) {
 #pragma unroll
             for (int j = 0; j < MB; ++j) { xf[j] = u32x4{(uint32_t)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(xf[j])); }
 #pragma unroll
@@ -549,6 +573,7 @@ const WoConfig g_wo[] = {
     MIXQ_WO(8, 3, 8, 3, 2, 2, "128x192_abl2_noX"),     // tuning: cfg 0 without X traffic
     MIXQ_WO(8, 3, 8, 3, 2, 3, "128x192_abl3_mfma"),    // tuning: MFMA + epilogue only
     MIXQ_WO(8, 3, 8, 3, 2, 4, "128x192_abl4_cvt"),     // tuning: MFMA + conversions
+    MIXQ_WO(8, 3, 8, 3, 2, 5, "128x192_abl5_noramp"),  // tuning: cfg 0 with all LOOK stages requested at once
 };
 constexpr int NUM_WO_PICK = 6;
 // M <= 32: the 32 x 64 tiling (one 64-channel weight panel per workgroup, 5 k-steps of weights in flight per wave): 11.7 us against
