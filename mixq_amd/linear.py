@@ -280,6 +280,28 @@ class MixLinear_GEMM(nn.Module):
             self._wpk, self._wpk_key = None, None                        # re-packed on the next forward
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    def _apply(self, fn, *args, **kwargs):
+        """nn.Module.to / .cuda / .half walk parameters and buffers only; after compaction the weights live in `_wpk` (a plain
+        attribute), so the packed image follows the module here and everything derived from the old tensors is rebuilt."""
+        out = super()._apply(fn, *args, **kwargs)
+        if self.__dict__.get("_wpk") is not None:
+            moved = fn(self._wpk)
+            if moved is not self._wpk:
+                tag = _fmt_of(self._wpk)
+                if hasattr(_backend, "set_fmt"):
+                    _backend.set_fmt(moved, tag)
+                self._wpk = moved
+        self._wpk_key = None                                             # (re-packed from q_weight when that buffer still exists)
+        if isinstance(self.__dict__.get("weight_cache"), Tensor):
+            self.weight_cache = fn(self.weight_cache)                    # 8-bit layers keep it as a plain attribute (linear.py:42)
+        if isinstance(self.__dict__.get("ind"), Tensor):
+            self.ind = fn(self.ind)
+        self._wstore = None
+        self._wo_ready = self._wo_key = None
+        self._ind_buf = self._ind_key = None
+        self._n_dev, self._n_dev_host = None, -1
+        return out
+
     def x_fmt(self):
         """Layout this layer wants its quantised activation in (what a fused norm in front of it should emit)."""
         wpk = self._packed_weight()

@@ -1124,6 +1124,31 @@ def test_gemm_reads_the_outlier_count_from_device_memory(M, N, K, bit, n_out, ca
     assert np.array_equal(bits(n(_run_fused(c, fmt))), bits(n(_run_fused(c, fmt, n_dev_cap=cap))))      # same bits as the host count
 
 
+def test_module_apply_carries_the_packed_only_weights():
+    """After compaction the weights exist only as the packed image, a plain attribute nn.Module.to() / .cuda() would not touch:
+    _apply moves it with the module and drops every cache derived from the old tensors.  (One GPU here: the walk is exercised with
+    a cloning function, and with .to() / .half() as no-ops.)"""
+    M, K, N = 48, 512, 320
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(K, N, bias=True).half()
+    cache = MixLibCache(M, device=DEV)
+    layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(5)).half()
+    x[:, [7, 300]] *= 30
+    for _ in range(3):
+        y0 = layer(x.clone().to(DEV), None, True)
+    assert layer._buffers["q_weight"] is None and layer.ind.numel() == 2
+    old = layer._wpk
+    layer._apply(lambda t: t.clone())
+    assert layer._wpk is not old and mixlib.fmt_of(layer._wpk) == mixlib.fmt_of(old) and torch.equal(layer._wpk, old)
+    y1 = layer(x.clone().to(DEV), None, True)
+    assert torch.equal(y0, y1)
+    layer.to(DEV).half()
+    assert torch.equal(layer(x.clone().to(DEV), None, True), y0)
+    sd = layer.state_dict()
+    assert sd["q_weight"].shape == (N, K) and sd["q_weight"].dtype == torch.int8
+
+
 def test_operator_runs_on_the_device_count():
     """The operator hands the kernels `ind` / outlier operands of capacity pad16(n) with the count in `cache.n_dev`: after
     the search froze, lowering the DEVICE count (no host-side change, nothing re-captured) drops exactly those columns."""
