@@ -1124,6 +1124,33 @@ def test_gemm_reads_the_outlier_count_from_device_memory(M, N, K, bit, n_out, ca
     assert np.array_equal(bits(n(_run_fused(c, fmt))), bits(n(_run_fused(c, fmt, n_dev_cap=cap))))      # same bits as the host count
 
 
+def test_operator_at_prefill_batch_sizes_ragged_m():
+    """M = 4099 tokens (33 M-tiles of 128, the last one 3 rows) through the operator: sampled rows against the oracle, every row against
+    the first-128-row result of the same layer (rows are independent: a row's output must not depend on the batch it arrives in)."""
+    M, K, N = 4099, 1024, 768
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(K, N, bias=True).half()
+    cache = MixLibCache(M, device=DEV)
+    layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
+    cols = [5, 130, 1000]
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).half()
+    x[:, cols] *= 25
+    for _ in range(3):
+        y = layer(x.clone().to(DEV), None, True)
+    assert layer.add_outliers is False and set(cols) <= set(n(layer.ind).tolist())
+    rows = [0, 127, 128, 2047, 4095, 4096, 4098]
+    ind = n(layer.ind).astype(np.int32)
+    xh = x.numpy()[rows].copy()
+    xo = O.extract_outliers_zero(xh, ind)
+    qx, sx = O.find_row_scale(xh, 8)
+    ref = O.linear_fused(qx, n(layer.q_weight), sx, n(layer.scale_col), xo=xo, wo=n(layer.weight_cache), bias=n(layer.bias)).astype(np.float32)
+    got = n(y)[rows].astype(np.float32)
+    assert (np.abs(got - ref) <= ulp_tol(ref)).all(), float(np.abs(got - ref).max())
+    cache2 = MixLibCache(128, device=DEV)
+    y_small = layer(x[4096 - 125:4096 + 3].clone().to(DEV), cache2, True)
+    assert torch.equal(y_small, y[4096 - 125:4096 + 3])
+
+
 def test_module_apply_carries_the_packed_only_weights():
     """After compaction the weights exist only as the packed image, a plain attribute nn.Module.to() / .cuda() would not touch:
     _apply moves it with the module and drops every cache derived from the old tensors.  (One GPU here: the walk is exercised with
