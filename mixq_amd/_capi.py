@@ -134,21 +134,24 @@ def device_info() -> str:
     return buf.value.decode()
 
 
-_workspace = None
+_workspaces = {}
 
 
 def ensure_workspace(device=None):
-    """Allocate (once per process) and register the zero-filled stream-K workspace on the current GPU."""
-    global _workspace
-    if _workspace is None:
-        import torch
+    """Allocate (once per process and device) and register the zero-filled stream-K workspace on that GPU."""
+    import torch
+    dev = torch.device(device or "cuda")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _workspaces:
         lib = load()
         nbytes = int(lib.mixq_gemm_workspace_bytes())
-        _workspace = torch.zeros(nbytes, dtype=torch.uint8, device=device or "cuda")
-        rc = lib.mixq_gemm_set_workspace(_workspace.data_ptr(), nbytes)
+        with torch.cuda.device(idx):
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=f"cuda:{idx}")
+            rc = lib.mixq_gemm_set_workspace(ws.data_ptr(), nbytes)      # registered for the device that is current here
         if rc != 0:
             raise MixqError("mixq_gemm_set_workspace", rc)
-    return _workspace
+        _workspaces[idx] = ws
+    return _workspaces[idx]
 
 
 def w8a16_config_names():

@@ -435,9 +435,15 @@ const SkConfig g_sk[] = {
 };
 constexpr int NUM_SK = sizeof(g_sk) / sizeof(g_sk[0]);
 
-void* g_ws = nullptr;
-size_t g_ws_bytes = 0;
-int g_num_cu = 0;
+// per-device state (one process may drive several GPUs): the registered workspace and the CU count of the CURRENT device
+constexpr int SK_MAX_DEV = 64;
+struct SkDev { void* ws; size_t bytes; int num_cu; };
+SkDev g_dev[SK_MAX_DEV] = {};
+SkDev* sk_dev() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SK_MAX_DEV) { (void)hipGetLastError(); return nullptr; }
+    return &g_dev[dev];
+}
 
 }  // namespace
 
@@ -452,14 +458,15 @@ constexpr size_t SK_FLAG_BYTES = 4096;                   // up to 1024 workgroup
 size_t mixq_sk_workspace_need(int c, int G) { return SK_FLAG_BYTES + static_cast<size_t>(G) * g_sk[c].bm * g_sk[c].bn * 4; }
 
 bool mixq_sk_usable(int c) {
-    if (c < 0 || c >= NUM_SK || !g_ws) return false;
-    if (g_num_cu == 0) {
+    SkDev* d = sk_dev();
+    if (c < 0 || c >= NUM_SK || !d || !d->ws) return false;
+    if (d->num_cu == 0) {
         int dev = 0;
         hipDeviceProp_t p;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-        g_num_cu = p.multiProcessorCount;
+        d->num_cu = p.multiProcessorCount;
     }
-    return g_num_cu > 0 && mixq_sk_workspace_need(c, g_num_cu) <= g_ws_bytes;
+    return d->num_cu > 0 && mixq_sk_workspace_need(c, d->num_cu) <= d->bytes;
 }
 
 int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
@@ -478,11 +485,12 @@ int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
     a.nk = KB / BKB;
     a.total_units = a.tiles_m * a.tiles_n * a.nk;
-    a.G = g_num_cu < a.total_units ? g_num_cu : a.total_units;
+    SkDev* d = sk_dev();
+    a.G = d->num_cu < a.total_units ? d->num_cu : a.total_units;
     if (const char* e = getenv("MIXQ_SK_G")) { const int g2 = atoi(e); if (g2 > 0 && g2 <= a.G) a.G = g2; }     // tuning only
     if (const char* e = getenv("MIXQ_SK_DBG")) a.dbg = atoi(e);
-    a.flags = static_cast<int32_t*>(g_ws);
-    a.ws = reinterpret_cast<int32_t*>(static_cast<char*>(g_ws) + SK_FLAG_BYTES);
+    a.flags = static_cast<int32_t*>(d->ws);
+    a.ws = reinterpret_cast<int32_t*>(static_cast<char*>(d->ws) + SK_FLAG_BYTES);
     if (static_cast<size_t>(a.G) * 4 > SK_FLAG_BYTES) return MIXQ_EINVAL;
     void (*k)(const SkArgs) = bit == 8 ? g.k8 : g.k4;
     const size_t shm = static_cast<size_t>(g.bm + g.bn) * BKB * g.nstage;
@@ -494,8 +502,10 @@ int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
 extern "C" int mixq_gemm_set_workspace(void* ws, long long bytes)
 {
     if (bytes < 0 || (bytes > 0 && !ws)) return MIXQ_EINVAL;
-    g_ws = bytes ? ws : nullptr;
-    g_ws_bytes = static_cast<size_t>(bytes);
+    SkDev* d = sk_dev();                                 // the workspace belongs to the device that is current at registration
+    if (!d) return MIXQ_ENODEV;
+    d->ws = bytes ? ws : nullptr;
+    d->bytes = static_cast<size_t>(bytes);
     return MIXQ_OK;
 }
 
