@@ -232,8 +232,8 @@ def main(argv=None):
         return dry_run(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: mixq_amd has no CPU path (the CPU numbers it prints are the baseline only)")
+    torch.cuda.set_device(dist_env()[1])                         # before the process group exists: RCCL binds to the current device
     rank, local_rank, world = init_dist(args.gpus, args.backend)
-    torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from mixq_amd import _capi, mixlib
     info = _capi.device_info()                                  # loads libmixq_hip.so; raises if it is missing
