@@ -125,6 +125,107 @@ def FindRowScale(x, x_scale, M, K, bit=8):
     return q
 
 
+# ---- opt-in: the outlier product fused into the GEMM behind the UNCHANGED reference operator ------------------------------
+# The reference computes `outliers_fp16 = torch.mm(cache.activation_outliers, self.weight_cache.T)` (linear.py:236,248) - an [M,N] fp16
+# tensor written by one kernel and read back as the addend of the next - where the native operator runs the same product as the fp16
+# MFMA tail of the int8 GEMM.  With set_fused_outliers(True) ExtractOutliersAndSetToZeros returns its (real) [M,n] tensor as an
+# OutlierActivations; torch.mm / matmul / @ of THAT tensor with a transposed fp16 [N,n] matrix yields a PendingOutlierProduct: an [M,N]
+# fp16 tensor whose values are only computed if something other than a mixlib GEMM entry point looks at them.  The GEMM entry points
+# take the two factors as their outlier operands instead.  Off by default because it changes one rounding: the literal route rounds
+# the product to fp16 before it is added (torch.mm), the fused tail adds it in fp32 like the native operator (include/mixq_hip.h,
+# convention 2; <= 2 fp16 ulp apart).
+_fused_outliers = False
+_wo_padded = {}        # (data_ptr, version, shape, stride) -> weight_cache re-laid with a 16-column-padded pitch
+
+
+def set_fused_outliers(enabled):
+    global _fused_outliers
+    prev, _fused_outliers = _fused_outliers, bool(enabled)
+    if not enabled:
+        _wo_padded.clear()
+    return prev
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+class OutlierActivations(torch.Tensor):
+    """x_out [M,n] as returned by ExtractOutliersAndSetToZeros under set_fused_outliers(True): a view of 16-column-padded storage
+    (what the GEMM's tail reads) that recognises the reference's torch.mm with weight_cache.T."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        T = torch.Tensor
+        if _fused_outliers and not kwargs and len(args) == 2 and func in (torch.mm, torch.matmul, T.mm, T.matmul, T.__matmul__):
+            a, b = args
+            if (isinstance(a, OutlierActivations) and isinstance(b, torch.Tensor) and not isinstance(b, OutlierActivations)
+                    and a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0] and a.shape[1] > 0
+                    and a.dtype == torch.float16 and b.dtype == torch.float16 and b.device == a.device and b.stride(0) == 1):
+                return PendingOutlierProduct(a, b)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+class PendingOutlierProduct(torch.Tensor):
+    """torch.mm(activation_outliers, weight_cache.T), deferred: see set_fused_outliers."""
+
+    @staticmethod
+    def __new__(cls, xo, wo_t):
+        t = torch.Tensor._make_subclass(cls, torch.empty((xo.shape[0], wo_t.shape[1]), dtype=torch.float16, device=xo.device))
+        t._mixq_args = (xo, wo_t)
+        t._mixq_done = False
+        return t
+
+    def _materialize(self):
+        if getattr(self, "_mixq_done", True):
+            return
+        self._mixq_done = True
+        with torch._C.DisableTorchFunctionSubclass():
+            xo, wo_t = self._mixq_args
+            torch.mm(xo.as_subclass(torch.Tensor), wo_t, out=self.as_subclass(torch.Tensor))
+        self._mixq_args = None
+
+    def _operands(self):
+        """(x_out, ldxo-ready tensor, w_out padded, n) for the fused tail, or None once materialised."""
+        if getattr(self, "_mixq_done", True):
+            return None
+        xo, wo_t = self._mixq_args
+        n = xo.shape[1]
+        wo = wo_t.t()                                        # [N, n], unit column stride
+        pad = _pad16(n)
+        with torch._C.DisableTorchFunctionSubclass():
+            xo = xo.as_subclass(torch.Tensor)
+            if xo.stride(1) != 1 or xo.stride(0) % 8 or xo.stride(0) < pad or xo.data_ptr() % 16:
+                return None                                  # not the padded storage ExtractOutliersAndSetToZeros hands out
+            if wo.stride(0) % 8 or wo.stride(0) < pad or wo.data_ptr() % 16:
+                key = (wo.data_ptr(), wo._version, tuple(wo.shape), wo.stride(0))
+                wp = _wo_padded.get(key)
+                if wp is None:
+                    if len(_wo_padded) > 1024:
+                        _wo_padded.clear()
+                    buf = torch.zeros((wo.shape[0], pad), dtype=torch.float16, device=wo.device)
+                    buf[:, :n] = wo
+                    wp = _wo_padded[key] = buf
+                wo = wp[:, :n]
+        return xo, wo, n
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func not in _meta_funcs():
+            for a in list(args) + list(kwargs.values()):
+                if isinstance(a, PendingOutlierProduct):
+                    a._materialize()
+                elif isinstance(a, (list, tuple)):
+                    for b in a:
+                        if isinstance(b, PendingOutlierProduct):
+                            b._materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
 def ExtractOutliersAndSetToZeros(ind, x):
     """mixlib.ExtractOutliersAndSetToZeros(ind, x) -> x_out [M,n]; zeroes columns `ind` of x IN PLACE (linear.py:189,205)."""
     _dev_check(ind, x)
@@ -134,10 +235,24 @@ def ExtractOutliersAndSetToZeros(ind, x):
     xp, ldx = _rows(x, "x")
     M, K = x.shape
     n = ind.numel()
+    if _fused_outliers and n:
+        buf = torch.empty((M, _pad16(n)), dtype=torch.float16, device=x.device)          # (columns >= n: never read as values)
+        _capi.call("mixq_extract_outliers_zero", xp, ind.data_ptr(), n, buf.data_ptr(), M, K, ldx, buf.shape[1], _stream())
+        return buf[:, :n].as_subclass(OutlierActivations)
     out = torch.empty((M, n), dtype=torch.float16, device=x.device)
     if n:
         _capi.call("mixq_extract_outliers_zero", xp, ind.data_ptr(), n, out.data_ptr(), M, K, ldx, n, _stream())
     return out
+
+
+def _outlier_operands(addend):
+    """(x_out ptr, ldxo, w_out ptr, ldwo, n, keepalive) when `addend` is a still-deferred outlier product, else None."""
+    if isinstance(addend, PendingOutlierProduct):
+        ops = addend._operands()
+        if ops is not None:
+            xo, wo, n = ops
+            return xo.data_ptr(), xo.stride(0), wo.data_ptr(), wo.stride(0), n, (xo, wo)
+    return None
 
 
 def _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, bit, act):
@@ -147,14 +262,21 @@ def _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, bit, act):
         if fmt_of(q_w) == FMT_PLAIN:
             raise RuntimeError("mixq_amd.mixlib: packed q_x with a plain weight that cannot be packed (K % 64)")
     y = torch.empty((M, N), dtype=torch.float16, device=q_x.device)
-    if _is_zero_addend(addend):
+    xop, ldxo, wop, ldwo, n_out = None, 0, None, 0, 0
+    outl = _outlier_operands(addend)
+    if outl is not None and tuple(addend.shape) == (M, N):
+        xop, ldxo, wop, ldwo, n_out, _keep = outl            # the product runs as the GEMM's fp16 tail; nothing is added afterwards
+        ap, lda = None, 0
+    elif _is_zero_addend(addend):
         ap, lda = None, 0
     else:
+        if isinstance(addend, PendingOutlierProduct):
+            addend._materialize()
         _dev_check(addend)
         ap, lda = _rows(addend, "addend")
     fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"
     _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(),
-               None, 0, None, 0, 0, None, ap, lda, None, y.data_ptr(), N, M, N, K, act, _layout_bits(fmt_of(q_x), fmt_of(q_w)),
+               xop, ldxo, wop, ldwo, n_out, None, ap, lda, None, y.data_ptr(), N, M, N, K, act, _layout_bits(fmt_of(q_x), fmt_of(q_w)),
                _stream())
     return y
 
@@ -279,6 +401,8 @@ def _dequant(y32, x_scale, scale_col, addend, bit, M, N, act):
     if _is_zero_addend(addend):
         ap, lda = None, 0
     else:
+        if isinstance(addend, PendingOutlierProduct):
+            addend._materialize()                            # the literal pair adds the product as the reference computed it
         ap, lda = _rows(addend, "addend")
     yp, ldy32 = _rows(y32, "y32")
     _capi.call("mixq_dequant", yp, ldy32, x_scale.data_ptr(), scale_col.data_ptr(), ap, lda, None, y.data_ptr(), N, M, N,
@@ -452,6 +576,8 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
     elif _is_zero_addend(addend):
         ap, lda = None, 0
     else:
+        if isinstance(addend, PendingOutlierProduct):
+            addend._materialize()
         _dev_check(addend)
         ap, lda = _rows(addend, "addend")
     fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"

@@ -1315,6 +1315,57 @@ def test_wreg_kernel_under_graph_replay_and_cold_buffers():
         lib.mixq_gemm_set_config(-1)
 
 
+@pytest.mark.parametrize("route", ["arch9", "fused"])
+def test_fused_outliers_behind_the_reference_call_sequence(route):
+    """set_fused_outliers(True): the reference's own sequence - ExtractOutliersAndSetToZeros, FindRowScale, torch.mm(activation_outliers,
+    weight_cache.T), then gemm + dequantizeInt8 (linear.py:234-241) or int8FusedDequantize (:248-256) - runs the outlier product as the
+    fp16 tail of the int8 GEMM.  Same bits as the native operator's kernel on the same operands; within 2 fp16 ulp of the literal
+    route (which rounds the product to fp16 first); every other use of the deferred product still sees torch.mm's values."""
+    M, K, N = 96, 1024, 640
+    c = _fused_case(M, N, K, 8, seed=77, n_out=41, bias=False, addend=False, act=0)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(3)).half()
+    ind = torch.from_numpy(np.sort(np.random.default_rng(4).choice(K, 41, replace=False)).astype(np.int32)).to(DEV)
+    x[:, ind.cpu().long()] *= 20
+    q_weight, scale_col = t(c["qw"]), t(c["sw"]).reshape(1, N)
+    weight_cache = (torch.randn(N, 41, generator=torch.Generator().manual_seed(5)) / 8).half().to(DEV)       # plain [N,41]: unpadded pitch
+    x_scale = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+
+    def run():
+        xd = x.clone().to(DEV)
+        xo = mixlib.ExtractOutliersAndSetToZeros(ind, xd)
+        qx = mixlib.FindRowScale(xd, x_scale, M, K, 8)
+        mm = torch.mm(xo, weight_cache.T)
+        if route == "arch9":
+            return mixlib.dequantizeInt8(mixlib.gemm(qx, q_weight, M, N, K), x_scale, scale_col, mm, 8, M, N), xo, mm, qx
+        return mixlib.int8FusedDequantize(qx, q_weight, x_scale, scale_col, mm, M, N, K), xo, mm, qx
+
+    y_lit, xo_lit, mm_lit, qx = run()
+    assert type(mm_lit) is torch.Tensor
+    prev = mixlib.set_fused_outliers(True)
+    try:
+        y_f, xo_f, mm_f, _ = run()
+        assert isinstance(xo_f, mixlib.OutlierActivations) and isinstance(mm_f, mixlib.PendingOutlierProduct)
+        assert mm_f._mixq_done is False and tuple(mm_f.shape) == (M, N)                 # consumed by the GEMM, never computed
+        assert torch.equal(xo_f.as_subclass(torch.Tensor), xo_lit)
+        # the same operands through the native entry point (padded outlier operands, one fused kernel)
+        wo = torch.zeros((N, 48), dtype=torch.float16, device=DEV); wo[:, :41] = weight_cache
+        xo = torch.zeros((M, 48), dtype=torch.float16, device=DEV); xo[:, :41] = xo_lit
+        y_nat = mixlib.FusedLinear(qx, q_weight, x_scale, scale_col, xo[:, :41], wo[:, :41], 41, None, M, N, K)
+        assert torch.equal(y_f, y_nat)
+        d = (y_f.float() - y_lit.float()).abs()
+        assert (d <= 2 * torch.from_numpy(ulp_tol(n(y_lit).astype(np.float32))).to(DEV)).all(), float(d.max())
+        # any other use of the deferred product computes it: same values as the plain torch.mm
+        _, _, mm2, _ = run()
+        assert torch.equal(mm2 + 0, mm_lit) and mm2._mixq_done is True
+        # a product that was already looked at goes in as an ordinary addend
+        _, xo3, _, qx3 = run()
+        mm3 = torch.mm(xo3, weight_cache.T); _ = mm3.sum()
+        y3 = mixlib.int8FusedDequantize(qx3, q_weight, x_scale, scale_col, mm3, M, N, K)
+        assert torch.equal(y3, mixlib.int8FusedDequantize(qx3, q_weight, x_scale, scale_col, mm_lit, M, N, K))
+    finally:
+        mixlib.set_fused_outliers(prev)
+
+
 def test_gemm_shim_refuses_operands_that_do_not_match_m_n_k():
     """The reference's arch == 9 route calls mixlib.gemm for 4-bit layers too (linear.py:235) with nibble-packed [., K/2] operands and
     the full K: a byte GEMM over them would read past both buffers, so the shim raises instead of launching."""

@@ -43,15 +43,20 @@ def native():
     x = xs[i[0] % 8]; i[0] += 1
     return layer(x, None, True)
 flops = 2.0 * M * N * K
-for name, lazy, packed, fn in [("arch==9 route, deferred product (default)", True, False, seq_arch9),
-                               ("arch==9 route, literal pair", False, False, seq_arch9),
-                               ("fused branch (arch != 9): int8FusedDequantize, plain operands", True, False, seq_fused_branch),
-                               ("arch==9 route, deferred product + set_packed_operands(True)", True, True, seq_arch9),
-                               ("fused branch + set_packed_operands(True)", True, True, seq_fused_branch),
-                               ("native operator (packed operands, fused quantise + GEMM)", True, False, native)]:
+for name, lazy, packed, fo, fn in [("arch==9 route, deferred product (default)", True, False, False, seq_arch9),
+                                   ("arch==9 route, literal pair", False, False, False, seq_arch9),
+                                   ("fused branch (arch != 9): int8FusedDequantize, plain operands", True, False, False, seq_fused_branch),
+                                   ("arch==9 route, deferred product + set_packed_operands(True)", True, True, False, seq_arch9),
+                                   ("fused branch + set_packed_operands(True)", True, True, False, seq_fused_branch),
+                                   ("arch==9 route + set_fused_outliers(True)", True, False, True, seq_arch9),
+                                   ("arch==9 route + set_packed_operands(True) + set_fused_outliers(True)", True, True, True, seq_arch9),
+                                   ("fused branch + set_packed_operands(True) + set_fused_outliers(True)", True, True, True, seq_fused_branch),
+                                   ("native operator (packed operands, fused quantise + GEMM)", True, False, False, native)]:
     prev = mixlib.set_lazy_gemm(lazy)
     prevp = mixlib.set_packed_operands(packed)
+    prevo = mixlib.set_fused_outliers(fo)
     us = time_graph(fn, 50, 10)
+    mixlib.set_fused_outliers(prevo)
     mixlib.set_packed_operands(prevp)
     mixlib.set_lazy_gemm(prev)
-    print(f"{name:70s} {us:8.2f} us / forward  {flops / us / 1e6:7.1f} TFLOPS ({100 * flops / us / 1e6 / 5033:4.1f} % of peak)", flush=True)
+    print(f"{name:74s} {us:8.2f} us / forward  {flops / us / 1e6:7.1f} TFLOPS ({100 * flops / us / 1e6 / 5033:4.1f} % of peak)", flush=True)
