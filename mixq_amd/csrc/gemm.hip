@@ -91,6 +91,12 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
     constexpr int NEWER = LOOK - 1;                    // stages younger than the one a wait retires
     constexpr bool I4 = (MODE == 1);
     constexpr int OPITCH = BN * 2 + 16;                // bytes per row of the fp16 output staging tile
+    // Outlier-tail operands staged through the idle ring by the loader waves (epilogue): needs loaders and (BM + BN) x 256 bytes, and is
+    // compiled into the int4 kernels only.  W4A4 layers carry 128 outlier columns (fp_features_num, linear.py:123-143): as global
+    // fragment loads that tail costs 4.4 us at the metric tile, staged 2.6 us.  A short tail (W8A8's 41 columns) is faster from the
+    // register ring whose first k-steps are requested before the dequantisation (1.8 vs 2.9 us), and both forms in one kernel cost 98
+    // spilled registers - so the int8 kernels keep the ring, the int4 kernels stage (a short int4 tail pays ~1 us for it).
+    constexpr bool TAIL_LDS = LOADERS > 0 && MODE == 1 && (BM + BN) * 256 <= NSTAGE * STAGE_BYTES;
     static_assert((BM + BN) * CH % 64 == 0, "stage must be a whole number of 1-KiB DMA pieces");
     static_assert(BM % 16 == 0 && BN % 16 == 0, "tiles are made of 16-row blocks");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
@@ -184,9 +190,38 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                 wait_vmcnt<0>();
                 if constexpr (ABL != 8) __builtin_amdgcn_s_barrier();
             }
-            if constexpr (MODE != 2) {                   // take part in the epilogue's two barriers and its stores
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_s_barrier();
+            if constexpr (MODE != 2) {                   // take part in the epilogue's barriers and its stores
+                __builtin_amdgcn_s_barrier();            // every wave is done reading the ring
+                if constexpr (TAIL_LDS) {
+                    // The fp16 outlier tail's operands through LDS: as global fragment loads they are 32-byte pieces of 2 n-byte rows
+                    // (one cache line per lane pair, every tail k-step an exposed round trip: 4.4 us at 128 columns, the W4A4 case);
+                    // here the loader waves copy the tile's X_out and W_out rows - up to 128 columns = 256 contiguous bytes per
+                    // row and pass - into the idle ring with LDS-DMA (chunk c of row r at position c ^ (r & 15): conflict-free
+                    // fragment reads) while the consumers dequantise, and the tail MFMAs run out of LDS.
+                    int n_out_l = a.n_out;
+                    if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out_l = nd < n_out_l ? nd : n_out_l; }
+                    if (!a.xo || !a.wo || ABL == 6) n_out_l = 0;
+                    if (n_out_l > 0) {
+                        const int kpad_l = (n_out_l + 15) & ~15;
+                        const int lw = wave - CW;
+                        for (int pass0 = 0; pass0 < n_out_l; pass0 += 128) {
+                            if (pass0 > 0) __builtin_amdgcn_s_barrier();           // the previous pass has been consumed
+                            for (int q = lw; q < (BM + BN) / 4; q += LOADERS) {
+                                const int rr = 4 * q + (lane >> 4);
+                                int col = pass0 + (((lane & 15) ^ (rr & 15)) << 3);
+                                col = col < kpad_l ? col : 0;                      // past the readable width: any valid address (masked later)
+                                const uint16_t* src;
+                                if (rr < BM) { int m = m0 + rr; m = m < a.M ? m : a.M - 1; src = a.xo + static_cast<size_t>(m) * a.ldxo + col; }
+                                else         { int n = n0 + rr - BM; n = n < a.N ? n : a.N - 1; src = a.wo + static_cast<size_t>(n) * a.ldwo + col; }
+                                glds16(reinterpret_cast<const uint8_t*>(src), lds + q * 1024);
+                            }
+                            wait_vmcnt<0>();
+                            __builtin_amdgcn_s_barrier();                          // this pass has landed
+                        }
+                        __builtin_amdgcn_s_barrier();                              // tail reads done: the staging tile may overwrite them
+                    }
+                }
+                __builtin_amdgcn_s_barrier();            // staging tile complete
             }
         }
     }
@@ -458,7 +493,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                     woq[P][i] = *reinterpret_cast<const u32x4*>(a.wo + static_cast<size_t>(wr) * a.ldwo + lh * 8 + kk * 16);
                 }
             };
-            if (ksteps > 0) tail_load(0, 0);                                   // the rest of the ring: after the dequantisation
+            if constexpr (!TAIL_LDS) { if (ksteps > 0) tail_load(0, 0); }                      // the rest of the ring: after the dequantisation
             if (LOADERS > 0 || staged) __builtin_amdgcn_s_barrier();          // every wave is done reading the ring
             stamp(6);
 
@@ -495,16 +530,46 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                         fa[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, woq[P][i]),
                                                                           __builtin_bit_cast(f16x8, xoq[P][j]), fa[i][j], 0, 0, 0);
             };
+            if constexpr (TAIL_LDS) {
+              if (ksteps > 0) {
+                auto tail_lds_load = [&](int P, int kl) {    // tail k-step kl (16 columns) of the current pass: chunk 2 kl + lh of a row
 #pragma unroll
-            for (int d = 1; d < TD; ++d)
-                if (d < ksteps) tail_load(d, d);
-            for (int kk0 = 0; kk0 < ksteps; kk0 += TD) {
+                    for (int j = 0; j < MI; ++j)
+                        xoq[P][j] = *reinterpret_cast<const u32x4*>(lds + xrow[j] * 256 + (((2 * kl + lh) ^ (xrow[j] & 15)) << 4));
 #pragma unroll
-                for (int d = 0; d < TD; ++d) {
-                    const int kk = kk0 + d;
-                    if (kk < ksteps) {
-                        tail_mma(d, kk);
-                        if (kk + TD < ksteps) tail_load(d, kk + TD);
+                    for (int i = 0; i < NI; ++i)
+                        woq[P][i] = *reinterpret_cast<const u32x4*>(lds + (BM + wrow[i]) * 256 + (((2 * kl + lh) ^ ((BM + wrow[i]) & 15)) << 4));
+                };
+                for (int pass0 = 0; pass0 < n_out; pass0 += 128) {
+                    if (pass0 > 0) __builtin_amdgcn_s_barrier();               // (the loaders refill only after everybody has read the previous pass)
+                    __builtin_amdgcn_s_barrier();                              // this pass has landed
+                    const int k0 = pass0 >> 4;
+                    const int kn = (ksteps - k0) < 8 ? (ksteps - k0) : 8;
+                    tail_lds_load(0, 0);
+                    for (int kl = 0; kl < kn; kl += 2) {
+                        if (kl + 1 < kn) tail_lds_load(1, kl + 1);
+                        tail_mma(0, k0 + kl);
+                        if (kl + 1 < kn) {
+                            if (kl + 2 < kn) tail_lds_load(0, kl + 2);
+                            tail_mma(1, k0 + kl + 1);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                                  // tail reads done: the staging tile may overwrite them
+              }
+            } else {
+#pragma unroll
+                for (int d = 1; d < TD; ++d)
+                    if (d < ksteps) tail_load(d, d);
+                for (int kk0 = 0; kk0 < ksteps; kk0 += TD) {
+#pragma unroll
+                    for (int d = 0; d < TD; ++d) {
+                        const int kk = kk0 + d;
+                        if (kk < ksteps) {
+                            tail_mma(d, kk);
+                            if (kk + TD < ksteps) tail_load(d, kk + TD);
+                        }
                     }
                 }
             }

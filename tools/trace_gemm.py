@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--cfgs", default="8")
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--nout", type=int, default=0, help="outlier columns (the fp16 MFMA tail of the epilogue)")
     args = ap.parse_args()
     dev = "cuda"
     lib = _capi.load()
@@ -34,11 +35,16 @@ def main():
         qxp = mixlib.PackOperand(qx, 1)
         qw_by_fmt = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 2)}
         out = torch.empty(M, N, dtype=torch.float16, device=dev)
+        xo = wo = None
+        if args.nout:
+            pad = (args.nout + 15) // 16 * 16
+            xo = torch.randn((M, pad), device=dev).half()[:, :args.nout]
+            wo = torch.randn((N, pad), device=dev).half()[:, :args.nout]
         trace = torch.zeros(16 * 4096, dtype=torch.int64, device=dev)
         for c in [int(v) for v in args.cfgs.split(",")]:
             assert lib.mixq_gemm_set_config(c) == 0
             qwp = qw_by_fmt[2 if names[c].startswith("wr") else 1]
-            run = lambda: mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out)
+            run = lambda: mixlib.FusedLinear(qxp, qwp, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
@@ -69,7 +75,7 @@ def main():
             }
             mhz = (t[:, 10] - t[:, 9]) / ((t[:, 2] - t[:, 1]) / 100.0)
             cyc = np.median(t[:, 10] - t[:, 9]) / (K if args.bit == 8 else K // 2) * 64
-            print(f"{shp} bit={args.bit} cfg{c} {names[c]}: {t.shape[0]} workgroups; s_memtime ticks per us in the k loop: "
+            print(f"{shp} bit={args.bit} n_out={args.nout} cfg{c} {names[c]}: {t.shape[0]} workgroups; s_memtime ticks per us in the k loop: "
                   f"{np.median(mhz):.0f} ({cyc:.0f} shader cycles per 64-byte k-step); microseconds min / median / p90 / max")
             for k, v in ph.items():
                 v = v / 100.0
