@@ -168,14 +168,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
             nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
         }
-        for (; kt + 1 < nk; ++kt) {
-            wr_wait_vmcnt<0>();
-            if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
-        }
         // The fp16 outlier tail's activation operand (X_out rows of this tile) is the same for the four consumer waves: like X it
         // goes through LDS once - fragment-ordered 16 x 32 blocks of the first TQ tail k-steps (64 outlier columns), DMA-ed
-        // behind the ring while the consumers finish the k loop - instead of being fetched from L2 by each wave (4 x 8 KiB per
-        // tail k-step: as much traffic as two k-steps of the main loop, 0.6 us of a 27 us launch at 41 outlier columns).
+        // behind the ring - instead of being fetched from L2 by each wave (4 x 8 KiB per tail k-step: as much traffic as two
+        // k-steps of the main loop, 0.6 us of a 27 us launch at 41 outlier columns).  Requested HERE, when the last X stage has been
+        // issued and LOOK k-steps of the main loop are still to run, so it has landed long before the consumers reach the epilogue.
         if (a.xo && a.wo) {
             int n_out_l = a.n_out;
             if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out_l = nd < n_out_l ? nd : n_out_l; }
@@ -194,8 +191,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     }
                 }
             }
-            wr_wait_vmcnt<0>();
         }
+        for (; kt + 1 < nk; ++kt) {
+            wr_wait_vmcnt<0>();
+            if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
+        }
+        wr_wait_vmcnt<0>();                                                      // (nk = 1: no drain iteration waited for the tail blocks)
         __builtin_amdgcn_s_barrier();                                            // the epilogue's two barriers
         __builtin_amdgcn_s_barrier();
     }
