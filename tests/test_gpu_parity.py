@@ -1056,6 +1056,28 @@ def test_more_than_128_outlier_columns_every_kernel_family(n_out, M):
         lib.mixq_gemm_set_config(-1)
 
 
+@pytest.mark.parametrize("n_out", [1, 16, 65, 128, 129, 200, 257])
+def test_int4_outlier_tail_staged_through_lds_every_tiling(n_out):
+    """The int4 kernels copy the outlier tail's operands into the idle ring with the loader waves and run the tail out of LDS, in
+    passes of 128 columns (gemm.hip, TAIL_LDS): one column, exactly one pass, one column more, two passes and a bit - every LDS-staged
+    tiling (and the ones without loader waves, which keep the register ring), ragged M and N, against the oracle; and the device-side
+    count (n_out_dev < capacity, poison behind it) must give the same bits."""
+    M, N, K = 200, 328, 512
+    c = _fused_case(M, N, K, 4, seed=900 + n_out, n_out=n_out, bias=True, addend=False, act=0)
+    ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], bias=c["bias"], bit=4).astype(np.float32)
+    names = _capi.gemm_config_names()
+    lib = _capi.load()
+    try:
+        for cfg in _tiled_configs():
+            assert lib.mixq_gemm_set_config(cfg) == 0
+            y = n(_run_fused(c, 1))
+            assert (np.abs(y.astype(np.float32) - ref) <= ulp_tol(ref)).all(), (names[cfg], float(np.abs(y.astype(np.float32) - ref).max()))
+            y_dev = n(_run_fused(c, 1, n_dev_cap=n_out + 23))
+            assert np.array_equal(bits(y), bits(y_dev)), names[cfg]
+    finally:
+        lib.mixq_gemm_set_config(-1)
+
+
 @pytest.mark.parametrize("K,N", [(8192, 8192), (8192, 28672), (14336, 4096)])
 def test_full_size_operator_70b_and_long_k_with_one_percent_outliers(K, N):
     """Operator-level forward at the Llama-2-70b shapes (and Llama-3's down projection) with 1 % outlier columns (82 / 143:
