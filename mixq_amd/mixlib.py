@@ -12,6 +12,8 @@ DetectOutlierCols, DequantWeightCols, FusedLinear), used by mixq_amd.linear.MixL
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _capi
@@ -116,6 +118,22 @@ def FindRowScale(x, x_scale, M, K, bit=8):
     if bit not in (4, 8):
         raise RuntimeError("FindRowScale: bit must be 4 or 8")
     KB, dt = (K, torch.int8) if bit == 8 else (K // 2, torch.uint8)
+    global _pending_extract
+    pend = _pending_extract() if _pending_extract is not None else None
+    if pend is not None:
+        ind_p, x_p, ldo_p = pend._mixq_pending
+        same = (x_p.data_ptr() == x2.data_ptr() and tuple(x_p.shape) == tuple(x2.shape) and x_p.stride(0) == x2.stride(0)
+                and x2.shape[0] == M and K % 8 == 0)
+        if same:                                             # extract + zero + scale + quantise in ONE pass (the native operator's kernel)
+            _pending_extract = None
+            pend.__dict__.pop("_mixq_pending", None)
+            packed = _packed_operands and M > 0 and KB % 64 == 0
+            q = torch.empty((packed_rows(M) if packed else M, KB), dtype=dt, device=x.device)
+            with torch._C.DisableTorchFunctionSubclass():
+                _capi.call("mixq_quant_fused", xp, ind_p.data_ptr(), ind_p.numel(), None, x_scale.data_ptr(), q.data_ptr(), pend.data_ptr(),
+                           None, M, K, ldx, ldo_p, bit, 6.0, FMT_P16X64 if packed else FMT_PLAIN, _stream())
+            return set_fmt(q[:M], FMT_P16X64) if packed else q
+        _flush_pending_extract()
     if _packed_operands and M > 0 and KB % 64 == 0:
         buf = torch.empty((packed_rows(M), KB), dtype=dt, device=x.device)
         _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), buf.data_ptr(), M, K, ldx, bit, FMT_P16X64, _stream())
@@ -150,14 +168,54 @@ def _pad16(n):
     return (n + 15) // 16 * 16
 
 
+# ---- opt-in: extract + quantise as ONE pass behind the reference's two calls ----------------------------------------------
+# The reference calls ExtractOutliersAndSetToZeros(ind, x) and then FindRowScale(x, ...) on the same tensor (linear.py:189-193):
+# two kernels, two passes over X, two launch floors.  With set_fused_prepass(True) (needs set_fused_outliers(True): the outlier
+# tensor must be one of ours) the first call only allocates its result and remembers (ind, x); FindRowScale on that same x then runs
+# the native operator's fused kernel, which gathers, zeroes, scales and quantises in one pass.  Anything else that touches the outlier
+# tensor first - or a FindRowScale / ExtractOutliersAndSetToZeros on another tensor - runs the deferred extraction at once, in order.
+# What it cannot see: code that READS x between the two calls would still find the outlier columns unzeroed.  Off by default.
+_fused_prepass = False
+_pending_extract = None        # weakref to the OutlierActivations whose extraction is still deferred
+
+
+def set_fused_prepass(enabled):
+    global _fused_prepass
+    _flush_pending_extract()
+    prev, _fused_prepass = _fused_prepass, bool(enabled)
+    return prev
+
+
+def _flush_pending_extract():
+    global _pending_extract
+    t = _pending_extract() if _pending_extract is not None else None
+    _pending_extract = None
+    if t is not None:
+        t._run_extract()
+
+
 class OutlierActivations(torch.Tensor):
     """x_out [M,n] as returned by ExtractOutliersAndSetToZeros under set_fused_outliers(True): a view of 16-column-padded storage
     (what the GEMM's tail reads) that recognises the reference's torch.mm with weight_cache.T."""
+
+    def _run_extract(self):
+        """The deferred extraction of set_fused_prepass (a no-op when there is none)."""
+        pend = self.__dict__.pop("_mixq_pending", None)
+        if pend is not None:
+            ind, x, ldo = pend
+            with torch._C.DisableTorchFunctionSubclass():
+                _capi.call("mixq_extract_outliers_zero", x.data_ptr(), ind.data_ptr(), ind.numel(), self.data_ptr(), x.shape[0], x.shape[1],
+                           x.stride(0), ldo, _stream())
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         T = torch.Tensor
+        if func not in _meta_funcs():
+            for a in args:
+                if isinstance(a, OutlierActivations) and "_mixq_pending" in a.__dict__:
+                    _flush_pending_extract()
+                    a._run_extract()
         if _fused_outliers and not kwargs and len(args) == 2 and func in (torch.mm, torch.matmul, T.mm, T.matmul, T.__matmul__):
             a, b = args
             if (isinstance(a, OutlierActivations) and isinstance(b, torch.Tensor) and not isinstance(b, OutlierActivations)
@@ -192,6 +250,9 @@ class PendingOutlierProduct(torch.Tensor):
         if getattr(self, "_mixq_done", True):
             return None
         xo, wo_t = self._mixq_args
+        if isinstance(xo, OutlierActivations) and "_mixq_pending" in xo.__dict__:
+            _flush_pending_extract()
+            xo._run_extract()
         n = xo.shape[1]
         wo = wo_t.t()                                        # [N, n], unit column stride
         pad = _pad16(n)
@@ -228,6 +289,7 @@ class PendingOutlierProduct(torch.Tensor):
 
 def ExtractOutliersAndSetToZeros(ind, x):
     """mixlib.ExtractOutliersAndSetToZeros(ind, x) -> x_out [M,n]; zeroes columns `ind` of x IN PLACE (linear.py:189,205)."""
+    global _pending_extract
     _dev_check(ind, x)
     if x.dtype != torch.float16:
         raise RuntimeError("ExtractOutliersAndSetToZeros: x must be float16")
@@ -235,10 +297,16 @@ def ExtractOutliersAndSetToZeros(ind, x):
     xp, ldx = _rows(x, "x")
     M, K = x.shape
     n = ind.numel()
+    _flush_pending_extract()                                 # (an earlier deferred extraction runs first: program order)
     if _fused_outliers and n:
         buf = torch.empty((M, _pad16(n)), dtype=torch.float16, device=x.device)          # (columns >= n: never read as values)
+        out = buf[:, :n].as_subclass(OutlierActivations)
+        if _fused_prepass and x.dim() == 2:
+            out._mixq_pending = (ind, x, buf.shape[1])
+            _pending_extract = weakref.ref(out)
+            return out
         _capi.call("mixq_extract_outliers_zero", xp, ind.data_ptr(), n, buf.data_ptr(), M, K, ldx, buf.shape[1], _stream())
-        return buf[:, :n].as_subclass(OutlierActivations)
+        return out
     out = torch.empty((M, n), dtype=torch.float16, device=x.device)
     if n:
         _capi.call("mixq_extract_outliers_zero", xp, ind.data_ptr(), n, out.data_ptr(), M, K, ldx, n, _stream())

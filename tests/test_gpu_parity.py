@@ -1388,6 +1388,43 @@ def test_fused_outliers_behind_the_reference_call_sequence(route):
         mixlib.set_fused_outliers(prev)
 
 
+def test_fused_prepass_behind_the_reference_call_sequence():
+    """set_fused_prepass(True) (with set_fused_outliers): ExtractOutliersAndSetToZeros is deferred and FindRowScale on the same tensor
+    runs the one-pass extract + zero + scale + quantise kernel.  Same q_x, x_scale, x_out and zeroed x as the two separate calls; a
+    deferred extraction that FindRowScale never picks up runs as soon as its result is touched, or before the next prepass call."""
+    M, K = 70, 1024
+    rng = np.random.default_rng(12)
+    x0 = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float16))
+    ind = torch.from_numpy(np.sort(rng.choice(K, 19, replace=False)).astype(np.int32)).to(DEV)
+    x0[:, ind.cpu().long()] *= 20
+    xs_a = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+    xs_b = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+    xa = x0.clone().to(DEV)
+    xo_a = mixlib.ExtractOutliersAndSetToZeros(ind, xa)
+    q_a = mixlib.FindRowScale(xa, xs_a, M, K, 8)
+    po, pp = mixlib.set_fused_outliers(True), mixlib.set_fused_prepass(True)
+    try:
+        xb = x0.clone().to(DEV)
+        xo_b = mixlib.ExtractOutliersAndSetToZeros(ind, xb)
+        assert "_mixq_pending" in xo_b.__dict__ and torch.equal(xb.cpu(), x0)             # nothing has run yet
+        q_b = mixlib.FindRowScale(xb, xs_b, M, K, 8)
+        assert "_mixq_pending" not in xo_b.__dict__
+        assert torch.equal(q_b, q_a) and torch.equal(xs_b, xs_a) and torch.equal(xb, xa)
+        assert torch.equal(xo_b.as_subclass(torch.Tensor), xo_a)
+        # never picked up: touching the result runs the extraction
+        xc = x0.clone().to(DEV)
+        xo_c = mixlib.ExtractOutliersAndSetToZeros(ind, xc)
+        assert torch.equal(xo_c + 0, xo_a) and torch.equal(xc, xa)
+        # ... and so does the next prepass call, in program order
+        xd, xe = x0.clone().to(DEV), x0.clone().to(DEV)
+        xo_d = mixlib.ExtractOutliersAndSetToZeros(ind, xd)
+        q_e = mixlib.FindRowScale(xe, xs_b, M, K, 8)                                       # another tensor: xd's extraction runs first
+        assert torch.equal(xd, xa) and torch.equal(xo_d.as_subclass(torch.Tensor), xo_a)
+        assert not torch.equal(q_e, q_a)                                                   # xe still had its outliers
+    finally:
+        mixlib.set_fused_prepass(pp); mixlib.set_fused_outliers(po)
+
+
 def test_gemm_shim_refuses_operands_that_do_not_match_m_n_k():
     """The reference's arch == 9 route calls mixlib.gemm for 4-bit layers too (linear.py:235) with nibble-packed [., K/2] operands and
     the full K: a byte GEMM over them would read past both buffers, so the shim raises instead of launching."""

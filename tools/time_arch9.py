@@ -51,12 +51,16 @@ for name, lazy, packed, fo, fn in [("arch==9 route, deferred product (default)",
                                    ("arch==9 route + set_fused_outliers(True)", True, False, True, seq_arch9),
                                    ("arch==9 route + set_packed_operands(True) + set_fused_outliers(True)", True, True, True, seq_arch9),
                                    ("fused branch + set_packed_operands(True) + set_fused_outliers(True)", True, True, True, seq_fused_branch),
+                                   ("arch==9 route + all three switches (packed operands, fused outliers, fused prepass)", True, True, 2, seq_arch9),
+                                   ("fused branch + all three switches", True, True, 2, seq_fused_branch),
                                    ("native operator (packed operands, fused quantise + GEMM)", True, False, False, native)]:
     prev = mixlib.set_lazy_gemm(lazy)
     prevp = mixlib.set_packed_operands(packed)
-    prevo = mixlib.set_fused_outliers(fo)
+    prevo = mixlib.set_fused_outliers(bool(fo))
+    prevq = mixlib.set_fused_prepass(fo == 2)
     us = time_graph(fn, 50, 10)
+    mixlib.set_fused_prepass(prevq)
     mixlib.set_fused_outliers(prevo)
     mixlib.set_packed_operands(prevp)
     mixlib.set_lazy_gemm(prev)
-    print(f"{name:74s} {us:8.2f} us / forward  {flops / us / 1e6:7.1f} TFLOPS ({100 * flops / us / 1e6 / 5033:4.1f} % of peak)", flush=True)
+    print(f"{name:88s} {us:8.2f} us / forward  {flops / us / 1e6:7.1f} TFLOPS ({100 * flops / us / 1e6 / 5033:4.1f} % of peak)", flush=True)
