@@ -212,10 +212,11 @@ class OutlierActivations(torch.Tensor):
         kwargs = kwargs or {}
         T = torch.Tensor
         if func not in _meta_funcs():
-            for a in args:
-                if isinstance(a, OutlierActivations) and "_mixq_pending" in a.__dict__:
-                    _flush_pending_extract()
-                    a._run_extract()
+            for a in list(args) + list(kwargs.values()):
+                for b in (a if isinstance(a, (list, tuple)) else (a,)):
+                    if isinstance(b, OutlierActivations) and "_mixq_pending" in b.__dict__:
+                        _flush_pending_extract()
+                        b._run_extract()
         if _fused_outliers and not kwargs and len(args) == 2 and func in (torch.mm, torch.matmul, T.mm, T.matmul, T.__matmul__):
             a, b = args
             if (isinstance(a, OutlierActivations) and isinstance(b, torch.Tensor) and not isinstance(b, OutlierActivations)

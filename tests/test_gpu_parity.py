@@ -1415,6 +1415,11 @@ def test_fused_prepass_behind_the_reference_call_sequence():
         xc = x0.clone().to(DEV)
         xo_c = mixlib.ExtractOutliersAndSetToZeros(ind, xc)
         assert torch.equal(xo_c + 0, xo_a) and torch.equal(xc, xa)
+        # ... also when it sits inside a sequence argument (the reference's torch.hstack((cache.activation_outliers, new)), linear.py:212)
+        xf_ = x0.clone().to(DEV)
+        xo_f = mixlib.ExtractOutliersAndSetToZeros(ind, xf_)
+        both = torch.hstack((xo_f, xo_a))
+        assert torch.equal(both[:, :19], xo_a) and torch.equal(xf_, xa) and type(both) is torch.Tensor
         # ... and so does the next prepass call, in program order
         xd, xe = x0.clone().to(DEV), x0.clone().to(DEV)
         xo_d = mixlib.ExtractOutliersAndSetToZeros(ind, xd)
