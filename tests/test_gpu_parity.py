@@ -1648,3 +1648,38 @@ def test_packed_operands_behind_the_reference_call_sequence():
         mixlib.set_packed_operands(prev)
     assert torch.equal(plain[0], fast[0]) and torch.equal(plain[1], fast[1]) and torch.equal(plain[0], plain[1])
     assert np.array_equal(plain[2], fast[2]) and np.array_equal(fast[2], O.gemm_i8(n(plain[3]), c["qw"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the bench line's contract (what the driver parses)
+# ---------------------------------------------------------------------------------------------------------------
+def test_bench_line_contract_on_the_gpu():
+    """`python bench.py --steps 20 --warmup 5` prints ONE JSON line with the fields the driver reads: metric / value / unit / n_gpus /
+    steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object for the
+    dominant kernel (measured live: achieved = algorithmic flops / its launch time) and a `cpu_baseline` object; value is consistent
+    with ms_per_step, and the self-check against the dequantised Linear is inside the 1e-2 gate."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5 and out["higher_is_better"] is True
+    assert out["unit"] == "TFLOPS" and out["dtype"] == "int8" and out["data"] == "synthetic" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and out["config"]["M"] == 512 and out["config"]["K"] == 4096 and out["config"]["N"] == 11008
+    flops = 2.0 * 512 * 4096 * 11008
+    assert out["value"] == pytest.approx(flops / (out["ms_per_step"] * 1e-3) / 1e12, rel=1e-3)
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == pytest.approx(5033.0)
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and 0.2 < rf["frac"] < 0.6
+    assert rf["achieved"] == pytest.approx(flops / (rf["us_per_launch"] * 1e-6) / 1e12, rel=1e-3)
+    assert rf["us_per_launch"] * 1e-3 < out["ms_per_step"]                              # the kernel is part of the step
+    assert rf["traffic"] is None or (rf["traffic"] > rf["algorithmic_bytes_per_launch"] * 0.9 and "traffic_source" in rf)
+    cb = out["cpu_baseline"]
+    assert cb["unit"] == "TFLOPS" and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
+    assert out["max_abs_err_vs_dequant_linear"] <= 1e-2
