@@ -687,6 +687,9 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
     static const struct { int cfg; float tk, fixed; } cand[] = {
         {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f},
         {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
+    // few tiles (narrow layer, small batch): when 64-row tiles would occupy at most half the CUs and 32-row tiles still fit one round,
+    // the 32 x 64 tiling wins (64 x 4096 -> 4096: 9.9 vs 11.1 us, 128 x 4096 -> 4096: 10.2 vs 11.3 us; profiles/r02_gemm_ab_mid_batch.txt)
+    if (cdiv(M, 32) * cdiv(N, 64) <= 256 && cdiv(M, 64) * cdiv(N, 64) <= 128) return 20;
     const int nk = KB >> 6;
     double best = 1e30; int bi = 0;
     for (const auto& c : cand) {
