@@ -587,6 +587,9 @@ inline int wo_cdiv(int a, int b) { return (a + b - 1) / b; }
 // time ~ rounds over the 256 CUs x (k-steps x time per k-step of one tile + fixed); per k-step a wave issues 2 MB WNB MFMAs of 16
 // cycles, the fixed part grows with the tile's output bytes
 int pick_wo(int M, int N, int K) {
+    // few tiles (narrow layer, small batch): 32-row tiles when 64-row ones would leave half the CUs idle (as in gemm_wreg.hip;
+    // 64 x 4096 -> 4096: 11.6 vs 13.2 us, 128 x 4096 -> 4096: 12.3 vs 13.7 us)
+    if (wo_cdiv(M, 32) * wo_cdiv(N, 64) <= 256 && wo_cdiv(M, 64) * wo_cdiv(N, 64) <= 128) return WO_SMALL;
     double best = 1e30; int bi = 0;
     const int nk = K >> 6;
     for (int c = 0; c < NUM_WO_PICK; ++c) {
