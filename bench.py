@@ -99,8 +99,13 @@ def init_dist(n_gpus, backend):
     return rank, local_rank, world
 
 
+def _group_up():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def barrier(world, device=None):
-    if world > 1:
+    if world > 1 or _group_up():                          # (a 1-rank group exists only in the RCCL smoke test)
         import torch.distributed as dist
         if device is not None and device.type == "cuda":
             dist.barrier(device_ids=[device.index])
@@ -111,7 +116,7 @@ def barrier(world, device=None):
 def gather_counters(elapsed_s, flops, world, device, per_rank=False):
     """All ranks contribute {elapsed seconds, FLOPs}; returns (max elapsed, total FLOPs[, per-rank elapsed list]).  The only
     collective of the whole job (a few floats over xGMI); the data path itself shards by batch and exchanges nothing."""
-    if world == 1:
+    if world == 1 and not _group_up():
         return (elapsed_s, flops, [elapsed_s]) if per_rank else (elapsed_s, flops)
     import torch.distributed as dist
     mine = torch.tensor([elapsed_s, flops], dtype=torch.float64, device=device)

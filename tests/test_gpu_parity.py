@@ -1683,3 +1683,31 @@ def test_bench_line_contract_on_the_gpu():
     cb = out["cpu_baseline"]
     assert cb["unit"] == "TFLOPS" and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
     assert out["max_abs_err_vs_dequant_linear"] <= 1e-2
+
+
+def test_bench_collectives_over_rccl_single_rank():
+    """The N-GPU bench's only collectives - the barriers around the timed region and one all_gather of {elapsed, FLOPs} - through
+    the real RCCL backend ("nccl" on ROCm) in a 1-rank group on this GPU: process-group creation after set_device, barrier with
+    device_ids, the gather on a CUDA tensor.  (The N-rank launch path itself is rehearsed on CPU over gloo, tests/test_dist_gloo.py.)"""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys, torch
+        sys.path.insert(0, %r)
+        import bench
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(bench.free_port()))
+        torch.cuda.set_device(0)
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        dev = torch.device("cuda", 0)
+        bench.barrier(1, dev)
+        mx, tot, per = bench.gather_counters(0.25, 3.0e9, 1, dev, per_rank=True)
+        bench.barrier(1, dev)
+        assert (mx, tot, per) == (0.25, 3.0e9, [0.25]), (mx, tot, per)
+        dist.destroy_process_group()
+        print("rccl ok")
+    """ % root)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
