@@ -18,7 +18,8 @@ import torch
 from . import mixlib as _mixlib
 
 _backend = _mixlib
-_packed = {}          # (data_ptr, version, shape) -> packed weights, for callers that only hold q_weight (w8_a16_gemm)
+_packed = {}          # (data_ptr, version, shape) -> (q_weight, packed weights), for callers that only hold q_weight (w8_a16_gemm).
+                      # The entry keeps q_weight itself alive: a key made of an address must not outlive the allocation it names.
 
 
 def set_backend(module):
@@ -88,13 +89,12 @@ def unprocess_weights(processed):
 
 def packed_weight(q_weight):
     key = (q_weight.data_ptr(), q_weight._version, tuple(q_weight.shape))
-    p = _packed.get(key)
-    if p is None:
+    e = _packed.get(key)
+    if e is None:
         if len(_packed) > 256:
             _packed.clear()
-        p = _backend.PackW8A16(q_weight)
-        _packed[key] = p
-    return p
+        e = _packed[key] = (q_weight, _backend.PackW8A16(q_weight))
+    return e[1]
 
 
 def w8_a16_gemm(x, q_weight, scale_col, bias=None):

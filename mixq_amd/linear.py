@@ -318,7 +318,7 @@ class MixLinear_GEMM(nn.Module):
         # W4A4 stays with the LDS-staged kernel (P16X64 weights): its nibble expansion hides behind 32-cycle MFMAs there, not
         # behind the 16-cycle ones of the weights-in-registers kernel (28.0 vs 32.4 us at the metric shape, interleaved A/B)
         fmt = PACK_FMT if self.bit == 8 else FMT_P16X64
-        key = (qw.data_ptr(), qw._version, fmt)
+        key = (id(qw), qw.data_ptr(), qw._version, fmt)
         if self._wpk is None or self._wpk_key != key:
             self._wpk = _backend.PackOperand(qw, fmt)
             self._wpk_key = key
@@ -331,7 +331,7 @@ class MixLinear_GEMM(nn.Module):
         if n == 0:
             return None, None
         ind = self.ind
-        key = (ind.data_ptr(), ind._version, n)
+        key = (id(ind), ind.data_ptr(), ind._version, n)
         if self._ind_buf is None or self._ind_key != key:
             buf = torch.zeros((_pad16(n),), dtype=torch.int32, device=ind.device)
             buf[:n] = ind
@@ -357,7 +357,7 @@ class MixLinear_GEMM(nn.Module):
             # weight_cache is static between outlier appends: re-pad it (e.g. a [N,129] buffer loaded from a checkpoint)
             # once, not on every forward
             wc = self.weight_cache
-            key = (wc.data_ptr(), wc._version, tuple(wc.shape), wc.stride(0))
+            key = (id(wc), wc.data_ptr(), wc._version, tuple(wc.shape), wc.stride(0))
             if self._wo_key != key:
                 self._wo_ready, self._wo_key = _gemm_ready(wc), key
             wo = self._wo_ready
@@ -395,7 +395,7 @@ class MixLinear_GEMM(nn.Module):
         M = inputs.shape[0]
         if self.weight_only is True:
             # linear.py:178-184 (w8_a16_gemm, then `y += bias`): here the bias rides in the GEMM epilogue
-            key = (self.q_weight.data_ptr(), self.q_weight._version)
+            key = (id(self.q_weight), self.q_weight.data_ptr(), self.q_weight._version)
             if self._wpk is None or self._wpk_key != key:
                 self._wpk, self._wpk_key = _backend.PackW8A16(self.q_weight), key
             y = _backend.W8A16Linear(inputs, self._wpk, self.scale_col, self.bias, self.out_features, self.in_features)

@@ -83,7 +83,7 @@ def _layout_bits(x_fmt, w_fmt):
 # given (cached per tensor: +1x the weight bytes) - the kernels of the native operator, behind the reference's own code.
 # Off by default: a caller that slices, copies or inspects q_x would lose the tag or read tile-major bytes.
 _packed_operands = False
-_wpacked = {}          # (data_ptr, version, shape) -> fragment-order copy of a plain weight
+_wpacked = {}          # (data_ptr, version, shape) -> (weight, fragment-order copy); the entry pins the weight: see eetq._packed
 
 
 def set_packed_operands(enabled):
@@ -98,12 +98,12 @@ def _weight_for_gemm(q_w, bit):
     if not _packed_operands or fmt_of(q_w) != FMT_PLAIN or q_w.dim() != 2 or q_w.shape[1] % 64 or not q_w.is_contiguous():
         return q_w
     key = (q_w.data_ptr(), q_w._version, tuple(q_w.shape))
-    p = _wpacked.get(key)
-    if p is None:
+    e = _wpacked.get(key)
+    if e is None:
         if len(_wpacked) > 1024:
             _wpacked.clear()
-        p = _wpacked[key] = PackOperand(q_w, FMT_F16X64 if bit == 8 else FMT_P16X64)
-    return p
+        e = _wpacked[key] = (q_w, PackOperand(q_w, FMT_F16X64 if bit == 8 else FMT_P16X64))
+    return e[1]
 
 
 def FindRowScale(x, x_scale, M, K, bit=8):
@@ -153,7 +153,7 @@ def FindRowScale(x, x_scale, M, K, bit=8):
 # the product to fp16 before it is added (torch.mm), the fused tail adds it in fp32 like the native operator (include/mixq_hip.h,
 # convention 2; <= 2 fp16 ulp apart).
 _fused_outliers = False
-_wo_padded = {}        # (data_ptr, version, shape, stride) -> weight_cache re-laid with a 16-column-padded pitch
+_wo_padded = {}        # (data_ptr, version, shape, stride) -> (weight_cache view, copy with a 16-column-padded pitch); pins its source
 
 
 def set_fused_outliers(enabled):
@@ -263,13 +263,15 @@ class PendingOutlierProduct(torch.Tensor):
                 return None                                  # not the padded storage ExtractOutliersAndSetToZeros hands out
             if wo.stride(0) % 8 or wo.stride(0) < pad or wo.data_ptr() % 16:
                 key = (wo.data_ptr(), wo._version, tuple(wo.shape), wo.stride(0))
-                wp = _wo_padded.get(key)
+                e = _wo_padded.get(key)
+                wp = e[1] if e is not None else None
                 if wp is None:
                     if len(_wo_padded) > 1024:
                         _wo_padded.clear()
                     buf = torch.zeros((wo.shape[0], pad), dtype=torch.float16, device=wo.device)
                     buf[:, :n] = wo
-                    wp = _wo_padded[key] = buf
+                    _wo_padded[key] = (wo, buf)
+                    wp = buf
                 wo = wp[:, :n]
         return xo, wo, n
 
