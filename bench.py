@@ -46,6 +46,8 @@ def parse(argv=None):
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--shape", default=None, help="K,N of the Linear (default 4096,11008); e.g. 8192,28672 for BASELINE config 3")
     ap.add_argument("--batch", type=int, default=None, help="token rows M (default 512)")
+    ap.add_argument("--bit", type=int, choices=[8, 4], default=8, help="8: W8A8O16 (the metric); 4: W4A4O16, 128 static fp16 columns (BASELINE config 2)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the eager / cold-weights secondary timings")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python instead of one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl")
@@ -81,8 +83,19 @@ def spawn_ranks(n_gpus, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    for p in procs:
-        rc = rc or p.wait()
+    pending = list(procs)
+    while pending:                                              # every child is reaped; the first failure stops the others
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:
+                    q.terminate()
+        if pending:
+            time.sleep(0.05)
     return rc
 
 
@@ -139,18 +152,31 @@ def rank_rows(total_rows, world, rank, scaling):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def build_layer(device, rows, seed=0):
+def outlier_columns():
+    g = torch.Generator().manual_seed(1)
+    return torch.randperm(K, generator=g)[: round(OUTLIER_FRAC * K)]
+
+
+def build_layer(device, rows, seed=0, bit=8, cache=None):
     from mixq_amd import MixLibCache, MixLinear_GEMM
     torch.manual_seed(seed)
     lin = torch.nn.Linear(K, N, bias=False).half()            # nn.Linear default init, as examples/benchbitsand.py:519
-    cache = MixLibCache(rows, sigma=SIGMA, bit=8, device=device)
-    layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=device, name="up_proj")
+    if cache is None:
+        cache = MixLibCache(rows, sigma=SIGMA, bit=bit, device=device)
+    if bit == 8:
+        layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=device, name="up_proj")
+    else:
+        # W4A4O16 (linear.py:123-143): the 128 input channels with the largest calibration scale stay fp16; the synthetic
+        # calibration marks the batch's outlier columns (and fills up to 128 with the next channels)
+        scales = torch.ones(K) + torch.arange(K) * 1e-6
+        cols = outlier_columns()
+        scales[cols] = 20.0 + torch.arange(cols.numel()) * 1e-3
+        layer = MixLinear_GEMM.from_linear(lin, 4, cache=cache, layer_scales=scales, dev=device, name="up_proj")
     return lin, cache, layer
 
 
 def make_batches(count, rows, device, rank):
-    g = torch.Generator().manual_seed(1)
-    cols = torch.randperm(K, generator=g)[: round(OUTLIER_FRAC * K)]
+    cols = outlier_columns()
     gx = torch.Generator().manual_seed(100 + rank)
     base = torch.randn(rows, K, generator=gx).half()
     base[:, cols] *= 20
@@ -245,7 +271,8 @@ def main(argv=None):
 
     lo, hi = rank_rows(M, world, rank, args.scaling)
     rows = hi - lo
-    lin, cache, layer = build_layer(device, rows)
+    bit = args.bit
+    lin, cache, layer = build_layer(device, rows, bit=bit)
     steps, warm = args.steps, args.warmup
     cols, base, pristine = make_batches(steps, rows, device, rank)
     nbuf = pristine.shape[0]
@@ -261,12 +288,22 @@ def main(argv=None):
     # quick self-check against a Linear over the dequantised operands on the GPU (the CPU-oracle parity lives in tests/)
     with torch.no_grad():
         xz = base.clone()
-        q, xo = mixlib.QuantFused(xz, layer.ind, cache.x_scale, 8, SIGMA)
+        q, xo = mixlib.QuantFused(xz, layer.ind, cache.x_scale, bit, SIGMA)
+        if bit == 4:                                            # nibbles -> signed values, even column in the low nibble
+            lo, hi = (q & 15).to(torch.int8), (q >> 4).to(torch.int8)
+            q = torch.stack((torch.where(lo > 7, lo - 16, lo), torch.where(hi > 7, hi - 16, hi)), dim=2).reshape(rows, K)
+            qw = layer.q_weight
+            wl, wh = (qw & 15).to(torch.int8), (qw >> 4).to(torch.int8)
+            Wq = torch.stack((torch.where(wl > 7, wl - 16, wl), torch.where(wh > 7, wh - 16, wh)), dim=2).reshape(N, K)
+        else:
+            Wq = layer.q_weight
         Xd = q.double() * cache.x_scale[:rows].double()
+        Wd = Wq.double() * layer.scale_col.double().T
+        Wd[:, layer.ind.long()] = layer.weight_cache.double()    # the fp16 columns the operator actually multiplies (linear.py:207)
         Xd[:, layer.ind.long()] = base[:, layer.ind.long()].double()
-        ref = Xd @ (layer.q_weight.double() * layer.scale_col.double().T).T
+        ref = Xd @ Wd.T
         max_abs_err = float((layer(base.clone(), None, True).double() - ref).abs().max())
-        del Xd, ref
+        del Xd, Wd, ref, Wq
 
     def one_step(i):
         return layer(pristine[i % nbuf], None, True)
@@ -306,7 +343,7 @@ def main(argv=None):
 
         # ---- dominant kernel (the int8 MFMA GEMM + fused epilogue) alone, HIP events on the launch stream ------------
         ind_buf, n_dev = layer._ind_dev()
-        q_x, x_out = mixlib.QuantFused(base.clone(), ind_buf, cache.x_scale, 8, SIGMA, n_dev=n_dev, fmt=layer.x_fmt())
+        q_x, x_out = mixlib.QuantFused(base.clone(), ind_buf, cache.x_scale, bit, SIGMA, n_dev=n_dev, fmt=layer.x_fmt())
         cache.q_xcache, cache.activation_outliers, cache.n_dev = q_x, (x_out[:, :n_ind] if n_ind else None), n_dev
         gsteps = max(20, min(steps, 200))
         for _ in range(5):
@@ -326,6 +363,61 @@ def main(argv=None):
         torch.cuda.synchronize()
         gemm_us = g0.elapsed_time(g1) * 1e3 / gsteps
 
+        # ---- secondary timings, outside the timed region of `value` --------------------------------------
+        eager_ms = cold_ms = None
+        cold_note = None
+        if not args.no_secondary:
+            # (a) the reference's own protocol, examples/benchbitsand.py:534-550: NO graph, 10 warm-up + 100 timed back-to-back
+            # `layer(x)` calls from Python between two events - what a plain Hugging Face loop pays per layer, host cost included
+            esteps = 100
+            pristine.copy_(base.unsqueeze(0).expand_as(pristine))
+            for i in range(10):
+                one_step(i)
+            torch.cuda.synchronize()
+            pristine.copy_(base.unsqueeze(0).expand_as(pristine))
+            torch.cuda.synchronize()
+            h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            h0.record(side)
+            for i in range(esteps):
+                one_step(i)
+            h1.record(side)
+            torch.cuda.synchronize()
+            eager_ms = h0.elapsed_time(h1) / esteps
+            # (b) cold weights: one graph whose steps rotate through enough copies of the layer to exceed the 256 MB MALL, as the
+            # layers of a model do (the headline loop, like the reference's, re-uses ONE layer whose weights stay cache-resident)
+            wbytes = int(layer._wpk.numel())
+            copies = max(8, -(-300 * (1 << 20) // wbytes) + 1)
+            layers = [layer]
+            for c in range(1, copies):
+                _, _, lc = build_layer(device, rows, seed=c, bit=bit, cache=cache)
+                for _ in range(3):
+                    lc(base.clone(), None, True)
+                layers.append(lc)
+            torch.cuda.synchronize()
+            csteps = max(copies * 4, 40)
+            pristine.copy_(base.unsqueeze(0).expand_as(pristine))
+            for i in range(copies):
+                layers[i](pristine[i % nbuf], None, True)
+            torch.cuda.synchronize()
+            pristine.copy_(base.unsqueeze(0).expand_as(pristine))
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg, stream=side):
+                for i in range(csteps):
+                    layers[i % copies](pristine[i % nbuf], None, True)
+            torch.cuda.synchronize()
+            cg.replay()
+            torch.cuda.synchronize()
+            pristine.copy_(base.unsqueeze(0).expand_as(pristine))
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record(side)
+            cg.replay()
+            c1.record(side)
+            torch.cuda.synchronize()
+            cold_ms = c0.elapsed_time(c1) / csteps
+            cold_note = f"one hipGraph of {csteps} steps rotating over {copies} layer copies ({copies * wbytes >> 20} MB of weights > 256 MB MALL)"
+            del layers, cg
+
     flops_step = 2.0 * rows * N * K
     max_elapsed, total_flops, per_rank = gather_counters(elapsed, flops_step * steps, world, device, per_rank=True)
     max_host, _ = gather_counters(host_elapsed, 0.0, world, device)
@@ -338,12 +430,12 @@ def main(argv=None):
         traffic, traffic_src = hbm_traffic_from_profile()
         shape_note = "Llama-2-7b up_proj shape" if (K, N) == (4096, 11008) else f"{K}->{N}"
         out = {
-            "metric": f"effective int8 TFLOPS, W8A8O16 MixQ Linear forward (quantise + int8 MFMA GEMM + fused dequant/outlier "
+            "metric": f"effective int8 TFLOPS, W{bit}A{bit}O16 MixQ Linear forward (quantise + int8 MFMA GEMM + fused dequant/outlier "
                       f"epilogue), batch {M}, {K}->{N}",
             "value": round(value, 2), "unit": "TFLOPS", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "int8", "data": "synthetic",
-            "config": {"workload": f"MixLinear_GEMM W8A8O16 forward, {shape_note}", "M": M, "K": K, "N": N,
+            "dtype": "int8" if bit == 8 else "int4 (expanded to int8 in registers: CDNA4 has no int4 MFMA)", "data": "synthetic",
+            "config": {"workload": f"MixLinear_GEMM W{bit}A{bit}O16 forward, {shape_note}", "M": M, "K": K, "N": N,
                        "outlier_columns": n_ind, "outlier_predict": "frozen after 2 warm-up forwards", "sigma": SIGMA,
                        "weights": "nn.Linear default init, quantised per output channel", "per_gpu_batch": rows,
                        "parallelism": f"batch-shard x{world} ({'independent replicas' if args.scaling == 'weak' else 'rows of one batch split'}, "
@@ -352,15 +444,19 @@ def main(argv=None):
                        "operand_format": {"activations": {0: "plain", 1: "P16x64"}[fmt], "weights": {0: "plain", 1: "P16x64", 2: "F16x64"}[mixlib.fmt_of(layer._wpk)]},
                        "weight_bytes_resident": int(layer._wpk.numel() + (0 if layer._buffers['q_weight'] is None else layer._buffers['q_weight'].numel()))},
             "timing": {"clock": "HIP events on the launch stream around the K steps", "host_wall_ms_per_step": round(max_host * 1e3 / steps, 5),
-                       "per_rank_ms_per_step": [round(v * 1e3 / steps, 5) for v in per_rank]},
+                       "per_rank_ms_per_step": [round(v * 1e3 / steps, 5) for v in per_rank],
+                       "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 5),
+                       "eager_protocol": "no graph: 10 warm-up + 100 back-to-back layer(x) calls from Python between two events (examples/benchbitsand.py:534-550), rank 0",
+                       "cold_weights_ms_per_step": None if cold_ms is None else round(cold_ms, 5), "cold_weights_protocol": cold_note},
             "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
             "max_abs_err_vs_dequant_linear": round(max_abs_err, 6),
             "roofline": {"bound": "mfma", "kernel": "int8 MFMA GEMM + fused epilogue (" +
-                                                    _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(rows, N, K, 8, mixlib.fmt_of(layer._wpk))] + ")",
+                                                    _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(rows, N, K, bit, mixlib.fmt_of(layer._wpk))] + ")",
+                         "rank": 0,
                          "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": flops_step,
-                         "algorithmic_bytes_per_launch": rows * K + N * K + 2 * rows * N},
+                         "algorithmic_bytes_per_launch": (rows * K + N * K) * bit // 8 + 2 * rows * N},
             "device": info,
         }
         if not args.no_cpu_baseline and world == 1:

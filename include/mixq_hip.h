@@ -153,6 +153,29 @@ int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x
                        const uint16_t* addend, int lda, const uint16_t* bias,
                        uint16_t* y, int ldy, int M, int N, int K, int act, int layout, mixq_stream_t stream);
 
+/* ---- the whole forward of a frozen layer in ONE call ---------------------------------------------------------
+ * mixq_linear_forward = mixq_quant_fused followed by mixq_gemm_i8_fused / mixq_gemm_i4_fused, both launched from C on `stream`:
+ * the steady state of MixLinear_GEMM.forward(x, cache, unfused=True) once outlier prediction has frozen
+ * (/root/reference/mixquant/modules/linear.py:187-193 then :244-285; with act / addend the SiLU twin :330-373).  One foreign call
+ * and one argument block per forward instead of two calls with 16 + 21 marshalled arguments: what an eager (un-graphed) decoder
+ * loop pays per layer (/root/reference/examples/benchbitsand.py:538-550 times exactly that loop).  The block is caller-owned and
+ * may be kept and re-used between calls (only x, q_x, x_out, y change from forward to forward).  Results are bit-identical to the
+ * two-call sequence.  Field meanings are those of the two entry points above:
+ *   x [M,K] fp16 ldx (outlier columns zeroed in place), ind / n_cap / n_dev, x_scale [M] (written), q_x (written, format qfmt),
+ *   x_out [M,ldxo] (written; NULL when n_cap = 0), flag (optional), q_w in format wfmt (MIXQ_FMT_*), scale_col [N],
+ *   w_out [N,ldwo], addend / lda, bias, y [M,ldy], act (MIXQ_ACT_*).  qfmt must be what the GEMM takes for wfmt:
+ *   PLAIN / P16X64 with wfmt PLAIN / P16X64 in any combination, P16X64 with wfmt F16X64. */
+typedef struct mixq_linear_args {
+    uint16_t* x; int ldx;
+    const int32_t* ind; int n_cap; const int32_t* n_dev;
+    uint16_t* x_scale; void* q_x; uint16_t* x_out; int ldxo; int32_t* flag;
+    const void* q_w; const uint16_t* scale_col; const uint16_t* w_out; int ldwo;
+    const uint16_t* addend; int lda; const uint16_t* bias;
+    uint16_t* y; int ldy;
+    int M, N, K, bit; float sigma; int act, qfmt, wfmt;
+} mixq_linear_args;
+int mixq_linear_forward(const mixq_linear_args* args, mixq_stream_t stream);
+
 /* ---- operand re-tiling ------------------------------------------------------------------------------------
  * Copy a plain [R,KB] byte matrix (int8 weights, or nibble-packed int4) into MIXQ_FMT_P16X64.
  * dst holds roundup(R,16) * KB bytes; rows >= R are zero-filled.  KB % 64 == 0.  Done once per weight at load. */
@@ -215,12 +238,16 @@ long long mixq_gemm_workspace_bytes(void);
 int mixq_gemm_set_workspace(void* ws, long long bytes);
 
 /* ---- tuning / introspection (not part of the reference surface) ----------------------------------------
- * Force a GEMM tile configuration id (>= 0) for subsequent mixq_gemm_* calls, -1 = automatic shape-aware
- * choice.  Returns MIXQ_EINVAL for an unknown id.  mixq_gemm_config_name writes the config's description. */
+ * Force a GEMM tile configuration id (>= 0) for subsequent mixq_gemm_* calls ON THE CURRENT DEVICE (the state is kept per HIP
+ * device), -1 = automatic shape-aware choice.  Returns MIXQ_EINVAL for an unknown id.  mixq_gemm_config_name writes the config's
+ * description.  Every configuration of the product library computes the same (correct) result; the ablation forms used for
+ * tuning, the in-kernel timeline stamps (mixq_gemm_set_trace), the K rotation (mixq_gemm_set_krot) and the quantise kernel's
+ * timing probes (mixq_quant_set_config >= 100) exist only in the -DMIXQ_TUNING build (`make -C mixq_amd/csrc tuning` ->
+ * libmixq_hip_tuning.so, loaded by the tools/ scripts): in the product library those calls return MIXQ_EINVAL. */
 int mixq_gemm_set_config(int cfg);
 /* Launch geometry of the extract + scale + quantise pass (mixq_quant_fused / mixq_find_row_scale): -1 automatic, 0 the
  * one-row-per-256-thread-workgroup kernel, 1..9 (threads per row, rows per workgroup) = (64,1) (64,2) (64,4) (128,1)
- * (128,2) (256,1) (256,2) (512,1) (512,2).  Every geometry produces identical bytes. */
+ * (128,2) (256,1) (256,2) (512,1) (512,2).  Every geometry produces identical bytes.  Per device, like mixq_gemm_set_config. */
 int mixq_quant_set_config(int cfg);
 /* Diagnostics: when buf is non-null every workgroup of the data-parallel fused GEMM writes 16 x u64 to
  * buf[16 * workgroup + i]: i in 0..7 = the 100 MHz device wall clock at 0 entry, 1 first stage landed, 2 k loop

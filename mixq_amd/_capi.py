@@ -11,6 +11,10 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmixq_hip.so")
+# tools/ scripts that need the ablation kernels / trace stamps set MIXQ_TUNING_LIB=1 to load the -DMIXQ_TUNING build instead
+# (`make -C mixq_amd/csrc tuning`); the package itself never asks for it
+if os.environ.get("MIXQ_TUNING_LIB") == "1":
+    LIB_PATH = os.path.join(_HERE, "libmixq_hip_tuning.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mixq_hip.h")
 
 MIXQ_OK = 0
@@ -78,8 +82,20 @@ SIGNATURES = {
     "mixq_gemm_w8a16_config_name": [_I, C.c_char_p, _I],
     "mixq_gemm_workspace_bytes": [],
     "mixq_gemm_set_workspace": [_P, C.c_longlong],
+    "mixq_linear_forward": [_P, _P],
 }
 RESTYPES = {"mixq_gemm_workspace_bytes": C.c_longlong}
+
+
+class LinearArgs(C.Structure):
+    """struct mixq_linear_args of include/mixq_hip.h, field for field (tests/test_capi_symbols.py compares the two)."""
+    _fields_ = [("x", _P), ("ldx", _I),
+                ("ind", _P), ("n_cap", _I), ("n_dev", _P),
+                ("x_scale", _P), ("q_x", _P), ("x_out", _P), ("ldxo", _I), ("flag", _P),
+                ("q_w", _P), ("scale_col", _P), ("w_out", _P), ("ldwo", _I),
+                ("addend", _P), ("lda", _I), ("bias", _P),
+                ("y", _P), ("ldy", _I),
+                ("M", _I), ("N", _I), ("K", _I), ("bit", _I), ("sigma", _F), ("act", _I), ("qfmt", _I), ("wfmt", _I)]
 
 _lib = None
 

@@ -15,10 +15,14 @@ Policy (reference `utils/module.py:2-12`, applied in `quantize/mixquant.py:163-2
 Weight-only (W8A16) layers are the one place where the two sides store DIFFERENT bytes under the same key, shape and
 dtype: the reference's `q_weight` there is EETQ's CUTLASS-interleaved image (modules/linear.py:102-106), ours the plain
 int8 [K,N] matrix.  `quant_config.json` therefore records `"w8a16_layout"`: "plain" (written by save_quantized) or
-"eetq" (assumed when the key is missing, i.e. for a checkpoint the reference wrote); load_quantized converts "eetq" layers
-with mixq_amd.eetq.unprocess_weights, and save_quantized(..., w8a16_layout="eetq") writes the reference's form.  (EETQ is
-un-versioned and absent from the reference tree: the interleave is restated from the FasterTransformer routine it wraps -
-parity for these layers stays UNPINNED, see mixq_amd/eetq.py.)
+"eetq"; load_quantized converts "eetq" layers with mixq_amd.eetq.unprocess_weights, and save_quantized(...,
+w8a16_layout="eetq") writes the reference's form.  A checkpoint WITHOUT the key is ambiguous - the reference writes none
+(interleaved image), and this library's own round-1 checkpoints wrote none either (plain matrix) - so load_quantized then
+takes the layout from its `w8a16_layout=` argument or, failing that, from the bytes themselves (`detect_w8a16_layout`: the
+interleaved image is offset-binary, q + 128, so read as int8 its values crowd the two ends of the range, whereas quantised
+weights crowd zero) and says so in a warning.  save_quantized also records `"writer": "mixq_amd"`.  (EETQ is un-versioned and
+absent from the reference tree: the interleave is restated from the FasterTransformer routine it wraps - parity for these
+layers stays UNPINNED, see mixq_amd/eetq.py.)
 
 Nothing here touches the GPU by itself: quantisation uses torch ops on whatever device the layer lives on; the kernels
 are only reached through `MixLinear_GEMM.forward`.
@@ -26,6 +30,7 @@ are only reached through `MixLinear_GEMM.forward`.
 import json
 import os
 import re
+import warnings
 
 import torch
 import torch.nn as nn
@@ -176,6 +181,7 @@ def save_quantized(root, save_dir, quant_config, safetensors=False, shard_size="
     cfg = dict(quant_config)
     cfg.setdefault("version", "MIX")
     cfg["w8a16_layout"] = w8a16_layout
+    cfg["writer"] = "mixq_amd"
     if hasattr(root, "save_pretrained") and hasattr(root, "config"):
         root.config.save_pretrained(save_dir)
     weights_name = "model.safetensors" if safetensors else "pytorch_model.bin"
@@ -232,13 +238,33 @@ def load_state_dict_files(load_dir):
     return sd
 
 
-def load_quantized(root, load_dir, cache, arch="LlamaForCausalLM", blocks=None, dev=None, strict=True):
+def detect_w8a16_layout(q_weight):
+    """"eetq" or "plain" from the bytes of a weight-only layer's q_weight (int8 [K,N]).  EETQ's image stores q + 128: viewed as int8
+    a typical weight (|q| small) lands next to -128 / 127, so the mean magnitude is ~100; a plain per-column symmetric quantisation
+    has its mass around zero (mean |q| ~ 20-45 for Gaussian-like weights scaled to absmax 127).  Threshold 64."""
+    v = q_weight.detach().to("cpu").view(torch.int8).to(torch.int16).abs().float().mean().item()
+    return "eetq" if v > 64.0 else "plain"
+
+
+def load_quantized(root, load_dir, cache, arch="LlamaForCausalLM", blocks=None, dev=None, strict=True, w8a16_layout=None):
     """`from_quantized` for an already-constructed skeleton (`base.py:161-229`): swap the Linears for empty quantised
-    layers per `quant_config.json`, then load the shards.  Returns the quant config."""
+    layers per `quant_config.json`, then load the shards.  Returns the quant config.
+    `w8a16_layout` ("plain" | "eetq") overrides what quant_config.json says about weight-only layers; when neither says anything the
+    layout is detected from the bytes (module docstring) and reported in a warning."""
     quant_config = read_quant_config(load_dir)
     prepare_(root, quant_config, cache, arch, blocks, dev)
     sd = load_state_dict_files(load_dir)
-    layout = quant_config.get("w8a16_layout", "eetq")       # no key: a checkpoint written by the reference (EETQ's interleaved image)
+    layout = w8a16_layout if w8a16_layout is not None else quant_config.get("w8a16_layout")
+    wo_keys = [pre + "q_weight" for pre in _weight_only_prefixes(root) if pre + "q_weight" in sd]
+    if layout is None and wo_keys:
+        votes = [detect_w8a16_layout(sd[k]) for k in wo_keys]
+        layout = "eetq" if votes.count("eetq") * 2 > len(votes) else "plain"
+        warnings.warn(f"{load_dir}: quant_config.json has no 'w8a16_layout' key; the {len(wo_keys)} weight-only layer(s) look like the "
+                      f"{'reference (EETQ-interleaved)' if layout == 'eetq' else 'plain [K,N] int8'} form ({votes.count(layout)}/{len(votes)} "
+                      f"by byte statistics) and are loaded as such - pass w8a16_layout= to load_quantized to decide yourself",
+                      RuntimeWarning, stacklevel=2)
+    if layout is None:
+        layout = "plain"                                     # no weight-only layers: nothing to convert
     if layout not in ("plain", "eetq"):
         raise ValueError(f"quant_config.json: unknown w8a16_layout {layout!r}")
     if layout == "eetq":

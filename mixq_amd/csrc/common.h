@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include "../../include/mixq_hip.h"
@@ -20,6 +21,21 @@ typedef u32x2 u32x2_u __attribute__((aligned(2)));   // fp16-aligned access to 4
 #define MIXQ_WAVE 64
 
 static inline hipStream_t mixq_stream(mixq_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Tuning state (a forced tile configuration, a forced launch geometry) is kept PER DEVICE: one slot per HIP device, indexed by the
+// device that is current in the calling thread - a process that drives several GPUs ("one process, per-device streams") can force
+// a configuration on one of them without touching launches on the others.
+inline int mixq_cur_dev() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d & 63;
+}
+struct MixqDevInt {
+    std::atomic<int> v[64];
+    explicit MixqDevInt(int init) { for (auto& x : v) x.store(init, std::memory_order_relaxed); }
+    int get() const { return v[mixq_cur_dev()].load(std::memory_order_relaxed); }
+    void set(int x) { v[mixq_cur_dev()].store(x, std::memory_order_relaxed); }
+};
 
 // hipGetLastError() after a launch; maps to the int the C ABI returns.
 static inline int mixq_launch_status() {

@@ -118,11 +118,15 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
     const int nk = a.KB / BKB;
-    auto stamp = [&](int slot) {                         // diagnostics only (mixq_gemm_set_trace)
+    auto stamp = [&](int slot) {                         // diagnostics only (mixq_gemm_set_trace; tools build)
+#ifdef MIXQ_TUNING
         if (a.trace && tid == 0) {
             a.trace[blockIdx.x * 16 + slot] = wall_clock64();
             a.trace[blockIdx.x * 16 + 8 + slot] = __builtin_readcyclecounter();   // s_memtime
         }
+#else
+        (void)slot;
+#endif
     };
     stamp(0);
     int n_out_dev_v = 0;                                 // requested now, consumed by the epilogue
@@ -672,11 +676,13 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
                 }
             }
         }
+#ifdef MIXQ_TUNING
         if (a.trace) {
             stamp(4);
             wait_vmcnt<0>();
             stamp(5);
         }
+#endif
     }
 }
 
@@ -767,19 +773,25 @@ const GemmConfig g_cfgs[] = {
     MIXQ_CFG(256, 256, 4, 2, 5, 0),     // 13: 8 consumers 64(M) x 128(N) self-issuing
     MIXQ_CFG(128, 256, 2, 2, 5, 2),     // 14: 4 consumers 64 x 128 + 2 loaders
     MIXQ_CFG(128, 256, 2, 2, 5, 4),     // 15
-    MIXQ_ABL(128, 192, 2, 2, 5, 4, 1),  // 16: cfg 8, DMA only
-    MIXQ_ABL(128, 192, 2, 2, 5, 4, 2),  // 17: cfg 8, no DMA
-    MIXQ_ABL(128, 192, 2, 2, 5, 4, 3),  // 18: cfg 8, MFMA only
-    MIXQ_ABL(128, 192, 2, 2, 5, 4, 6),  // 19: cfg 8, epilogue without the optional terms compiled in (code size probe)
-    MIXQ_ABL(128, 192, 2, 2, 5, 4, 8),  // 20: cfg 8 without the k-loop barriers (timing probe: results are garbage)
-    MIXQ_CFG(64, 128, 2, 2, 5, 2),      // 21: 4 consumers 32 x 64 + 2 loaders: N = 4096 at M = 512 is exactly 256 such tiles
-    MIXQ_CFG(64, 128, 2, 2, 5, 4),      // 22
-    MIXQ_CFG(64, 192, 2, 2, 5, 4),      // 23: 4 consumers 32 x 96
+    MIXQ_CFG(64, 128, 2, 2, 5, 2),      // 16: 4 consumers 32 x 64 + 2 loaders: N = 4096 at M = 512 is exactly 256 such tiles
+    MIXQ_CFG(64, 128, 2, 2, 5, 4),      // 17
+    MIXQ_CFG(64, 192, 2, 2, 5, 4),      // 18: 4 consumers 32 x 96
+#ifdef MIXQ_TUNING                      // ablation forms (results are garbage by design): only in the tools build (make tuning)
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 1),  // cfg 8, DMA only
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 2),  // cfg 8, no DMA
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 3),  // cfg 8, MFMA only
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 6),  // cfg 8, epilogue without the optional terms compiled in (code size probe)
+    MIXQ_ABL(128, 192, 2, 2, 5, 4, 8),  // cfg 8 without the k-loop barriers (timing probe)
+#endif
 };
 constexpr int NUM_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
-int g_forced_cfg = -1;
-unsigned long long* g_trace = nullptr;             // diagnostics: see mixq_gemm_set_trace
+MixqDevInt g_forced_cfg(-1);                       // per device (common.h): -1 = automatic
+#ifdef MIXQ_TUNING
+unsigned long long* g_trace = nullptr;             // diagnostics: see mixq_gemm_set_trace (tools build only)
+#else
+constexpr unsigned long long* g_trace = nullptr;
+#endif
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -791,7 +803,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // N = 6144, 128x128 at N = 8192, 128x192 around N = 10-12k, 128x256 at N = 14k, 256x256 when there are >= ~200 such tiles.  Row-strided (plain) operands feed slower but rank the same.
 struct PickEntry { int cfg; float tk; };
 const PickEntry g_pick[] = {{0, 0.60f}, {1, 0.39f}, {2, 0.60f}, {3, 0.40f}, {4, 0.40f}, {5, 0.40f}, {6, 0.37f}, {7, 0.40f}, {8, 0.31f},
-                            {9, 0.33f}, {10, 0.26f}, {11, 0.17f}, {12, 0.15f}, {13, 0.60f}, {14, 0.40f}, {15, 0.36f}, {22, 0.165f}, {23, 0.21f}};
+                            {9, 0.33f}, {10, 0.26f}, {11, 0.17f}, {12, 0.15f}, {13, 0.60f}, {14, 0.40f}, {15, 0.36f}, {17, 0.165f}, {18, 0.21f}};
 constexpr int NUM_PICK = sizeof(g_pick) / sizeof(g_pick[0]);
 int pick_config(int M, int N, int KB, bool packed) {
     (void)KB; (void)packed;
@@ -829,7 +841,8 @@ int pick_stream_k(int M, int N, int KB) {
 
 int launch_gemm(GemmArgs& a, int mode, hipStream_t st) {
     const bool packed = a.x_packed && a.w_packed;
-    const int c = (g_forced_cfg >= 0 && g_forced_cfg < NUM_CFGS) ? g_forced_cfg : pick_config(a.M, a.N, a.KB, packed);
+    const int forced = g_forced_cfg.get();
+    const int c = (forced >= 0 && forced < NUM_CFGS) ? forced : pick_config(a.M, a.N, a.KB, packed);
     const GemmConfig* g = &g_cfgs[c];
     a.tiles_m = cdiv(a.M, g->bm);
     a.tiles_n = cdiv(a.N, g->bn);
@@ -872,31 +885,32 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
     const int sk_num = mixq_sk_num_configs();
     const int skinny_id = NUM_CFGS + sk_num, wr0 = skinny_id + 1;
+    const int g_forced = g_forced_cfg.get();                     // this device's forced configuration (-1: automatic)
     // small-batch form (gemm_skinny.hip): M <= 32, packed operands (either packed layout): a weight stream, no LDS staging
     {
         const bool both_packed = a.x_packed && (a.w_packed || wf16);
         // (wide layers with fragment-order int8 weights: the 32 x 64 weights-in-registers tiling streams faster, gemm_wreg.hip)
-        const bool wide_wr = wf16 && bit == 8 && N >= 8192 && g_forced_cfg < 0;
-        if (!wide_wr && (g_forced_cfg < 0 || g_forced_cfg == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed))
+        const bool wide_wr = wf16 && bit == 8 && N >= 8192 && g_forced < 0;
+        if (!wide_wr && (g_forced < 0 || g_forced == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed))
             return mixq_skinny_launch(bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                                       ldy, M, N, KB, act, wf16 ? 1 : 0, mixq_stream(stream));
-        if (g_forced_cfg == skinny_id) return MIXQ_EINVAL;
+        if (g_forced == skinny_id) return MIXQ_EINVAL;
     }
     // fragment-order weights: the weights-in-registers kernels (gemm_wreg.hip)
     if (wf16) {
         int c;
-        if (g_forced_cfg >= wr0) c = g_forced_cfg - wr0;
-        else if (g_forced_cfg >= 0) return MIXQ_EINVAL;  // a P16X64 / plain tiling was forced: wrong operand layout
+        if (g_forced >= wr0) c = g_forced - wr0;
+        else if (g_forced >= 0) return MIXQ_EINVAL;  // a P16X64 / plain tiling was forced: wrong operand layout
         else c = mixq_wr_pick(bit, M, N, KB);
         return mixq_wr_launch(c, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                               ldy, M, N, KB, act, g_trace, mixq_stream(stream));
     }
-    if (g_forced_cfg >= wr0) return MIXQ_EINVAL;
+    if (g_forced >= wr0) return MIXQ_EINVAL;
     // stream-K form (gemm_sk.hip): packed operands, workspace registered, chosen explicitly or by the shape rule
     if (a.x_packed && a.w_packed && act != MIXQ_ACT_SILU_MUL) {       // (the stream-K epilogue has no multiplier form)
         int sk = -1;
-        if (g_forced_cfg >= NUM_CFGS) sk = g_forced_cfg - NUM_CFGS;
-        else if (g_forced_cfg < 0) sk = pick_stream_k(M, N, KB);
+        if (g_forced >= NUM_CFGS) sk = g_forced - NUM_CFGS;
+        else if (g_forced < 0) sk = pick_stream_k(M, N, KB);
         if (sk >= 0 && mixq_sk_usable(sk))
             return mixq_sk_launch(sk, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda,
                                   bias, y, ldy, M, N, KB, act, mixq_stream(stream));
@@ -962,11 +976,16 @@ extern "C" int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_sca
 static int total_configs() { return NUM_CFGS + mixq_sk_num_configs() + 1 + mixq_wr_num_configs(); }
 extern "C" int mixq_gemm_set_config(int cfg) {
     if (cfg < -1 || cfg >= total_configs()) return MIXQ_EINVAL;
-    g_forced_cfg = cfg;
+    g_forced_cfg.set(cfg);
     return MIXQ_OK;
 }
+#ifdef MIXQ_TUNING
 extern "C" int mixq_gemm_set_trace(unsigned long long* buf) { g_trace = buf; return MIXQ_OK; }
 extern "C" int mixq_gemm_set_krot(int v) { return mixq_wr_set_krot(v); }
+#else                                              // product build: no in-kernel stamps, no K rotation knob
+extern "C" int mixq_gemm_set_trace(unsigned long long* buf) { return buf ? MIXQ_EINVAL : MIXQ_OK; }
+extern "C" int mixq_gemm_set_krot(int v) { return v ? MIXQ_EINVAL : MIXQ_OK; }
+#endif
 extern "C" int mixq_gemm_num_configs(void) { return total_configs(); }
 extern "C" int mixq_gemm_config_name(int cfg, char* buf, int cap) {
     if (cfg < 0 || cfg >= total_configs() || !buf || cap <= 0) return MIXQ_EINVAL;

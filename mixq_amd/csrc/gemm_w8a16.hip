@@ -569,18 +569,20 @@ const WoConfig g_wo[] = {
     MIXQ_WO(8, 3, 8, 4, 2, 0, "128x192_s8_d4_l2"),     // 6
     MIXQ_WO(8, 3, 6, 3, 1, 0, "128x192_s6_d3_l1"),     // 7
     MIXQ_WO(2, 1, 8, 5, 1, 0, "32x64_s8_d5_l1"),       // 8: small batches of wide layers (see gemm_wreg.hip's 32x64 tiling)
+#ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): tools build only (make tuning)
     MIXQ_WO(8, 3, 8, 3, 2, 1, "128x192_abl1_noW"),     // tuning: cfg 0 without the weight loads
     MIXQ_WO(8, 3, 8, 3, 2, 2, "128x192_abl2_noX"),     // tuning: cfg 0 without X traffic
     MIXQ_WO(8, 3, 8, 3, 2, 3, "128x192_abl3_mfma"),    // tuning: MFMA + epilogue only
     MIXQ_WO(8, 3, 8, 3, 2, 4, "128x192_abl4_cvt"),     // tuning: MFMA + conversions
     MIXQ_WO(8, 3, 8, 3, 2, 5, "128x192_abl5_noramp"),  // tuning: cfg 0 with all LOOK stages requested at once
+#endif
 };
 constexpr int NUM_WO_PICK = 6;
 // M <= 32: the 32 x 64 tiling (one 64-channel weight panel per workgroup, 5 k-steps of weights in flight per wave): 11.7 us against
 // 20.6 us for gemm_w8a16_skinny_kernel at 32 x 4096 -> 11008, 11.1 vs 11.5 us at 4096 -> 4096 (profiles/r02_decode.txt)
 constexpr int WO_SMALL = 8;
 constexpr int NUM_WO = sizeof(g_wo) / sizeof(g_wo[0]);
-int g_wo_forced = -1;
+MixqDevInt g_wo_forced_dev(-1);                      // per device (common.h)
 
 inline int wo_cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -622,6 +624,7 @@ extern "C" int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_pack
     if ((K % 64) || (N & 3) || (ldy & 3) || ldy < N || ldx < K || (ldx & 7)) return MIXQ_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) return MIXQ_EINVAL;
     if (M == 0 || N == 0) return MIXQ_OK;
+    const int g_wo_forced = g_wo_forced_dev.get();
     WoArgs a;
     a.x = x; a.w = w_packed; a.sw = scale_col; a.bias = bias; a.y = y;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldy = ldy; a.tiles_m = a.tiles_n = 0; a.wblocks = (N + 15) >> 4;
@@ -643,7 +646,7 @@ extern "C" int mixq_gemm_w8a16(const uint16_t* x, int ldx, const uint8_t* w_pack
 
 extern "C" int mixq_gemm_w8a16_set_config(int cfg) {
     if (cfg < -1 || cfg > NUM_WO) return MIXQ_EINVAL;          // NUM_WO = the small-batch kernel
-    g_wo_forced = cfg;
+    g_wo_forced_dev.set(cfg);
     return MIXQ_OK;
 }
 extern "C" int mixq_gemm_w8a16_num_configs(void) { return NUM_WO + 1; }

@@ -101,11 +101,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // weight panel (same tn) start together - they share the panel's bytes in their XCD's L2 - while neighbouring panels start
     // krot k-steps apart, so the CUs of an XCD are not all asking the L2 for the same activation slab at the same moment.
     const int rot = nk > 1 ? (tn * a.krot) % nk : 0;
-    auto stamp = [&](int slot) {
+    auto stamp = [&](int slot) {                         // diagnostics (mixq_gemm_set_trace): tools build only
+#ifdef MIXQ_TUNING
         if (a.trace && tid == 0) {
             a.trace[blockIdx.x * 16 + slot] = wall_clock64();
             a.trace[blockIdx.x * 16 + 8 + slot] = __builtin_readcyclecounter();
         }
+#else
+        (void)slot;
+#endif
     };
     stamp(0);
 
@@ -494,23 +498,23 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         if (TD > 1 && ksteps > 0) tail_load_x(0, 0);
         if (TD > 1 && ksteps > 1) tail_load_x(1, 1);
 
+        // Dequantisation and the first tail k-steps as ONE block-wise pipeline: block b+1 is dequantised (12 VALU) between the
+        // tail MFMAs of block b, so the fp16 MFMAs of the first two tail k-steps (all of the tail up to 64 outlier columns) run under
+        // the dequantisation's VALU work instead of behind it (round 2 ran 288 VALU, then 48 MFMAs: 1.05 us for 41 columns).
+        // Per element the order of operations is unchanged: acc * sx * sw, then k-step 0, 1, 2, ... - results are bit-identical.
         f32x4 fa[MB][WNB];
-        {
-            float swv[WNB][4];
+        float swv[WNB][4], sxv[MB];
 #pragma unroll
-            for (int i = 0; i < WNB; ++i) unpack4(swp[i], swv[i]);
+        for (int i = 0; i < WNB; ++i) unpack4(swp[i], swv[i]);
 #pragma unroll
-            for (int j = 0; j < MB; ++j) {
-                const float sxv = h2f(sxh[j]) * PRE;
+        for (int j = 0; j < MB; ++j) sxv[j] = h2f(sxh[j]) * PRE;
+        auto dequant_block = [&](int j, int i) {
 #pragma unroll
-                for (int i = 0; i < WNB; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) fa[j][i][r] = static_cast<float>(acc[j][i][r]) * sxv * swv[i][r];
-            }
-        }
-        auto tail_mma = [&](int P, int kk) {
+            for (int r = 0; r < 4; ++r) fa[j][i][r] = static_cast<float>(acc[j][i][r]) * sxv[j] * swv[i][r];
+        };
+        auto tail_mask = [&](int P, int kk) {                                    // columns >= n_out of a k-step (the pad may hold anything)
             const int kb = kk * 32 + lq * 8;
-            if (kb + 8 > n_out) {                                                // mask columns >= n_out (the pad may hold anything)
+            if (kb + 8 > n_out) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     uint32_t keep = 0;
@@ -522,22 +526,52 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     for (int i = 0; i < WNB; ++i) woq[P][i][d] &= keep;
                 }
             }
+        };
+        auto tail_mfma1 = [&](int P, int j, int i) {
+            fa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, woq[P][i]), __builtin_bit_cast(f16x8, xoq[P][j]),
+                                                              fa[j][i], 0, 0, 0);
+        };
+        auto tail_mma = [&](int P, int kk) {
+            tail_mask(P, kk);
 #pragma unroll
             for (int j = 0; j < MB; ++j)
 #pragma unroll
-                for (int i = 0; i < WNB; ++i)
-                    fa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, woq[P][i]),
-                                                                      __builtin_bit_cast(f16x8, xoq[P][j]), fa[j][i], 0, 0, 0);
+                for (int i = 0; i < WNB; ++i) tail_mfma1(P, j, i);
+        };
+        // K0 / K1: tail k-step 0 from register set 0 / k-step 1 from set 1 ride along (compile-time: straight-line code)
+        auto dequant_with_tail = [&](auto k0_c, auto k1_c) {
+            constexpr bool K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
+            constexpr int NB = MB * WNB;
+            dequant_block(0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int j = b / WNB, i = b % WNB;
+                if (b + 1 < NB) dequant_block((b + 1) / WNB, (b + 1) % WNB);
+                if constexpr (K0) tail_mfma1(0, j, i);
+                if constexpr (K1) tail_mfma1(TD - 1, j, i);
+                // (block order is left to the scheduler)
+            }
         };
         if constexpr (TD == 1) {
+            dequant_with_tail(std::false_type{}, std::false_type{});
             for (int kk = 0; kk < ksteps; ++kk) { tail_load(0, kk); tail_mma(0, kk); }
         } else {
-            for (int kk0 = 0; kk0 < ksteps; kk0 += 2) {
-                tail_mma(0, kk0);
-                if (kk0 + 2 < ksteps) tail_load(0, kk0 + 2);
-                if (kk0 + 1 < ksteps) {
-                    tail_mma(TD - 1, kk0 + 1);
-                    if (kk0 + 3 < ksteps) tail_load(TD - 1, kk0 + 3);
+            // ONE straight-line form for every outlier count: a register set whose k-step does not exist was never loaded (it
+            // holds old weight-ring bytes) and tail_mask clears all of it (kb >= n_out), so its MFMAs add zeros - under VALU work
+            // that is there anyway.  (Branching between "with" and "without" forms of this phase cost 92-300 spilled registers.)
+            tail_mask(0, 0);
+            tail_mask(1, 1);
+            dequant_with_tail(std::true_type{}, std::true_type{});
+            if (ksteps > 2) {                                                    // > 64 outlier columns: the two sets again, one pair ahead
+                tail_load(0, 2);
+                if (ksteps > 3) tail_load(TD - 1, 3);
+                for (int kk0 = 2; kk0 < ksteps; kk0 += 2) {
+                    tail_mma(0, kk0);
+                    if (kk0 + 2 < ksteps) tail_load(0, kk0 + 2);
+                    if (kk0 + 1 < ksteps) {
+                        tail_mma(TD - 1, kk0 + 1);
+                        if (kk0 + 3 < ksteps) tail_load(TD - 1, kk0 + 3);
+                    }
                 }
             }
         }
@@ -617,11 +651,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             }
         }
     }
+#ifdef MIXQ_TUNING
     if (a.trace) {
         stamp(4);
         wr_wait_vmcnt<0>();
         stamp(5);
     }
+#endif
 }
 
 // ---- configuration table -------------------------------------------------------------------------------------------
@@ -652,28 +688,39 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 11
     MIXQ_WR(8, 4, 8, 3, 1, 0, "128x256_s8_d3_l1"),     // 12
     MIXQ_WR(4, 2, 8, 4, 1, 0, "64x128_s8_d4_l1"),      // 13
-    MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // 14: cfg 0 without the weight loads
-    MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // 15: cfg 0 without X traffic
-    MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // 16: cfg 0, MFMA + epilogue only
-    MIXQ_WR(8, 3, 16, 4, 2, 7, "128x192_abl7_nostore"),// 17: cfg 0 without the stores of Y
-    MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// 18: cfg 0 with ordinary (not nt) stores of Y
-    MIXQ_WR(8, 3, 16, 4, 2, 9, "128x192_abl9_empty"),  // 19: returns at entry: the launch floor of this grid and LDS footprint
     // small batches (M <= 32) of wide layers (N >= 8192): a weight stream, one 64-channel panel per workgroup.  12.4 us against
     // the 17.4 us of gemm_skinny.hip's in-workgroup K split at 32 x 4096 -> 11008 with cold weights; deeper weight rings (10, 14
     // k-steps) are slower (13.8, 14.0 us), narrow layers (N = 4096: 64 panels for 256 CUs) stay with gemm_skinny.hip
     // (profiles/r02_decode.txt)
-    MIXQ_WR(2, 1, 8, 6, 1, 0, "32x64_s8_d6_l1"),       // 20
-    MIXQ_WR(8, 3, 16, 4, 2, 12, "128x192_abl12_noramp"),// 21: cfg 0 with all LOOK stages requested at once (the form before the ramp)
+    MIXQ_WR(2, 1, 8, 6, 1, 0, "32x64_s8_d6_l1"),       // 14 (WR_SMALL)
+#ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): only in the tools build (make tuning)
+    MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
+    MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic
+    MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // cfg 0, MFMA + epilogue only
+    MIXQ_WR(8, 3, 16, 4, 2, 7, "128x192_abl7_nostore"),// cfg 0 without the stores of Y
+    MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// cfg 0 with ordinary (not nt) stores of Y
+    MIXQ_WR(8, 3, 16, 4, 2, 9, "128x192_abl9_empty"),  // returns at entry: the launch floor of this grid and LDS footprint
+    MIXQ_WR(8, 3, 16, 4, 2, 12, "128x192_abl12_noramp"),// cfg 0 with all LOOK stages requested at once (the form before the ramp)
+#endif
 };
+constexpr int WR_SMALL = 14;
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
+#ifdef MIXQ_TUNING
 int g_wr_krot = 0;
+#else
+constexpr int g_wr_krot = 0;
+#endif
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
 int mixq_wr_num_configs() { return NUM_WR; }
+#ifdef MIXQ_TUNING
 int mixq_wr_set_krot(int v) { if (v < 0) return MIXQ_EINVAL; g_wr_krot = v; return MIXQ_OK; }
+#else
+int mixq_wr_set_krot(int v) { return v ? MIXQ_EINVAL : MIXQ_OK; }
+#endif
 const char* mixq_wr_config_name(int c) { return (c >= 0 && c < NUM_WR) ? g_wr[c].name : "?"; }
 
 // Estimated time = rounds over the 256 CUs x (k-steps x time per k-step of one tile + the tile's fixed prologue / epilogue), both
@@ -683,13 +730,13 @@ const char* mixq_wr_config_name(int c) { return (c >= 0 && c < NUM_WR) ? g_wr[c]
 int mixq_wr_pick(int bit, int M, int N, int KB)
 {
     (void)bit;
-    if (M <= 32) return 20;                              // (narrow layers run the weight-stream kernel of gemm_skinny.hip instead)
+    if (M <= 32) return WR_SMALL;                        // (narrow layers run the weight-stream kernel of gemm_skinny.hip instead)
     static const struct { int cfg; float tk, fixed; } cand[] = {
         {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f},
         {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
     // few tiles (narrow layer, small batch): when 64-row tiles would occupy at most half the CUs and 32-row tiles still fit one round,
     // the 32 x 64 tiling wins (64 x 4096 -> 4096: 9.9 vs 11.1 us, 128 x 4096 -> 4096: 10.2 vs 11.3 us; profiles/r02_gemm_ab_mid_batch.txt)
-    if (cdiv(M, 32) * cdiv(N, 64) <= 256 && cdiv(M, 64) * cdiv(N, 64) <= 128) return 20;
+    if (cdiv(M, 32) * cdiv(N, 64) <= 256 && cdiv(M, 64) * cdiv(N, 64) <= 128) return WR_SMALL;
     const int nk = KB >> 6;
     double best = 1e30; int bi = 0;
     for (const auto& c : cand) {

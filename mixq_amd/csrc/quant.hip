@@ -389,8 +389,12 @@ __global__ __launch_bounds__(QT) void repack_kernel(const uint8_t* __restrict__ 
 
 // Launch geometry of the extract + scale + quantise pass: 0 = the round-1 kernel (256 threads, one row per workgroup), 1.. =
 // quant_rows2_kernel as (threads per row, rows per workgroup); -1 = choose by shape.  Tuning / test knob: mixq_quant_set_config.
-int g_quant_cfg = -1;
-int g_quant_dbg = 0;                    // timing probes (bits: 1 no in-place zeroing, 2 no gather loads, 4 no outlier handling, 8 no x_out stores)
+MixqDevInt g_quant_cfg(-1);             // per device (common.h)
+#ifdef MIXQ_TUNING
+int g_quant_dbg = 0;                    // timing probes (bits: 1 no in-place zeroing, 2 no gather loads, 4 no outlier handling, 8 no x_out stores): tools build only
+#else
+constexpr int g_quant_dbg = 0;
+#endif
 constexpr int NUM_QUANT_CFGS = 10;
 
 template <int BIT, int TPR, int RPB>
@@ -417,7 +421,7 @@ int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int
                       uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st)
 {
     const int nchunk = K >> 3;
-    int cfg = g_quant_cfg;
+    int cfg = g_quant_cfg.get();
     if (cfg < 0) {
         // measured on an MI355X (tools/time_quant.py, profiles/r02_quant_sweep.txt), M = 512, K = 4096, 41 outlier columns, us per
         // launch in a graph: (256,1) 5.3 | (256,2) 5.4 | round-1 kernel 5.4 | (128,2) 6.6 | (128,1) 7.1 | (64,x) 9.2-9.4.  A row in ONE wave
@@ -598,8 +602,10 @@ extern "C" int mixq_unpack_operand(const void* src, void* dst, int R, int KB, in
 
 extern "C" int mixq_quant_set_config(int cfg)
 {
+#ifdef MIXQ_TUNING
     if (cfg >= 100) { g_quant_dbg = cfg - 100; return MIXQ_OK; }      // (tools/time_quant.py --probe: results are then wrong on purpose)
+#endif
     if (cfg < -1 || cfg >= NUM_QUANT_CFGS) return MIXQ_EINVAL;
-    g_quant_cfg = cfg;
+    g_quant_cfg.set(cfg);
     return MIXQ_OK;
 }

@@ -42,6 +42,9 @@ PACK_FMT = FMT_F16X64
 # After a layer's outlier search has frozen, keep ONLY the packed weight image in HBM (the plain [N,K] `q_weight` is
 # re-created on demand for state_dict / attribute reads).  False keeps both copies (2x the reference's weight memory).
 COMPACT_WEIGHTS = True
+# Frozen layers run their forward (extract + quantise, GEMM) through ONE C-ABI call on a kept argument block
+# (mixq_linear_forward).  False keeps the two-call route (same kernels, same results; the parity test compares the two).
+ONE_CALL_FORWARD = True
 
 
 def set_pack_fmt(fmt):
@@ -170,6 +173,8 @@ class MixLinear_GEMM(nn.Module):
         self._n_dev = None           # int32[1] on the device: the live outlier count (kernel.py:108-111 reads K this way)
         self._n_dev_host = -1
         self._silu_calls = 0
+        self._plan = None            # argument block of the one-call forward of the frozen layer (mixq_linear_forward)
+        self._plan_key = None
 
     # ------------------------------------------------------------------------------------------------------
     @classmethod
@@ -385,6 +390,45 @@ class MixLinear_GEMM(nn.Module):
         return _backend.FusedLinear(qx, w, cache.x_scale, self.scale_col, None, None, 0, self.bias, M, self.out_features,
                                     self.in_features, bit=self.bit, act=act, addend=addend)
 
+    # ---- frozen steady state: the whole forward behind ONE foreign call (include/mixq_hip.h: mixq_linear_forward) ------
+    def _frozen_key(self, cache, inputs, M):
+        """Identity of everything the kept argument block carries an address of: a replaced tensor (new id) or an in-place rewrite
+        of a tensor this layer keeps a derived copy of (`ind`, `weight_cache`, `q_weight`: their versions) invalidates the plan."""
+        d = self.__dict__
+        b = d["_buffers"]
+        ind = d.get("ind")
+        if ind is None:
+            ind = b.get("ind")
+        wc = d.get("weight_cache")
+        if wc is None:
+            wc = b.get("weight_cache")
+        qw = b.get("q_weight")
+        return (M, inputs.stride(0), id(cache), id(cache.x_scale), id(ind), ind._version, id(d.get("_wpk")), id(qw),
+                -1 if qw is None else qw._version, id(wc), -1 if wc is None else wc._version, id(b.get("bias", d.get("bias"))),
+                id(b.get("scale_col")), PACK_FMT)
+
+    def _build_plan(self, cache, inputs, M):
+        if not hasattr(_backend, "ForwardPlan") or M == 0 or inputs.dtype != torch.float16 or inputs.stride(1) != 1 \
+                or inputs.stride(0) % 8 or not inputs.is_cuda:
+            return None
+        wpk = self._packed_weight()
+        if wpk is None:
+            return None                                      # K % 64: plain operands, the two-call route serves them
+        n = int(self.ind.shape[0])
+        ind_buf, n_dev = self._ind_dev()
+        wo = None
+        if n:
+            wc = self.weight_cache
+            key = (id(wc), wc.data_ptr(), wc._version, tuple(wc.shape), wc.stride(0))
+            if self._wo_key != key:
+                self._wo_ready, self._wo_key = _gemm_ready(wc), key
+            wo = self._wo_ready
+            if wo is None or wo.shape[1] != n or wo.stride(0) < _pad16(n):
+                return None
+            wo = _wide(wo, _pad16(n))
+        return _backend.ForwardPlan(M, self.out_features, self.in_features, self.bit, self._sigma_f, inputs.stride(0), ind_buf, n, n_dev,
+                                    cache.x_scale, wpk, self.scale_col, wo, self.bias, self.x_fmt())
+
     # ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, x, cache=None, unfused=False):
@@ -393,6 +437,23 @@ class MixLinear_GEMM(nn.Module):
         cache.shape = x.shape[:-1] + (self.out_features,)
         inputs = x.reshape(-1, x.shape[-1])
         M = inputs.shape[0]
+        if unfused and not self.add_outliers and self.weight_only is False and ONE_CALL_FORWARD:
+            # prediction frozen: extract + quantise + GEMM enqueued by one C call on a kept argument block; bit-identical to the
+            # route below (tests/test_gpu_parity.py::test_one_call_forward_is_bit_identical)
+            key = self._frozen_key(cache, inputs, M)
+            if self._plan_key != key:
+                self._plan = self._build_plan(cache, inputs, M)
+                if COMPACT_WEIGHTS and self._plan is not None:
+                    self.compact_weights_()                  # (e.g. after a load_state_dict into a frozen layer re-created q_weight)
+                self._plan_key = self._frozen_key(cache, inputs, M)
+            plan = self._plan
+            if plan is not None:
+                y1, cache.q_xcache, xo = plan.run(inputs)
+                if xo is not None:
+                    cache.activation_outliers = xo
+                cache.n_dev = plan.keep[1]
+                cache.ind = self.ind
+                return y1.reshape(cache.shape)
         if self.weight_only is True:
             # linear.py:178-184 (w8_a16_gemm, then `y += bias`): here the bias rides in the GEMM epilogue
             key = (id(self.q_weight), self.q_weight.data_ptr(), self.q_weight._version)

@@ -12,8 +12,6 @@ DetectOutlierCols, DequantWeightCols, FusedLinear), used by mixq_amd.linear.MixL
 """
 from __future__ import annotations
 
-import weakref
-
 import torch
 
 from . import _capi
@@ -119,7 +117,7 @@ def FindRowScale(x, x_scale, M, K, bit=8):
         raise RuntimeError("FindRowScale: bit must be 4 or 8")
     KB, dt = (K, torch.int8) if bit == 8 else (K // 2, torch.uint8)
     global _pending_extract
-    pend = _pending_extract() if _pending_extract is not None else None
+    pend = _pending_extract
     if pend is not None:
         ind_p, x_p, ldo_p = pend._mixq_pending
         same = (x_p.data_ptr() == x2.data_ptr() and tuple(x_p.shape) == tuple(x2.shape) and x_p.stride(0) == x2.stride(0)
@@ -176,7 +174,8 @@ def _pad16(n):
 # tensor first - or a FindRowScale / ExtractOutliersAndSetToZeros on another tensor - runs the deferred extraction at once, in order.
 # What it cannot see: code that READS x between the two calls would still find the outlier columns unzeroed.  Off by default.
 _fused_prepass = False
-_pending_extract = None        # weakref to the OutlierActivations whose extraction is still deferred
+_pending_extract = None        # the OutlierActivations whose extraction is still deferred (a STRONG reference: the in-place zeroing of
+                               # x is a side effect the caller is owed even if it drops the returned tensor before FindRowScale runs)
 
 
 def set_fused_prepass(enabled):
@@ -188,7 +187,7 @@ def set_fused_prepass(enabled):
 
 def _flush_pending_extract():
     global _pending_extract
-    t = _pending_extract() if _pending_extract is not None else None
+    t = _pending_extract
     _pending_extract = None
     if t is not None:
         t._run_extract()
@@ -245,6 +244,18 @@ class PendingOutlierProduct(torch.Tensor):
             xo, wo_t = self._mixq_args
             torch.mm(xo.as_subclass(torch.Tensor), wo_t, out=self.as_subclass(torch.Tensor))
         self._mixq_args = None
+
+    # exports that do not go through __torch_function__ compute the values first
+    def __dlpack__(self, *args, **kwargs):
+        self._materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__dlpack__(*args, **kwargs)
+
+    @property
+    def __cuda_array_interface__(self):
+        self._materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__cuda_array_interface__
 
     def _operands(self):
         """(x_out, ldxo-ready tensor, w_out padded, n) for the fused tail, or None once materialised."""
@@ -306,7 +317,7 @@ def ExtractOutliersAndSetToZeros(ind, x):
         out = buf[:, :n].as_subclass(OutlierActivations)
         if _fused_prepass and x.dim() == 2:
             out._mixq_pending = (ind, x, buf.shape[1])
-            _pending_extract = weakref.ref(out)
+            _pending_extract = out
             return out
         _capi.call("mixq_extract_outliers_zero", xp, ind.data_ptr(), n, buf.data_ptr(), M, K, ldx, buf.shape[1], _stream())
         return out
@@ -418,6 +429,18 @@ class PendingGemmI32(torch.Tensor):
             _capi.call("mixq_gemm_i8", q_x.data_ptr(), q_w.data_ptr(), self.data_ptr(), N, M, N, K, _stream())
         self._mixq_args = None
 
+    # exports that do not go through __torch_function__ compute the values first
+    def __dlpack__(self, *args, **kwargs):
+        self._materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__dlpack__(*args, **kwargs)
+
+    @property
+    def __cuda_array_interface__(self):
+        self._materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__cuda_array_interface__
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
@@ -433,20 +456,27 @@ class PendingGemmI32(torch.Tensor):
             return func(*args, **kwargs)
 
 
-_lazy_gemm = True
+_lazy_gemm = False
 
 
 def set_lazy_gemm(enabled):
-    """False: `gemm` computes its int32 result at once (the literal unfused pair); True (default): deferred, see PendingGemmI32."""
+    """False (default): `gemm` computes its int32 result at once (the literal unfused pair).  True: deferred, see PendingGemmI32 - an
+    opt-in like the switches above, because a consumer that bypasses __torch_function__ (a C++ extension taking at::Tensor) would
+    read the not-yet-computed storage.  set_packed_operands(True) / set_fused_outliers(True) imply it: their handles only make sense
+    when `gemm` + `dequantizeInt8` run as one kernel."""
     global _lazy_gemm
     prev, _lazy_gemm = _lazy_gemm, bool(enabled)
     return prev
 
 
+def _lazy():
+    return _lazy_gemm or _packed_operands or _fused_outliers
+
+
 def gemm(q_x, q_w, M, N, K):
     """mixlib.gemm(q_x, q_w, M, N, K) -> int32 [M,N] (linear.py:235,321)."""
     _dev_check(q_x, q_w)
-    if fmt_of(q_w) != FMT_PLAIN or (fmt_of(q_x) != FMT_PLAIN and not _lazy_gemm):
+    if fmt_of(q_w) != FMT_PLAIN or (fmt_of(q_x) != FMT_PLAIN and not _lazy()):
         raise RuntimeError("mixlib.gemm: the raw int32 GEMM takes plain row-major operands")
     if K % 64 or N % 4:
         raise _capi.MixqError("mixq_gemm_i8", _capi.MIXQ_ESHAPE)
@@ -456,7 +486,7 @@ def gemm(q_x, q_w, M, N, K):
         # a one-byte-per-value GEMM over them would read past both buffers)
         raise RuntimeError(f"mixlib.gemm: operands must be one-byte [>=M,K] and [>=N,K] matrices (got {tuple(q_x.shape)}, "
                            f"{tuple(q_w.shape)} for M,N,K = {M},{N},{K}); nibble-packed int4 operands go through int4FusedDequantize")
-    if _lazy_gemm and M > 0 and N > 0:
+    if _lazy() and M > 0 and N > 0:
         return PendingGemmI32(q_x, q_w, M, N, K)
     y = torch.empty((M, N), dtype=torch.int32, device=q_x.device)
     _capi.call("mixq_gemm_i8", q_x.data_ptr(), q_w.data_ptr(), y.data_ptr(), N, M, N, K, _stream())
@@ -655,6 +685,56 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
     _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(), xop, ldxo, wop, ldwo, n_out,
                _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act, _layout_bits(x_fmt, w_fmt), _stream())
     return y
+
+
+class ForwardPlan:
+    """The argument block of mixq_linear_forward (include/mixq_hip.h) for one frozen layer and batch size, built once and re-used:
+    a forward then costs three allocations, four pointer updates and ONE foreign call that enqueues the quantise pass and the
+    GEMM (the steady state of linear.py:187-193 + :244-285).  Holds references to every tensor whose address it carries."""
+
+    __slots__ = ("args", "ref", "fn", "keep", "M", "N", "n", "ldxo", "q_shape", "q_dtype", "qfmt", "device")
+
+    def __init__(self, M, N, K, bit, sigma, ldx, ind_buf, n, n_dev, x_scale, q_w, scale_col, w_out, bias, qfmt, act=ACT_NONE):
+        import ctypes as C
+        _dev_check(x_scale, q_w, scale_col, ind_buf, n_dev, w_out, bias)
+        if x_scale.numel() < M or scale_col.numel() < N:
+            raise RuntimeError("ForwardPlan: x_scale / scale_col are shorter than M / N")
+        n_cap = 0 if ind_buf is None else int(ind_buf.numel())
+        a = _capi.LinearArgs()
+        a.ldx, a.M, a.N, a.K, a.bit, a.sigma, a.act = ldx, M, N, K, bit, float(sigma), act
+        a.qfmt, a.wfmt = qfmt, fmt_of(q_w)
+        a.ind, a.n_cap, a.n_dev = _ptr(ind_buf), n_cap, _ptr(n_dev)
+        a.x_scale, a.q_w, a.scale_col, a.bias = x_scale.data_ptr(), q_w.data_ptr(), scale_col.data_ptr(), _ptr(bias)
+        self.ldxo = a.ldxo = _pad16(n_cap) if n_cap else 0
+        if n_cap:
+            ind_buf = _check_ind(ind_buf, "ForwardPlan")
+            wop, ldwo = _rows(w_out, "w_out")
+            if ldwo < n_cap or ldwo % 8:
+                raise RuntimeError("ForwardPlan: w_out row stride must be >= the outlier capacity and a multiple of 8")
+            a.w_out, a.ldwo = wop, ldwo
+        a.ldy = N
+        self.args, self.ref, self.fn = a, C.byref(a), _capi.load().mixq_linear_forward
+        self.keep = (ind_buf, n_dev, x_scale, q_w, scale_col, w_out, bias)
+        self.M, self.N, self.n, self.qfmt, self.device = M, N, n, qfmt, x_scale.device
+        KB = K if bit == 8 else K // 2
+        self.q_shape, self.q_dtype = (packed_rows(M) if qfmt else M, KB), (torch.int8 if bit == 8 else torch.uint8)
+
+    def run(self, x):
+        """x: fp16 [M,K] with the row stride the plan was built for.  Returns (y [M,N], q_x, x_out [M,n] or None)."""
+        a = self.args
+        dev = self.device
+        q = torch.empty(self.q_shape, dtype=self.q_dtype, device=dev)
+        y = torch.empty((self.M, self.N), dtype=torch.float16, device=dev)
+        xo = None
+        if self.ldxo:
+            xo = torch.empty((self.M, self.ldxo), dtype=torch.float16, device=dev)
+            a.x_out = xo.data_ptr()
+        a.x, a.q_x, a.y = x.data_ptr(), q.data_ptr(), y.data_ptr()
+        rc = self.fn(self.ref, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise _capi.MixqError("mixq_linear_forward", rc)
+        q._mixq_fmt = self.qfmt
+        return y, q, (xo[:, :self.n] if xo is not None else None)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -33,6 +33,24 @@ def test_header_arity_matches_ctypes_table():
         assert n == len(_capi.SIGNATURES[name]), f"{name}: header has {n} parameters, ctypes table {len(_capi.SIGNATURES[name])}"
 
 
+def test_linear_args_block_matches_the_header():
+    """struct mixq_linear_args: the ctypes mirror has the header's fields in the header's order with matching C types."""
+    txt = open(_capi.HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    body = re.search(r"typedef struct mixq_linear_args \{(.*?)\} mixq_linear_args;", txt, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        kind = "ptr" if "*" in decl else ("float" if decl.startswith("float") else "int")
+        names = [v.strip().lstrip("*").strip() for v in re.sub(r"^(const\s+)?\w+\s*\**", "", decl, count=1).split(",")]
+        fields += [(nm, kind) for nm in names]
+    want = {"ptr": C.c_void_p, "int": C.c_int, "float": C.c_float}
+    assert [(nm, want[k]) for nm, k in fields] == list(_capi.LinearArgs._fields_)
+    assert C.sizeof(_capi.LinearArgs) >= 8 * 14 + 4 * 13
+
+
 def test_code_object_is_gfx950():
     """The fat binary carries gfx950 code objects and nothing for another GPU (read from the bundle's own entry ids; running
     llvm-objdump --offloading would unpack the bundle next to the library)."""
@@ -79,6 +97,32 @@ def test_argument_validation_without_device():
     assert lib.mixq_gemm_w8a16(C.c_void_p(8), 128, one, one, None, one, 64, 4, 64, 128, None) == _capi.MIXQ_EINVAL  # x alignment
     assert lib.mixq_gemm_w8a16(one, 128, one, one, None, one, 64, 0, 64, 128, None) == 0                      # M = 0
     assert lib.mixq_gemm_w8a16_set_config(99) == _capi.MIXQ_EINVAL and lib.mixq_gemm_w8a16_set_config(-1) == 0
+    # the one-call forward checks its block before it launches anything
+    assert lib.mixq_linear_forward(None, None) == _capi.MIXQ_EINVAL
+    blk = _capi.LinearArgs()
+    blk.bit = 3
+    assert lib.mixq_linear_forward(C.byref(blk), None) == _capi.MIXQ_EINVAL
+
+
+def test_product_library_ships_no_tuning_variants():
+    """The product .so exports no configuration whose output is wrong by design (the ablation forms), no trace stamps, no K rotation
+    and no quantise probes: those live in the -DMIXQ_TUNING build only (engineering #8)."""
+    assert os.path.basename(_capi.LIB_PATH) == "libmixq_hip.so"
+    lib = _capi.load()
+    assert all("abl" not in nm for nm in _capi.gemm_config_names()), _capi.gemm_config_names()
+    assert all("abl" not in nm for nm in _capi.w8a16_config_names())
+    assert lib.mixq_gemm_set_trace(C.c_void_p(4096)) == _capi.MIXQ_EINVAL and lib.mixq_gemm_set_trace(None) == 0
+    assert lib.mixq_gemm_set_krot(3) == _capi.MIXQ_EINVAL and lib.mixq_gemm_set_krot(0) == 0
+    assert lib.mixq_quant_set_config(100) == _capi.MIXQ_EINVAL and lib.mixq_quant_set_config(-1) == 0
+    blob = open(_capi.LIB_PATH, "rb").read()
+    assert b"abl3_mfma" not in blob and b"abl1_noW" not in blob
+
+
+def test_forced_configuration_round_trips():
+    lib = _capi.load()
+    names = _capi.gemm_config_names()
+    assert lib.mixq_gemm_set_config(len(names) - 1) == 0 and lib.mixq_gemm_set_config(-1) == 0
+    assert lib.mixq_quant_set_config(9) == 0 and lib.mixq_quant_set_config(10) == _capi.MIXQ_EINVAL and lib.mixq_quant_set_config(-1) == 0
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):

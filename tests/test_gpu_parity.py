@@ -1683,6 +1683,12 @@ def test_bench_line_contract_on_the_gpu():
     cb = out["cpu_baseline"]
     assert cb["unit"] == "TFLOPS" and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
     assert out["max_abs_err_vs_dequant_linear"] <= 1e-2
+    # secondary timings: the reference's eager protocol and the cold-weights rotation, both slower than or equal to the
+    # graph figure, neither absurd
+    tm = out["timing"]
+    assert tm["eager_ms_per_step"] >= 0.9 * out["ms_per_step"] and tm["eager_ms_per_step"] < 20 * out["ms_per_step"]
+    assert tm["cold_weights_ms_per_step"] >= 0.9 * out["ms_per_step"] and tm["cold_weights_ms_per_step"] < 3 * out["ms_per_step"]
+    assert "layer copies" in tm["cold_weights_protocol"]
 
 
 def test_bench_collectives_over_rccl_single_rank():

@@ -1,0 +1,178 @@
+"""Round-3 parity tests on the MI355X (through the C ABI): the one-call forward of a frozen layer against the two-call route, the
+operator-level full-size forwards round 2 covered only by the int32 checksum, and the bench line's other configurations."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mixq_amd import MixLibCache, MixLinear_GEMM, _capi, mixlib  # noqa: E402
+from mixq_amd import linear as L  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+DEV = "cuda"
+GATE = 1e-2
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def ulp_tol(ref):
+    a = np.abs(ref.astype(np.float32))
+    ulp = np.where(a > 0, 2.0 ** (np.floor(np.log2(np.maximum(a, 6e-5))) - 10), 2.0 ** -24)
+    return np.maximum(2 * ulp, 1e-3)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    assert "gfx950" in _capi.device_info()
+    _capi.load().mixq_gemm_set_config(-1)
+    yield
+    _capi.load().mixq_gemm_set_config(-1)
+    L.ONE_CALL_FORWARD = True
+
+
+def frozen_layer(M, K, N, bit, ncols, bias, seed=0):
+    torch.manual_seed(seed)
+    lin = torch.nn.Linear(K, N, bias=bias).half()
+    cols = torch.randperm(K, generator=torch.Generator().manual_seed(1))[:ncols]
+    cache = MixLibCache(M, bit=bit, device=DEV)
+    if bit == 8:
+        layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
+    else:
+        scales = torch.ones(K) + torch.arange(K) * 1e-6
+        scales[cols] = 20.0 + torch.arange(cols.numel()) * 1e-3
+        layer = MixLinear_GEMM.from_linear(lin, 4, cache=cache, layer_scales=scales, dev=DEV)
+    for call in range(3):
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(10 + call)).half()
+        x[:, cols] *= 20
+        layer(x.to(DEV), None, True)
+    assert layer.add_outliers is False
+    return layer, cache, cols
+
+
+@pytest.mark.parametrize("M,K,N,bit,ncols,bias", [(512, 4096, 11008, 8, 41, False), (96, 1024, 320, 8, 5, True), (40, 512, 256, 8, 0, False),
+                                                   (33, 1024, 192, 8, 16, True), (64, 1024, 256, 4, 10, False), (512, 4096, 4096, 4, 41, True)])
+def test_one_call_forward_is_bit_identical(M, K, N, bit, ncols, bias):
+    """mixq_linear_forward (one C call, kept argument block) against the two-call route (mixq_quant_fused, mixq_gemm_i*_fused) on
+    the same frozen layer and input: y, x_scale, q_x, the extracted outliers and the zeroed x must agree bit for bit."""
+    layer, cache, cols = frozen_layer(M, K, N, bit, ncols, bias)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(77)).half()
+    x[:, cols] *= 20
+    res = {}
+    for one in (False, True, True):                                  # the third run re-uses the kept plan
+        L.ONE_CALL_FORWARD = one
+        xd = x.to(DEV)
+        cache.x_scale.zero_()
+        y = layer(xd, None, True)
+        torch.cuda.synchronize()
+        if one:
+            assert layer._plan is not None, "the frozen layer did not take the one-call route"
+        got = (n(y).copy(), n(cache.x_scale[:M]).copy(), n(cache.q_xcache).copy(), n(xd).copy(),
+               None if cache.activation_outliers is None else n(cache.activation_outliers).copy(), mixlib.fmt_of(cache.q_xcache))
+        if not res:
+            res = got
+            continue
+        for a, b in zip(res[:4], got[:4]):
+            assert np.array_equal(a.view(np.uint8) if a.dtype != np.uint8 else a, b.view(np.uint8) if b.dtype != np.uint8 else b)
+        assert (res[4] is None) == (got[4] is None) and (res[4] is None or np.array_equal(res[4].view(np.uint16), got[4].view(np.uint16)))
+        assert res[5] == got[5]
+    L.ONE_CALL_FORWARD = True
+    # and the route is the operator's real arithmetic: sampled rows against the oracle
+    rows = sorted({0, M // 2, M - 1})
+    xh = x.numpy()[rows].copy()
+    ind = n(layer.ind).astype(np.int32)
+    xo = O.extract_outliers_zero(xh, ind) if ind.size else None
+    qx, sx = O.find_row_scale(xh, bit)
+    ref = O.linear_fused(qx, n(layer.q_weight), sx, n(layer.scale_col), xo=xo, wo=(n(layer.weight_cache) if ind.size else None),
+                         bias=(n(layer.bias) if bias else None), bit=bit).astype(np.float32)
+    assert (np.abs(res[0][rows].astype(np.float32) - ref) <= ulp_tol(ref)).all()
+
+
+def test_one_call_plan_follows_the_layer_state():
+    """The kept argument block is dropped when anything it carries an address of is replaced: another batch size, a strided input, a
+    reloaded state dict, an in-place rewrite of `ind`'s companion tensors."""
+    layer, cache, cols = frozen_layer(64, 1024, 256, 8, 7, True)
+    x = torch.randn(64, 1024, generator=torch.Generator().manual_seed(5)).half()
+    x[:, cols] *= 20
+    y1 = layer(x.to(DEV), None, True)
+    p1 = layer._plan
+    y1b = layer(x.to(DEV), None, True)
+    assert layer._plan is p1 and torch.equal(y1, y1b)
+    y2 = layer(x[:32].to(DEV), None, True)                              # another M: a new block
+    assert layer._plan is not p1 and torch.equal(y2, y1[:32])
+    wide = torch.zeros(64, 2048, dtype=torch.float16, device=DEV)       # a row-strided view of a wider buffer
+    wide[:, :1024] = x.to(DEV)
+    y3 = layer(wide[:, :1024], None, True)
+    assert torch.equal(y3, y1)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    sd["bias"] = sd["bias"] + 1
+    layer.load_state_dict(sd)
+    y4 = layer(x.to(DEV), None, True)
+    L.ONE_CALL_FORWARD = False
+    y4b = layer(x.to(DEV), None, True)
+    L.ONE_CALL_FORWARD = True
+    assert torch.equal(y4, y4b) and not torch.equal(y4, y1)
+
+
+def test_linear_forward_c_entry_validates_its_block():
+    lib = _capi.load()
+    assert lib.mixq_linear_forward(None, None) == _capi.MIXQ_EINVAL
+    a = _capi.LinearArgs()
+    a.bit = 5
+    assert lib.mixq_linear_forward(C.byref(a), None) == _capi.MIXQ_EINVAL
+    a.bit, a.wfmt, a.qfmt = 8, _capi.FMT_F16X64, _capi.FMT_PLAIN          # fragment-order weights need P16X64 activations
+    assert lib.mixq_linear_forward(C.byref(a), None) == _capi.MIXQ_EINVAL
+    a.wfmt, a.qfmt, a.n_cap = _capi.FMT_PLAIN, _capi.FMT_PLAIN, 16          # outlier capacity without the tail's operands
+    assert lib.mixq_linear_forward(C.byref(a), None) == _capi.MIXQ_EINVAL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# operator-level forwards at the BASELINE shapes round 2 covered only through the raw int32 checksum
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N", [(28672, 8192), (11008, 4096), (4096, 6144), (8192, 10240), (4096, 4096), (4096, 12288)])
+def test_full_size_operator_remaining_shapes_with_one_percent_outliers(K, N):
+    """M = 512, 1 % outlier columns (287 at K = 28672: the > 128 tail at full size), prediction frozen; quantise + GEMM + fp16 tail +
+    dequant epilogue on sampled rows against the oracle (<= 2 fp16 ulp) and the north-star gate."""
+    M = 512
+    layer, cache, cols = frozen_layer(M, K, N, 8, round(0.01 * K), False)
+    assert set(cols.tolist()) <= set(n(layer.ind).tolist())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(12)).half()
+    x[:, cols] *= 20
+    y = layer(x.to(DEV), None, True)
+    rows = [0, 255, 511]
+    xh = x.numpy()[rows].copy()
+    ind = n(layer.ind).astype(np.int32)
+    xo = O.extract_outliers_zero(xh, ind)
+    qx, sx = O.find_row_scale(xh, 8)
+    qw, sw, wo = n(layer.q_weight), n(layer.scale_col), n(layer.weight_cache)
+    ref = O.linear_fused(qx, qw, sx, sw, xo=xo, wo=wo).astype(np.float32)
+    got = n(y)[rows].astype(np.float32)
+    assert (np.abs(got - ref) <= ulp_tol(ref)).all(), float(np.abs(got - ref).max())
+    gate = O.linear_dequant_ref(qx, qw, sx, sw, xo=xo, ind=ind, wo=wo)
+    a = np.abs(gate)
+    assert (np.abs(got - gate) <= np.maximum(GATE, 2.0 ** (np.floor(np.log2(np.maximum(a, 1.0))) - 10))).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's other configurations work first time (config 3's shape for the SCALE command, config 2's bit width)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("extra,K,N,bit", [(["--shape", "8192,28672"], 8192, 28672, 8), (["--bit", "4"], 4096, 11008, 4)])
+def test_bench_other_configs_run(extra, K, N, bit):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-secondary"] + extra,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["K"] == K and out["config"]["N"] == N and out["steps"] == 5
+    assert out["value"] == pytest.approx(2.0 * 512 * K * N / (out["ms_per_step"] * 1e-3) / 1e12, rel=1e-3)
+    assert out["max_abs_err_vs_dequant_linear"] <= (1e-2 if bit == 8 else 4e-2)       # (W4: |y| reaches 30 at 128 fp16 columns: 1 ulp = 1.6e-2)
+    assert f"W{bit}A{bit}O16" in out["metric"] and out["roofline"]["frac"] > 0.1

@@ -173,3 +173,46 @@ def test_weight_only_checkpoint_in_the_references_layout(tmp_path):
             sd["fc_out.q_weight"] = eetq.unprocess_weights(sd["fc_out.q_weight"])
         fresh.load_state_dict(sd)
         assert torch.equal(fresh.fc_out.q_weight, plain)
+
+
+def test_keyless_checkpoints_are_told_apart_by_their_bytes(tmp_path):
+    """a checkpoint without the `w8a16_layout` key is the reference's (interleaved image) OR this library's own round-1
+    output (plain matrix).  load_quantized decides from the bytes, warns, and an explicit argument overrides."""
+    import json
+    import pytest
+    from mixq_amd import checkpoint as ck
+    from mixq_amd import MixLibCache
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc_out = torch.nn.Linear(128, 64, bias=False)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([Blk()])
+    torch.manual_seed(0)
+    m = Net().half()
+    cache = MixLibCache(8, device="cpu")
+    ck.quantize_(m, 8, cache, arch="GPTJForCausalLM", blocks=m.layers)
+    assert m.layers[0].fc_out.weight_only
+    plain = m.layers[0].fc_out.q_weight.clone()
+    assert ck.detect_w8a16_layout(plain) == "plain" and ck.detect_w8a16_layout(eetq.preprocess_weights(plain)) == "eetq"
+    for layout in ("plain", "eetq"):
+        d = tmp_path / layout
+        ck.save_quantized(m, str(d), {"w_bit": 8}, w8a16_layout=layout)
+        cfg = json.load(open(d / "quant_config.json"))
+        assert cfg["writer"] == "mixq_amd"
+        cfg.pop("w8a16_layout"); cfg.pop("writer")                   # a round-1 checkpoint of ours / a reference checkpoint
+        json.dump(cfg, open(d / "quant_config.json", "w"))
+        fresh = Net().half()
+        with pytest.warns(RuntimeWarning, match="w8a16_layout"):
+            ck.load_quantized(fresh, str(d), cache, arch="GPTJForCausalLM", blocks=fresh.layers)
+        assert torch.equal(fresh.layers[0].fc_out.q_weight, plain), layout
+        fresh2 = Net().half()                                          # the explicit argument wins, silently
+        import warnings as w
+        with w.catch_warnings():
+            w.simplefilter("error")
+            ck.load_quantized(fresh2, str(d), cache, arch="GPTJForCausalLM", blocks=fresh2.layers, w8a16_layout=layout)
+        assert torch.equal(fresh2.layers[0].fc_out.q_weight, plain)

@@ -5,7 +5,9 @@ round-robin for `--rounds` rounds, each replay timed with HIP events, and the pe
 reported - drift of clocks and temperature hits all configurations alike."""
 import argparse, os, sys
 import numpy as np
+import os
 import torch
+os.environ.setdefault("MIXQ_TUNING_LIB", "1")      # ablation kernels / trace stamps / probe knobs live in the tools build (make tuning)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mixq_amd import _capi, mixlib
 

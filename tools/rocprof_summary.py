@@ -7,7 +7,11 @@ import sys
 from collections import defaultdict
 
 
-def short(name, n=70):
+WIDTH = 70
+
+
+def short(name, n=None):
+    n = n or WIDTH
     name = name.replace("(anonymous namespace)::", "")
     return name if len(name) <= n else name[: n - 3] + "..."
 
@@ -15,6 +19,9 @@ def short(name, n=70):
 def main():
     db = sys.argv[1]
     filt = sys.argv[2] if len(sys.argv) > 2 else ""
+    global WIDTH
+    if len(sys.argv) > 3:
+        WIDTH = int(sys.argv[3])                # full kernel names (library kernels encode their tiling in them)
     con = sqlite3.connect(db)
     cur = con.cursor()
     rows = cur.execute("select name, start, end from kernels").fetchall()

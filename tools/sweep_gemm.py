@@ -10,6 +10,7 @@ import sys
 import time
 
 import torch
+os.environ.setdefault("MIXQ_TUNING_LIB", "1")      # ablation kernels / trace stamps / probe knobs live in the tools build (make tuning)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mixq_amd import _capi, mixlib  # noqa: E402

@@ -3,6 +3,7 @@
 (mixq_quant_set_config) and output format.  HBM bytes per launch: 2 M K read + M K bit/8 written (+ outlier columns)."""
 import os, sys
 import torch
+os.environ.setdefault("MIXQ_TUNING_LIB", "1")      # ablation kernels / trace stamps / probe knobs live in the tools build (make tuning)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mixq_amd import _capi, mixlib
 from tools.sweep_gemm import time_graph

@@ -70,10 +70,46 @@ void run(const char* name, int grid, int* out, unsigned long long* cyc)
            ops / (ms * 1e-3) / 1e12, avg / (ms * 1e3), avg / per_simd);
 }
 
-int main()
+// steady-state form (`ubench_mfma SECONDS`): the same kernel launched back to back for SECONDS so the chip settles into the clock its
+// power budget allows; reports the sustained rate over the second half of the run
+template <int W, int SHAPE>
+void run_long(const char* name, double seconds, int* out, unsigned long long* cyc)
+{
+    const int iters = 200000, grid = 256;                                  // ~27 ms per launch
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    double total_ms = 0, late_ms = 0, late_cyc = 0; int late_n = 0;
+    while (total_ms < seconds * 1e3) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((mfma_kernel<W, 0, SHAPE>), dim3(grid), dim3(W * 64), 0, 0, iters, out, cyc);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+        if (total_ms > seconds * 500) {
+            unsigned long long h[256];
+            CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
+            double avg = 0; for (int i = 0; i < grid; ++i) avg += (double)h[i]; avg /= grid;
+            late_ms += ms; late_cyc += avg; ++late_n;
+        }
+    }
+    const double ops = (double)grid * W * iters * 8 * (SHAPE == 32 ? 65536.0 : 32768.0) * late_n;
+    printf("%-28s sustained over %.1f s: %7.1f TOPS  clk(memtime)=%.0f MHz  cycles/MFMA/SIMD=%.2f\n", name, late_ms * 1e-3,
+           ops / (late_ms * 1e-3) / 1e12, late_cyc / (late_ms * 1e3), late_cyc / ((double)iters * 8 * (W / 4) * late_n));
+    fflush(stdout);
+}
+
+int main(int argc, char** argv)
 {
     int* out; unsigned long long* cyc;
     CHECK(hipMalloc(&out, 64)); CHECK(hipMalloc(&cyc, 8 * 1024));
+    if (argc > 1) {
+        const double s = atof(argv[1]);
+        run_long<4, 16>("w4 mfma_i32_16x16x64_i8", s, out, cyc);
+        run_long<8, 16>("w8 mfma_i32_16x16x64_i8", s, out, cyc);
+        run_long<4, 32>("w4 mfma_i32_32x32x32_i8", s, out, cyc);
+        return 0;
+    }
 #define RUN(W, B, S, G) run<W, B, S>("w" #W " barrier/" #B " mfma" #S, G, out, cyc)
     RUN(4, 0, 32, 256); RUN(8, 0, 32, 256); RUN(8, 8, 32, 256); RUN(8, 4, 32, 256); RUN(4, 8, 32, 256); RUN(4, 4, 32, 256);
     RUN(8, 0, 32, 172); RUN(8, 8, 32, 172);
