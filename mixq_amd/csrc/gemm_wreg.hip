@@ -44,10 +44,14 @@ struct WrArgs {
     int tiles_m, tiles_n;
     int xblocks, wblocks;                             // 16-row blocks per k-step of each operand
     int krot;                                         // k-step rotation between neighbouring N tiles (0: every tile starts at k = 0)
+    int gm;                                           // M tiles per group of the tile order (see the tile map in the kernel)
     unsigned long long* trace;
 };
 
-constexpr int WR_CW = 4;                              // consumer waves, 1 x 4 along N
+constexpr int WR_CW = 4;
+// every lambda of the kernels below is force-inlined: at 256-row tiles their bodies are big enough for the inliner to leave them as
+// functions, and a by-reference capture of the accumulator array behind a real call puts the whole frame in scratch memory
+#define MIXQ_INL __attribute__((always_inline))                              // consumer waves, 1 x 4 along N
 
 template <int N> __device__ __forceinline__ void wr_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
@@ -75,12 +79,18 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int BM = MB * 16, WN = WNB * 16, BN = CW * WN;
     constexpr int STAGE_BYTES = MB * 1024;
     constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
-    constexpr int LOADS = MB / LOADERS;                  // DMA pieces per loader wave and stage
+    // SELF (LOADERS = 0, the prefill form): four FAT waves, one per SIMD with the whole 512-entry register file each (256 accumulator
+    // registers at MB x WNB = 16 x 4: a 256 x 256 tile), and no room for loader waves - a fifth wave would halve every wave's register
+    // budget - so each consumer wave issues its quarter of the activation DMA itself, between its MFMAs.
+    constexpr bool SELF = LOADERS == 0;
+    constexpr int ISSUERS = SELF ? CW : LOADERS;
+    constexpr int LOADS = MB / ISSUERS;                  // DMA pieces per issuing wave and stage
     constexpr int OPITCH = BN * 2 + 16;
-    constexpr int TQ = 2;                                // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS
+    constexpr int TQ = SELF ? 0 : 2;                     // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS
     constexpr int TAILX = NSTAGE * STAGE_BYTES;          // LDS offset of those blocks: behind the ring, [TQ][MB] x 1 KiB
-    static_assert(LOADERS >= 1 && MB % LOADERS == 0, "pieces must divide evenly over the loader waves");
+    static_assert(MB % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
+    static_assert(!SELF || (LOOK == D + 1 && !I4 && ABL == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
     static_assert((NSTAGE + TQ) * STAGE_BYTES <= 160 * 1024, "X ring + tail blocks must fit the 160 KiB of LDS");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -92,7 +102,18 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, x = b & 7, s = b >> 3;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;          // XCD-aware, bijective for any ntiles
     }
-    const int tn = tile / a.tiles_m, tm = tile - tn * a.tiles_m;               // m fastest: a weight panel stays on one XCD
+    // Tile order inside an XCD's contiguous run of tiles: groups of gm M tiles, M fastest inside a group, then N, then the next group.
+    // With gm = tiles_m (few M tiles, e.g. the 4 of a 512-token batch) that is "M fastest": the CUs of an XCD share a handful of
+    // weight panels and ALL of the activation.  At prefill sizes (32 M tiles of 128 rows at 4096 tokens) M-fastest makes the 32 CUs
+    // of an XCD stream 32 different activation slabs against ONE weight panel - 17 MB of L2 misses per 32 tiles; groups of 8 M tiles
+    // x 4 weight panels need 8 MB for the same work.
+    int tm, tn;
+    {
+        const int per_group = a.gm * a.tiles_n, grp = tile / per_group, first_m = grp * a.gm;
+        const int gsz = a.tiles_m - first_m < a.gm ? a.tiles_m - first_m : a.gm;
+        const int r = tile - grp * per_group;
+        tn = r / gsz; tm = first_m + (r - tn * gsz);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
@@ -101,7 +122,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // weight panel (same tn) start together - they share the panel's bytes in their XCD's L2 - while neighbouring panels start
     // krot k-steps apart, so the CUs of an XCD are not all asking the L2 for the same activation slab at the same moment.
     const int rot = nk > 1 ? (tn * a.krot) % nk : 0;
-    auto stamp = [&](int slot) {                         // diagnostics (mixq_gemm_set_trace): tools build only
+    auto stamp = [&](int slot) MIXQ_INL {                         // diagnostics (mixq_gemm_set_trace): tools build only
 #ifdef MIXQ_TUNING
         if (a.trace && tid == 0) {
             a.trace[blockIdx.x * 16 + slot] = wall_clock64();
@@ -116,6 +137,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // =================================================================================================================
     // loader wave(s): X stage kt+LOOK issued, stage kt+1 retired, then the k-step's barrier
     // =================================================================================================================
+    if constexpr (!SELF) {
     if (wave >= CW) {
         __builtin_amdgcn_s_setprio(2);
         const int lw = wave - CW;
@@ -131,7 +153,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         const size_t xks = static_cast<size_t>(a.xblocks) * 1024;
         int xk = rot;                                    // k-step the next stage reads
         size_t xoff = static_cast<size_t>(rot) * xks;
-        auto stage = [&](int slot) {
+        auto stage = [&](int slot) MIXQ_INL {
             if constexpr (ABL != 2 && ABL != 3) {
 #pragma unroll
                 for (int i = 0; i < LOADS; ++i) wr_glds16(src[i] + xoff, lds + slot * STAGE_BYTES + dsto[i]);
@@ -149,7 +171,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             for (int s = 0; s < RP; ++s) stage(s);
             wr_wait_vmcnt<LOADS * (RP - 1)>();
             __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
-            wr_static_for<0, LOOK - RP>([&](auto i_c) {
+            wr_static_for<0, LOOK - RP>([&](auto i_c) MIXQ_INL {
                 constexpr int i = decltype(i_c)::value;
                 stage((RP + 2 * i) % NSTAGE);
                 stage((RP + 2 * i + 1) % NSTAGE);
@@ -204,6 +226,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         __builtin_amdgcn_s_barrier();                                            // the epilogue's two barriers
         __builtin_amdgcn_s_barrier();
     }
+    }
 
     // =================================================================================================================
     // consumer waves
@@ -232,7 +255,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         const size_t wks = static_cast<size_t>(a.wblocks) * 1024;
         int wk = rot;                                    // k-step the next weight loads read
         size_t woff = static_cast<size_t>(rot) * wks;
-        auto wadvance = [&](int cond) {                    // once per requested k-step (cond: wave-uniform 0 / 1)
+        auto wadvance = [&](int cond) MIXQ_INL {                    // once per requested k-step (cond: wave-uniform 0 / 1)
             if (cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
         };
         const int lane16 = lane * 16;
@@ -262,7 +285,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // the statement: the compiler sees one straight-line definition per slot and k-step, never a branch around a load whose
         // merge it might resolve with a v_mov of a register the memory system has not written yet.  A slot's registers are only
         // meaningful after wwait() for that slot.
-        auto wload1 = [&](auto d_c, int i, int cond) {
+        auto wload1 = [&](auto d_c, int i, int cond) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
                 const int cs = __builtin_amdgcn_readfirstlane(cond);             // provably wave-uniform for the "s" constraint
@@ -273,7 +296,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                              : "+v"(dst) : "v"(l16), "s"(src), "s"(cs) : "memory", "scc");
             }
         };
-        auto wload1_always = [&](auto d_c, int i) {
+        auto wload1_always = [&](auto d_c, int i) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
                 const uint8_t* src = wb[i] + woff;
@@ -284,7 +307,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         };
         // wait until at most CNT loads issued after slot d's are outstanding (vmcnt retires in order); naming the slot's registers
         // as read-write operands makes every MFMA that uses them depend on this statement
-        auto wwait = [&](auto d_c, auto cnt_c) {
+        auto wwait = [&](auto d_c, auto cnt_c) MIXQ_INL {
             constexpr int d = decltype(d_c)::value, CNT = decltype(cnt_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
                 if constexpr (WNB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wq[d][0]) : "i"(CNT));
@@ -295,7 +318,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             }
         };
         // the same with a run-time count (tail of the k loop): CNT in {0, WNB, 2 WNB, ...}, selected inside ONE statement
-        auto wwait_rt = [&](auto d_c, int younger) {
+        auto wwait_rt = [&](auto d_c, int younger) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
             if constexpr (ABL != 1 && ABL != 3) {
                 const int sel = __builtin_amdgcn_readfirstlane(younger >= D - 1 ? D - 1 : younger);   // k-steps requested after this one, capped at the ring depth
@@ -325,28 +348,28 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        auto xread = [&](int slot, int j) {
+        auto xread = [&](int slot, int j) MIXQ_INL {
             if constexpr (ABL != 2 && ABL != 3)
                 xf[j] = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * 1024 + xoff);
         };
         uint32_t nib = 0xf0f0f0f0u;
         if constexpr (I4) asm volatile("s_mov_b32 %0, 0xf0f0f0f0" : "=s"(nib));
-        auto lo4 = [&](i32x4 v) { i32x4 o;
+        auto lo4 = [&](i32x4 v) MIXQ_INL { i32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = static_cast<int>((static_cast<uint32_t>(v[e]) << 4) & nib);
             return o; };
-        auto hi4 = [&](i32x4 v) { i32x4 o;
+        auto hi4 = [&](i32x4 v) MIXQ_INL { i32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = static_cast<int>(static_cast<uint32_t>(v[e]) & nib);
             return o; };
 
         // one k-step: MFMAs of ring slot C, X fragment j re-read from stage kt+1 right behind its last MFMA (REFILL), weight load
         // i of k-step kt+D issued into slot L = (C + D) % NSLOT behind MFMA group WPOS(i) (FULL: unconditionally)
-        auto step = [&](auto c_c, auto full_c, bool refill, int issue, int rslot) {
+        auto step = [&](auto c_c, auto full_c, bool refill, int issue, int rslot) MIXQ_INL {
             constexpr int C = decltype(c_c)::value, L = (C + D) % NSLOT;
             constexpr bool FULL = decltype(full_c)::value;
             using LC = std::integral_constant<int, L>;
-            auto loads_behind = [&](int j) {                                     // j: compile-time after unrolling
+            auto loads_behind = [&](int j) MIXQ_INL {                                     // j: compile-time after unrolling
 #pragma unroll
                 for (int i = 0; i < WNB; ++i) {
                     const int pos = (WNB >= MB) ? (i % MB) : ((2 * i + 1) * MB) / (2 * WNB);      // spread evenly over the MB groups
@@ -384,19 +407,100 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             wadvance(FULL ? 1 : issue);
         };
 
-        // ---- prologue ------------------------------------------------------------------------------------------------
         // the epilogue's scales first: the oldest loads of this wave, so they never sit between the hand-counted weight loads
+        // (the fat prefill form requests them after its k loop instead: 24 registers held across the loop would be spilled there)
+        auto load_scales = [&]() MIXQ_INL {
 #pragma unroll
-        for (int j = 0; j < MB; ++j) {
-            const int m = m0 + j * 16 + lm;
-            sxh[j] = a.sx[m < a.M ? m : a.M - 1];
-        }
+            for (int j = 0; j < MB; ++j) {
+                const int m = m0 + j * 16 + lm;
+                sxh[j] = a.sx[m < a.M ? m : a.M - 1];
+            }
 #pragma unroll
-        for (int i = 0; i < WNB; ++i) {
-            const int n = nw0 + i * 16 + lq * 4;                                 // N % 4 == 0: 4 columns are all in or all out
-            swp[i] = *reinterpret_cast<const u32x2_u*>(a.sw + (n < a.N ? n : a.N - 4));
-        }
-        auto prologue_w = [&](auto d_c) {
+            for (int i = 0; i < WNB; ++i) {
+                const int n = nw0 + i * 16 + lq * 4;                             // N % 4 == 0: 4 columns are all in or all out
+                swp[i] = *reinterpret_cast<const u32x2_u*>(a.sw + (n < a.N ? n : a.N - 4));
+            }
+        };
+        if constexpr (!SELF) load_scales();
+        if constexpr (SELF) {
+            // ---- self-loading k loop (prefill form) -------------------------------------------------------------------------
+            // Every k-step, in this program order: MB MFMA groups; behind group i*MB/LOADS this wave's piece i of X stage kt+LOOK
+            // (LDS-DMA), behind group ((2i+1) MB)/(2 WNB) weight load i of k-step kt+D; fragment j re-read from stage kt+1 behind its
+            // last MFMA.  LOOK = D + 1: stage kt+1 and the weights of k-step kt were requested in the SAME k-step kt-D, pieces first,
+            // so ONE counted wait - at most (D-1)(WNB+LOADS) younger requests in flight - retires both (vmcnt retires in order).
+            // Requests past the end of K wrap around to the first k-steps (valid addresses, L2-hot, never consumed): every k-step is
+            // the same straight-line code, nothing conditional sits between the hand-counted loads.
+            const uint8_t* xsrc[LOADS];
+            int xdst[LOADS];
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int p = wave + i * CW;
+                int rb = (m0 >> 4) + p; rb = rb < a.xblocks ? rb : a.xblocks - 1;
+                xsrc[i] = a.qx + static_cast<size_t>(rb) * 1024 + lane * 16;
+                xdst[i] = p * 1024;
+            }
+            const size_t xks = static_cast<size_t>(a.xblocks) * 1024;
+            int xkq = rot;
+            size_t xoff_g = static_cast<size_t>(rot) * xks;
+            auto xpiece = [&](int slot, int i) MIXQ_INL { wr_glds16(xsrc[i] + xoff_g, lds + slot * STAGE_BYTES + xdst[i]); };
+            auto xadvance = [&]() MIXQ_INL { xoff_g += xks; if (++xkq == nk) { xkq = 0; xoff_g = 0; } };
+            constexpr int INFLIGHT = (D - 1) * (WNB + LOADS);
+            // prologue = the k-steps -D .. -1 of the steady state, preceded by stage 0
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) xpiece(0, i);
+            xadvance();
+            wr_static_for<0, D>([&](auto d_c) MIXQ_INL {
+                constexpr int d = decltype(d_c)::value;
+#pragma unroll
+                for (int i = 0; i < LOADS; ++i) xpiece((d + 1) % NSTAGE, i);
+                xadvance();
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) wload1_always(d_c, i);
+                wadvance(1);
+            });
+            wr_wait_vmcnt<INFLIGHT>();                                           // own pieces of stages 0 and 1, weights of k-step 0
+            __builtin_amdgcn_s_barrier();                                        // B0: everybody's pieces of stage 0 (and 1) landed
+            stamp(1);
+#pragma unroll
+            for (int j = 0; j < MB; ++j) xread(0, j);
+            int kt = 0, slot1 = 1 % NSTAGE, nxt = LOOK % NSTAGE;                 // ring slots of stage kt+1 and stage kt+LOOK
+            auto one = [&](auto c_c) MIXQ_INL {
+                constexpr int C = decltype(c_c)::value, L = (C + D) % NSLOT;
+                using LC = std::integral_constant<int, L>;
+                wwait(c_c, std::integral_constant<int, INFLIGHT>{});             // weights of k-step kt and own pieces of stage kt+1 landed
+                __builtin_amdgcn_s_barrier();                                    // everybody's: stage kt+1 readable, stage kt-2's slot free
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][i], xf[j], acc[j][i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    xread(slot1, j);
+#pragma unroll
+                    for (int i = 0; i < LOADS; ++i)
+                        if ((i * MB) / LOADS == j) xpiece(nxt, i);
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i)
+                        if (((2 * i + 1) * MB) / (2 * WNB) == j) wload1_always(LC{}, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wadvance(1);
+                xadvance();
+                slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
+                nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+                ++kt;
+            };
+            while (kt + NSLOT <= nk) wr_static_for<0, NSLOT>([&](auto c_c) MIXQ_INL { one(c_c); });
+            {
+                const int k0 = kt;                                               // (a group is entered at ring slot 0)
+                wr_static_for<0, NSLOT>([&](auto c_c) MIXQ_INL { if (k0 + decltype(c_c)::value < nk) one(c_c); });
+            }
+            wr_wait_vmcnt<0>();                                                  // the wrapped-around requests of the last k-steps: nothing may
+            load_scales();                                                       // land in a register the epilogue re-uses
+            stamp(2);
+        } else {
+        // ---- prologue ------------------------------------------------------------------------------------------------
+        auto prologue_w = [&](auto d_c) MIXQ_INL {
 #pragma unroll
             for (int i = 0; i < WNB; ++i) wload1(d_c, i, decltype(d_c)::value < nk ? 1 : 0);
             wadvance(decltype(d_c)::value < nk ? 1 : 0);
@@ -413,7 +517,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 
         // ---- k loop: unrolled by NSLOT so ring slots are compile-time registers ----------------------------------------
         int kt = 0, slot1 = 1 % NSTAGE;                                          // ring slot of stage kt+1
-        auto one = [&](auto c_c, auto full_c) {
+        auto one = [&](auto c_c, auto full_c) MIXQ_INL {
             constexpr bool FULL = decltype(full_c)::value;                       // FULL: stage kt+1 and k-step kt+D exist
             if constexpr (FULL) {
                 if constexpr (ABL != 4) wwait(c_c, std::integral_constant<int, WNB * (D - 1)>{});   // the D-1 younger k-steps stay in flight
@@ -428,15 +532,16 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
             ++kt;
         };
-        auto group = [&](auto full_c) { wr_static_for<0, NSLOT>([&](auto c_c) { one(c_c, full_c); }); };
+        auto group = [&](auto full_c) MIXQ_INL { wr_static_for<0, NSLOT>([&](auto c_c) MIXQ_INL { one(c_c, full_c); }); };
         while (kt + NSLOT + D <= nk) group(std::true_type{});                    // every k-step of the group has kt + D < nk
         while (kt < nk) {                                                        // fewer than NSLOT + D k-steps, guarded individually
             // (a group is entered at ring slot 0, so slot c holds k-step kt + c here as well)
             const int k0 = kt;
-            auto tail_one = [&](auto c_c) { if (k0 + decltype(c_c)::value < nk) one(c_c, std::false_type{}); };
+            auto tail_one = [&](auto c_c) MIXQ_INL { if (k0 + decltype(c_c)::value < nk) one(c_c, std::false_type{}); };
             wr_static_for<0, NSLOT>(tail_one);
         }
         stamp(2);
+        }
     }
 
     // =================================================================================================================
@@ -452,16 +557,16 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         constexpr float PRE = I4 ? (1.f / 256.f) : 1.f;
         const bool has_add = a.addend != nullptr, has_bias = a.bias != nullptr, do_silu = a.act != MIXQ_ACT_NONE;
         const bool mul_add = a.act == MIXQ_ACT_SILU_MUL;
-        auto unpack4 = [](u32x2 v, float* o) {
+        auto unpack4 = [](u32x2 v, float* o) MIXQ_INL {
             o[0] = h2f(static_cast<uint16_t>(v.x & 0xffffu)); o[1] = h2f(static_cast<uint16_t>(v.x >> 16));
             o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
         };
 
         // fp16 outlier tail operands: 16 x 32 fragments, lane = row lm, columns kk*32 + lq*8 .. +8.  TD register sets: with two,
         // the operands of tail k-step kk+1 are in flight behind the MFMAs of kk; the fattest tiles only have room for one.
-        constexpr int TD = (MB * WNB * 4 + 2 * (MB + WNB) * 4 + 40 > 256) ? 1 : 2;
+        constexpr int TD = (SELF || MB * WNB * 4 + 2 * (MB + WNB) * 4 + 40 > 256) ? 1 : 2;
         u32x4 xoq[TD][MB], woq[TD][WNB];
-        auto tail_load_w = [&](int P, int kk) {            // P: constant after unrolling
+        auto tail_load_w = [&](int P, int kk) MIXQ_INL {            // P: constant after unrolling
             const int kb = kk * 32 + lq * 8;
             const bool in = kb < kpad;                     // chunks past the padded width are not addressable: zeros
 #pragma unroll
@@ -470,7 +575,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 woq[P][i] = in ? *reinterpret_cast<const u32x4*>(a.wo + static_cast<size_t>(wr) * a.ldwo + kb) : u32x4{0, 0, 0, 0};
             }
         };
-        auto tail_load_x = [&](int P, int kk) {            // k-steps < TQ: from the blocks the loader staged in LDS (valid after barrier 1)
+        auto tail_load_x = [&](int P, int kk) MIXQ_INL {            // k-steps < TQ: from the blocks the loader staged in LDS (valid after barrier 1)
             const int kb = kk * 32 + lq * 8;
             const bool in = kb < kpad;
 #pragma unroll
@@ -483,7 +588,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 }
             }
         };
-        auto tail_load = [&](int P, int kk) { tail_load_w(P, kk); tail_load_x(P, kk); };
+        auto tail_load = [&](int P, int kk) MIXQ_INL { tail_load_w(P, kk); tail_load_x(P, kk); };
         // both register sets are requested BEFORE the barrier and the dequantisation (the weight ring and the X fragments are dead:
         // their registers hold the tail operands), so the tail's first two k-steps - all of it up to 64 outlier columns - expose
         // no memory round trip of their own
@@ -491,12 +596,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // saying so through the builtin the compiler's counter model understands keeps it from draining the tail loads issued next
         // with a vmcnt(0) in front of the dequantisation, whose scale operands it would otherwise believe to be still in flight)
         __builtin_amdgcn_s_waitcnt(0x0F70);                                      // vmcnt(0)
-        if (TD > 1 && ksteps > 0) tail_load_w(0, 0);
-        if (TD > 1 && ksteps > 1) tail_load_w(1, 1);
+        if (ksteps > 0) tail_load_w(0, 0);
+        if (TD > 1 && ksteps > 1) tail_load_w(TD - 1, 1);
         __builtin_amdgcn_s_barrier();                                            // every wave is done reading the ring; X_out blocks landed
         stamp(6);
-        if (TD > 1 && ksteps > 0) tail_load_x(0, 0);
-        if (TD > 1 && ksteps > 1) tail_load_x(1, 1);
+        if (ksteps > 0) tail_load_x(0, 0);
+        if (TD > 1 && ksteps > 1) tail_load_x(TD - 1, 1);
 
         // Dequantisation and the first tail k-steps as ONE block-wise pipeline: block b+1 is dequantised (12 VALU) between the
         // tail MFMAs of block b, so the fp16 MFMAs of the first two tail k-steps (all of the tail up to 64 outlier columns) run under
@@ -508,11 +613,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         for (int i = 0; i < WNB; ++i) unpack4(swp[i], swv[i]);
 #pragma unroll
         for (int j = 0; j < MB; ++j) sxv[j] = h2f(sxh[j]) * PRE;
-        auto dequant_block = [&](int j, int i) {
+        auto dequant_block = [&](int j, int i) MIXQ_INL {
 #pragma unroll
             for (int r = 0; r < 4; ++r) fa[j][i][r] = static_cast<float>(acc[j][i][r]) * sxv[j] * swv[i][r];
         };
-        auto tail_mask = [&](int P, int kk) {                                    // columns >= n_out of a k-step (the pad may hold anything)
+        auto tail_mask = [&](int P, int kk) MIXQ_INL {                                    // columns >= n_out of a k-step (the pad may hold anything)
             const int kb = kk * 32 + lq * 8;
             if (kb + 8 > n_out) {
 #pragma unroll
@@ -527,59 +632,42 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 }
             }
         };
-        auto tail_mfma1 = [&](int P, int j, int i) {
+        auto tail_mfma1 = [&](int P, int j, int i) MIXQ_INL {
             fa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, woq[P][i]), __builtin_bit_cast(f16x8, xoq[P][j]),
                                                               fa[j][i], 0, 0, 0);
         };
-        auto tail_mma = [&](int P, int kk) {
-            tail_mask(P, kk);
+        // PANELS: the fat prefill tile (SELF) holds 256 accumulator registers per lane; dequantised all at once they would need a
+        // second 256 - in VGPRs, since the VALU cannot write AGPRs - next to the tail operands (165 spilled registers, and wrong
+        // results under load).  So its epilogue runs one 16-channel column of blocks (PW = 1 of the WNB) at a time: read from the
+        // accumulator file, dequantise, tail, optional terms, fp16, staged - then the next.  Every other tiling is ONE panel.
+        constexpr int PW = SELF ? 1 : WNB, NP = WNB / PW;
+        auto tail_mma = [&](int P, int kk, auto p_c) MIXQ_INL {
+            constexpr int p = decltype(p_c)::value;
+            tail_mask(P, kk);                                                    // (idempotent: a set shared by several panels is masked again)
 #pragma unroll
             for (int j = 0; j < MB; ++j)
 #pragma unroll
-                for (int i = 0; i < WNB; ++i) tail_mfma1(P, j, i);
+                for (int i = p * PW; i < (p + 1) * PW; ++i) tail_mfma1(P, j, i);
         };
         // K0 / K1: tail k-step 0 from register set 0 / k-step 1 from set 1 ride along (compile-time: straight-line code)
-        auto dequant_with_tail = [&](auto k0_c, auto k1_c) {
+        auto dequant_with_tail = [&](auto k0_c, auto k1_c, auto p_c) MIXQ_INL {
             constexpr bool K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value;
-            constexpr int NB = MB * WNB;
-            dequant_block(0, 0);
+            constexpr int p = decltype(p_c)::value, NB = MB * PW;
+            dequant_block(0, p * PW);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int j = b / WNB, i = b % WNB;
-                if (b + 1 < NB) dequant_block((b + 1) / WNB, (b + 1) % WNB);
+                const int j = b / PW, i = p * PW + b % PW;
+                if (b + 1 < NB) dequant_block((b + 1) / PW, p * PW + (b + 1) % PW);
                 if constexpr (K0) tail_mfma1(0, j, i);
                 if constexpr (K1) tail_mfma1(TD - 1, j, i);
                 // (block order is left to the scheduler)
             }
         };
-        if constexpr (TD == 1) {
-            dequant_with_tail(std::false_type{}, std::false_type{});
-            for (int kk = 0; kk < ksteps; ++kk) { tail_load(0, kk); tail_mma(0, kk); }
-        } else {
-            // ONE straight-line form for every outlier count: a register set whose k-step does not exist was never loaded (it
-            // holds old weight-ring bytes) and tail_mask clears all of it (kb >= n_out), so its MFMAs add zeros - under VALU work
-            // that is there anyway.  (Branching between "with" and "without" forms of this phase cost 92-300 spilled registers.)
-            tail_mask(0, 0);
-            tail_mask(1, 1);
-            dequant_with_tail(std::true_type{}, std::true_type{});
-            if (ksteps > 2) {                                                    // > 64 outlier columns: the two sets again, one pair ahead
-                tail_load(0, 2);
-                if (ksteps > 3) tail_load(TD - 1, 3);
-                for (int kk0 = 2; kk0 < ksteps; kk0 += 2) {
-                    tail_mma(0, kk0);
-                    if (kk0 + 2 < ksteps) tail_load(0, kk0 + 2);
-                    if (kk0 + 1 < ksteps) {
-                        tail_mma(TD - 1, kk0 + 1);
-                        if (kk0 + 3 < ksteps) tail_load(TD - 1, kk0 + 3);
-                    }
-                }
-            }
-        }
-
-        auto finish_tile = [&](auto staged_c, auto opt_c) {
+        auto finish_tile = [&](auto staged_c, auto opt_c, auto p_c) MIXQ_INL {
             constexpr bool ST = decltype(staged_c)::value, OPT = decltype(opt_c)::value;
+            constexpr int p = decltype(p_c)::value;
 #pragma unroll
-            for (int i = 0; i < WNB; ++i) {
+            for (int i = p * PW; i < (p + 1) * PW; ++i) {
                 const int nloc = wave * WN + i * 16 + lq * 4, n = n0 + nloc;
                 const int nc = n < a.N ? n : a.N - 4;
                 float bv[4];
@@ -620,8 +708,38 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             }
         };
         const bool opt = has_add || has_bias || do_silu;
-        if (staged) { if (opt) finish_tile(std::true_type{}, std::true_type{}); else finish_tile(std::true_type{}, std::false_type{}); }
-        else        { if (opt) finish_tile(std::false_type{}, std::true_type{}); else finish_tile(std::false_type{}, std::false_type{}); }
+        wr_static_for<0, NP>([&](auto p_c) MIXQ_INL {
+            constexpr int p = decltype(p_c)::value;
+            if constexpr (TD == 1) {
+                // one register set: tail k-step 0 (requested before the barrier) rides along with the dequantisation, the rest follow
+                tail_mask(0, 0);
+                dequant_with_tail(std::true_type{}, std::false_type{}, p_c);
+                for (int kk = 1; kk < ksteps; ++kk) { tail_load(0, kk); tail_mma(0, kk, p_c); }
+                if constexpr (p + 1 < NP) { if (ksteps > 1) tail_load(0, 0); }     // the next panel starts from k-step 0 again
+            } else {
+                // ONE straight-line form for every outlier count: a register set whose k-step does not exist was never loaded (it
+                // holds old weight-ring bytes) and tail_mask clears all of it (kb >= n_out), so its MFMAs add zeros - under VALU work
+                // that is there anyway.  (Branching between "with" and "without" forms of this phase cost 92-300 spilled registers.)
+                tail_mask(0, 0);
+                tail_mask(1, 1);
+                dequant_with_tail(std::true_type{}, std::true_type{}, p_c);
+                if (ksteps > 2) {                                                // > 64 outlier columns: the two sets again, one pair ahead
+                    tail_load(0, 2);
+                    if (ksteps > 3) tail_load(TD - 1, 3);
+                    for (int kk0 = 2; kk0 < ksteps; kk0 += 2) {
+                        tail_mma(0, kk0, p_c);
+                        if (kk0 + 2 < ksteps) tail_load(0, kk0 + 2);
+                        if (kk0 + 1 < ksteps) {
+                            tail_mma(TD - 1, kk0 + 1, p_c);
+                            if (kk0 + 3 < ksteps) tail_load(TD - 1, kk0 + 3);
+                        }
+                    }
+                    if constexpr (p + 1 < NP) { tail_load(0, 0); tail_load(TD - 1, 1); }   // the next panel starts from k-steps 0 and 1 again
+                }
+            }
+            if (staged) { if (opt) finish_tile(std::true_type{}, std::true_type{}, p_c); else finish_tile(std::true_type{}, std::false_type{}, p_c); }
+            else        { if (opt) finish_tile(std::false_type{}, std::true_type{}, p_c); else finish_tile(std::false_type{}, std::false_type{}, p_c); }
+        });
         stamp(7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // ds_write is asynchronous; s_barrier does not wait for it
         __builtin_amdgcn_s_barrier();                                            // staging tile complete
@@ -701,6 +819,13 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// cfg 0 with ordinary (not nt) stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 9, "128x192_abl9_empty"),  // returns at entry: the launch floor of this grid and LDS footprint
     MIXQ_WR(8, 3, 16, 4, 2, 12, "128x192_abl12_noramp"),// cfg 0 with all LOOK stages requested at once (the form before the ramp)
+    // EXPERIMENT (round 3, kept for the record, not shipped): the vendor library's prefill shape - 256 x 256 tiles, four fat
+    // self-loading waves with 256 accumulator registers each (SELF form of the kernel), (16 + 16) KB of operands per k-step for
+    // 4 x 64 MFMAs, half the L1 / L2 bytes per MFMA of 128 x 256.  Measured at 4096 x 11008 x 4096 without outlier columns: 186.1 us
+    // against 191.3 us for 128 x 256 (profiles/r03_prefill_ab.txt) - the loop is not feed-bound there, the part is at its 1.4 kW
+    // power cap either way - and its one-register-set tail costs 33 us with 41 outlier columns.  Known fault: memory access
+    // violation at M = 8192 and with > 64 outlier columns.  int8 only.
+    { "wr256x256_s6_d3_self", 16, 4, 6, 0, gemm_wreg_kernel<16, 4, 6, 3, false, 0, 0>, nullptr },
 #endif
 };
 constexpr int WR_SMALL = 14;
@@ -764,10 +889,16 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     const int bm = g.mb * 16, bn = g.wnb * 64;
     a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, bn);
     a.xblocks = (M + 15) >> 4; a.wblocks = (N + 15) >> 4;
-    a.krot = g_wr_krot;
+    a.krot = g_wr_krot & 0xffff;
+    {
+        const int forced_gm = g_wr_krot >> 16;                               // (tuning build: mixq_gemm_set_krot(gm << 16 | krot); 0 = automatic)
+        a.gm = forced_gm > 0 ? forced_gm : (a.tiles_m <= 8 ? a.tiles_m : 8);
+        if (a.gm > a.tiles_m) a.gm = a.tiles_m;
+    }
     a.trace = trace;
     void (*k)(const WrArgs) = bit == 8 ? g.k8 : g.k4;
-    const size_t ring = static_cast<size_t>(g.nstage + 2) * g.mb * 1024, stg = static_cast<size_t>(bm) * (bn * 2 + 16);   // ring + the tail's X_out blocks
+    if (!k) return MIXQ_EINVAL;                                                  // (the prefill tiles have no nibble form)
+    const size_t ring = static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = static_cast<size_t>(bm) * (bn * 2 + 16);   // ring + the tail's X_out blocks
     const size_t shm = ring > stg ? ring : stg;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3((WR_CW + g.loaders) * 64), shm, st, a);

@@ -263,6 +263,9 @@ class MixLinear_GEMM(nn.Module):
         columns after compaction).  A fresh tensor every time: writes to it do not reach the layer - load_state_dict does."""
         if self.weight_only:
             raise RuntimeError("weight-only layers keep their plain q_weight")
+        if not self._wpk.is_cuda:
+            # the module was moved to the host (model.cpu() before saving): the re-tiling is pure index arithmetic, done in torch
+            return _unpack_host(self._wpk, self.out_features, _fmt_of(self._wpk))
         return _backend.UnpackOperand(self._wpk, self.out_features)
 
     def compact_weights_(self):
@@ -278,12 +281,25 @@ class MixLinear_GEMM(nn.Module):
         if "q_weight" in self._buffers and self._buffers["q_weight"] is None and self._wpk is not None:
             destination[prefix + "q_weight"] = self._plain_weight()      # the reference's on-disk layout (base.py:78-119)
 
-    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        if "q_weight" in self._buffers and self._buffers["q_weight"] is None and prefix + "q_weight" in state_dict:
-            src = state_dict[prefix + "q_weight"]
-            self._buffers["q_weight"] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self._wpk.device)
-            self._wpk, self._wpk_key = None, None                        # re-packed on the next forward
-        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        compacted = "q_weight" in self._buffers and self._buffers["q_weight"] is None and self._wpk is not None
+        if compacted:
+            key = prefix + "q_weight"
+            if key not in state_dict:
+                missing_keys.append(key)                                 # nn.Module skips None buffers: report it ourselves
+            else:
+                src = state_dict[key]
+                KB = self.in_features if self.bit == 8 else self.in_features // 2
+                want_dtype = torch.int8 if self.bit == 8 else torch.uint8
+                if tuple(src.shape) != (self.out_features, KB) or src.dtype != want_dtype:
+                    # keep the packed image: a mismatching tensor must not leave the layer with uninitialised weights
+                    error_msgs.append(f"size mismatch for {key}: copying a param with shape {tuple(src.shape)} ({src.dtype}) from checkpoint, "
+                                      f"the shape in current model is {(self.out_features, KB)} ({want_dtype}).")
+                    state_dict = {k: v for k, v in state_dict.items() if k != key}
+                else:
+                    self._buffers["q_weight"] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self._wpk.device)
+                    self._wpk, self._wpk_key = None, None                # re-packed on the next forward
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def _apply(self, fn, *args, **kwargs):
         """nn.Module.to / .cuda / .half walk parameters and buffers only; after compaction the weights live in `_wpk` (a plain
@@ -541,6 +557,20 @@ class MixLinear_GEMM(nn.Module):
         if COMPACT_WEIGHTS and self._silu_calls >= self.cache.stop:
             self.compact_weights_()
         return y1.reshape(cache.shape)
+
+
+def _unpack_host(packed, R, fmt):
+    """Plain [R,KB] matrix of a packed image held in HOST memory (include/mixq_hip.h: P16X64 / F16X64 block layouts)."""
+    rows16, KB = packed.shape
+    blocks = packed.reshape(KB // 64, rows16 // 16, 1024)
+    if fmt == FMT_F16X64:                                                # byte c*256 + r*16 + b
+        t = blocks.reshape(KB // 64, rows16 // 16, 4, 16, 16).permute(1, 3, 0, 2, 4)          # [rb, r, kb, c, b]
+    else:                                                                # P16X64: row r stores chunk c at position c ^ (-(r>>2) & 3)
+        t = blocks.reshape(KB // 64, rows16 // 16, 16, 4, 16)
+        r = torch.arange(16)
+        pos = torch.arange(4).unsqueeze(0) ^ ((0 - (r >> 2)) & 3).unsqueeze(1)                # [r, c] -> physical chunk
+        t = torch.gather(t, 3, pos.reshape(1, 1, 16, 4, 1).expand(KB // 64, rows16 // 16, 16, 4, 16)).permute(1, 2, 0, 3, 4)
+    return t.reshape(rows16, KB)[:R].contiguous()
 
 
 def _wide(t, cap):

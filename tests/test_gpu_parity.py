@@ -991,7 +991,7 @@ def test_silu_mul_needs_its_multiplier():
 # round 2: the holes VERDICT r01 listed
 # ---------------------------------------------------------------------------------------------------------------
 def _wr_configs():
-    return [i for i, name in enumerate(_capi.gemm_config_names()) if name.startswith("wr") and "abl" not in name]
+    return [i for i, name in enumerate(_capi.gemm_config_names()) if name.startswith("wr") and "abl" not in name and "self" not in name]
 
 
 def _tiled_configs():
@@ -1291,6 +1291,8 @@ def test_every_wreg_tiling_full_epilogue_and_int4():
             lib.mixq_gemm_set_config(names.index("128x128_w2x2_s5_l2"))
             y_lds = n(_run_fused(c, 1))
             for cfg in _wr_configs():
+                if bit == 4 and "self" in names[cfg]:
+                    continue                                # the prefill tiles (four fat self-loading waves) have no nibble form
                 assert lib.mixq_gemm_set_config(cfg) == 0
                 y = n(_run_fused(c, 2))
                 assert np.isfinite(y).all(), (names[cfg], M, N, K)
@@ -1605,6 +1607,8 @@ def test_wreg_every_k_step_count_every_tiling():
                 assert lib.mixq_gemm_set_config(cfg) == 0
                 y = n(mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K))
                 assert np.array_equal(bits(y), bits(want16)), (names[cfg], nk, "int8")
+                if "self" in names[cfg]:
+                    continue                                # (no nibble form of the prefill tiles)
                 y4 = n(_i4_call(qxp, qwp, sx4, sw4, M, N, K))
                 assert np.array_equal(bits(y4), bits(want4)), (names[cfg], nk, "int4")
     finally:

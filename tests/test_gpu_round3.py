@@ -77,7 +77,8 @@ def test_one_call_forward_is_bit_identical(M, K, N, bit, ncols, bias):
         torch.cuda.synchronize()
         if one:
             assert layer._plan is not None, "the frozen layer did not take the one-call route"
-        got = (n(y).copy(), n(cache.x_scale[:M]).copy(), n(cache.q_xcache).copy(), n(xd).copy(),
+        qplain = cache.q_xcache if mixlib.fmt_of(cache.q_xcache) == 0 else mixlib.UnpackOperand(cache.q_xcache, M)   # (pad rows of a packed image are never written)
+        got = (n(y).copy(), n(cache.x_scale[:M]).copy(), n(qplain).copy(), n(xd).copy(),
                None if cache.activation_outliers is None else n(cache.activation_outliers).copy(), mixlib.fmt_of(cache.q_xcache))
         if not res:
             res = got
@@ -176,3 +177,28 @@ def test_bench_other_configs_run(extra, K, N, bit):
     assert out["value"] == pytest.approx(2.0 * 512 * K * N / (out["ms_per_step"] * 1e-3) / 1e12, rel=1e-3)
     assert out["max_abs_err_vs_dequant_linear"] <= (1e-2 if bit == 8 else 4e-2)       # (W4: |y| reaches 30 at 128 fp16 columns: 1 ulp = 1.6e-2)
     assert f"W{bit}A{bit}O16" in out["metric"] and out["roofline"]["frac"] > 0.1
+
+
+def test_compacted_layer_state_dict_edge_cases():
+    """ADVICE r02 (linear.py compacted weights): a strict load without q_weight reports the missing key; a q_weight of the wrong
+    shape is an error that leaves the packed weights in place; state_dict() works after the module moved to the host."""
+    layer, cache, cols = frozen_layer(32, 512, 384, 8, 3, True)
+    assert layer._buffers["q_weight"] is None and layer._wpk is not None
+    x = torch.randn(32, 512, generator=torch.Generator().manual_seed(9)).half()
+    x[:, cols] *= 20
+    y0 = layer(x.to(DEV), None, True)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    with pytest.raises(RuntimeError, match="Missing key"):
+        layer.load_state_dict({k: v for k, v in sd.items() if k != "q_weight"})
+    bad = dict(sd)
+    bad["q_weight"] = sd["q_weight"][:, :256].contiguous()
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        layer.load_state_dict(bad)
+    assert layer._wpk is not None and torch.equal(layer(x.to(DEV), None, True), y0)
+    layer.cpu()
+    host_sd = layer.state_dict()
+    assert not host_sd["q_weight"].is_cuda and torch.equal(host_sd["q_weight"], sd["q_weight"].cpu())
+    layer.to(DEV)
+    cache2 = MixLibCache(32, device=DEV)
+    layer.cache = cache2
+    assert torch.equal(layer(x.to(DEV), cache2, True), y0)

@@ -146,3 +146,17 @@ def test_row_quantisation_invariants(rows, K, bit, seed):
     assert (err <= 0.5 * sf[nz, None] * 1.01 + 1e-6).all()
     # the element of largest magnitude maps to +-qmax
     assert (np.abs(qi[nz]).max(axis=1) == qmax).all()
+
+
+def test_host_unpack_inverts_both_packed_layouts():
+    """mixq_amd.linear._unpack_host (state_dict of a compacted layer that was moved to the CPU: ADVICE r02) against the reference
+    index maps of this file, both formats, ragged row counts."""
+    import torch
+    from mixq_amd.linear import _unpack_host
+    rng = np.random.default_rng(3)
+    for R, KB in [(16, 64), (37, 128), (100, 256)]:
+        q = rng.integers(-128, 128, size=(R, KB), dtype=np.int8)
+        for fmt in (1, 2):
+            img = packed_reference(q, fmt)
+            back = _unpack_host(torch.from_numpy(img.reshape(-1, KB)), R, fmt).numpy()
+            assert np.array_equal(back.view(np.int8), q), (R, KB, fmt)

@@ -18,6 +18,7 @@ ap.add_argument("--rounds", type=int, default=30)
 ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--nout", type=int, default=41)
 ap.add_argument("--bit", type=int, default=8)
+ap.add_argument("--gms", default="0", help="comma list of M-tile group sizes of the weights-in-registers kernels' tile order (0 = automatic)")
 args = ap.parse_args()
 dev = "cuda"
 lib = _capi.load()
@@ -42,10 +43,13 @@ out = torch.empty((M, N), dtype=torch.float16, device=dev)
 side = torch.cuda.Stream()
 graphs = []
 with torch.cuda.stream(side):
-    for nm in args.cfgs.split(","):
+    for nm, gm in [(nm, int(g)) for nm in args.cfgs.split(",") for g in args.gms.split(",")]:
         c = names.index(nm)
         w = wp[2 if nm.startswith("wr") else 1]
         assert lib.mixq_gemm_set_config(c) == 0
+        assert lib.mixq_gemm_set_krot(gm << 16) == 0
+        if gm:
+            nm = f"{nm}_gm{gm}"
         run = lambda: mixlib.FusedLinear(xp, w, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
         for _ in range(3):
             run()
@@ -57,6 +61,7 @@ with torch.cuda.stream(side):
         torch.cuda.synchronize()
         graphs.append((nm, gr))
     lib.mixq_gemm_set_config(-1)
+    lib.mixq_gemm_set_krot(0)
     times = {nm: [] for nm, _ in graphs}
     for r in range(args.rounds + 2):
         for nm, gr in graphs:
