@@ -153,6 +153,27 @@ int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x
                        const uint16_t* addend, int lda, const uint16_t* bias,
                        uint16_t* y, int ldy, int M, int N, int K, int act, int layout, mixq_stream_t stream);
 
+/* ---- the next layer's row maximum as a side output of the producing GEMM ------------------------------------------------
+ * down_proj's pre-pass (linear.py:187-193) needs max_k |x[m,k]| over the columns it does not extract - a full pass over the
+ * [M, 11008] activation that gate_proj's GEMM has just written (mixquant/modules/fused/mlp.py:57-70).  mixq_gemm_i8_fused_amax is
+ * mixq_gemm_i8_fused that ALSO maximises, per output row m, the fp16 bit patterns |y[m,n]| over the columns n whose bit in col_mask
+ * (bit n of a uint32 array, NULL = no column excluded) is clear, into row_amax[m] with integer atomic max: order-independent, so the
+ * value is exactly the maximum the quantiser would have found.  row_amax must be zero when the GEMM starts.
+ * mixq_quant_known_amax is mixq_quant_fused for rows whose maximum is known: one pass, no reduction; it reads row_amax[m], CLEARS it
+ * (ready for the producer's next run), and writes exactly the bytes mixq_quant_fused writes.  col_mask must mark the columns `ind`.
+ * mixq_gemm_amax_supported: 1 when the side output is available for (M, N, K, layout) - int8, MIXQ_X_PACKED | MIXQ_W_F16X64, the
+ * batches the weights-in-registers kernels serve - else 0 (mixq_gemm_i8_fused_amax then returns MIXQ_ESHAPE). */
+int mixq_gemm_i8_fused_amax(const int8_t* q_x, const int8_t* q_w, const uint16_t* x_scale,
+                            const uint16_t* scale_col, const uint16_t* x_out, int ldxo,
+                            const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
+                            const uint16_t* addend, int lda, const uint16_t* bias,
+                            uint16_t* y, int ldy, int M, int N, int K, int act, int layout,
+                            uint32_t* row_amax, const uint32_t* col_mask, mixq_stream_t stream);
+int mixq_gemm_amax_supported(int M, int N, int K, int layout);
+int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint32_t* row_amax,
+                          const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
+                          int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
+
 /* ---- the whole forward of a frozen layer in ONE call ---------------------------------------------------------
  * mixq_linear_forward = mixq_quant_fused followed by mixq_gemm_i8_fused / mixq_gemm_i4_fused, both launched from C on `stream`:
  * the steady state of MixLinear_GEMM.forward(x, cache, unfused=True) once outlier prediction has frozen
@@ -163,7 +184,8 @@ int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x
  * two-call sequence.  Field meanings are those of the two entry points above:
  *   x [M,K] fp16 ldx (outlier columns zeroed in place), ind / n_cap / n_dev, x_scale [M] (written), q_x (written, format qfmt),
  *   x_out [M,ldxo] (written; NULL when n_cap = 0), flag (optional), q_w in format wfmt (MIXQ_FMT_*), scale_col [N],
- *   w_out [N,ldwo], addend / lda, bias, y [M,ldy], act (MIXQ_ACT_*).  qfmt must be what the GEMM takes for wfmt:
+ *   w_out [N,ldwo], addend / lda, bias, y [M,ldy], act (MIXQ_ACT_*), row_amax / col_mask (optional: a producer left the row maxima,
+ *   see mixq_gemm_i8_fused_amax - the quantise pass is then mixq_quant_known_amax).  qfmt must be what the GEMM takes for wfmt:
  *   PLAIN / P16X64 with wfmt PLAIN / P16X64 in any combination, P16X64 with wfmt F16X64. */
 typedef struct mixq_linear_args {
     uint16_t* x; int ldx;
@@ -173,6 +195,7 @@ typedef struct mixq_linear_args {
     const uint16_t* addend; int lda; const uint16_t* bias;
     uint16_t* y; int ldy;
     int M, N, K, bit; float sigma; int act, qfmt, wfmt;
+    uint32_t* row_amax; const uint32_t* col_mask;   /* row_amax non-NULL: the rows' maxima are known (mixq_quant_known_amax runs instead) */
 } mixq_linear_args;
 int mixq_linear_forward(const mixq_linear_args* args, mixq_stream_t stream);
 

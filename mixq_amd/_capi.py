@@ -83,6 +83,9 @@ SIGNATURES = {
     "mixq_gemm_workspace_bytes": [],
     "mixq_gemm_set_workspace": [_P, C.c_longlong],
     "mixq_linear_forward": [_P, _P],
+    "mixq_gemm_i8_fused_amax": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "mixq_gemm_amax_supported": [_I, _I, _I, _I],
+    "mixq_quant_known_amax": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
 }
 RESTYPES = {"mixq_gemm_workspace_bytes": C.c_longlong}
 
@@ -95,7 +98,8 @@ class LinearArgs(C.Structure):
                 ("q_w", _P), ("scale_col", _P), ("w_out", _P), ("ldwo", _I),
                 ("addend", _P), ("lda", _I), ("bias", _P),
                 ("y", _P), ("ldy", _I),
-                ("M", _I), ("N", _I), ("K", _I), ("bit", _I), ("sigma", _F), ("act", _I), ("qfmt", _I), ("wfmt", _I)]
+                ("M", _I), ("N", _I), ("K", _I), ("bit", _I), ("sigma", _F), ("act", _I), ("qfmt", _I), ("wfmt", _I),
+                ("row_amax", _P), ("col_mask", _P)]
 
 _lib = None
 

@@ -21,8 +21,11 @@ extern "C" int mixq_linear_forward(const mixq_linear_args* a, mixq_stream_t stre
     if (a->wfmt == MIXQ_FMT_F16X64 && a->qfmt != MIXQ_FMT_P16X64) return MIXQ_EINVAL;
     const bool outl = a->n_cap > 0 && a->x_out && a->w_out;
     if (a->n_cap > 0 && !outl) return MIXQ_EINVAL;                  // known outlier columns need both operands of the tail
-    int rc = mixq_quant_fused(a->x, a->ind, a->n_cap, a->n_dev, a->x_scale, a->q_x, a->x_out, a->flag, a->M, a->K, a->ldx, a->ldxo,
-                              a->bit, a->sigma, a->qfmt, stream);
+    int rc = a->row_amax
+        ? mixq_quant_known_amax(a->x, a->ind, a->n_cap, a->n_dev, a->row_amax, a->col_mask, a->x_scale, a->q_x, a->x_out, a->flag, a->M,
+                                a->K, a->ldx, a->ldxo, a->bit, a->sigma, a->qfmt, stream)
+        : mixq_quant_fused(a->x, a->ind, a->n_cap, a->n_dev, a->x_scale, a->q_x, a->x_out, a->flag, a->M, a->K, a->ldx, a->ldxo,
+                           a->bit, a->sigma, a->qfmt, stream);
     if (rc) return rc;
     if (a->bit == 8)
         return mixq_gemm_i8_fused(static_cast<const int8_t*>(a->q_x), static_cast<const int8_t*>(a->q_w), a->x_scale, a->scale_col,

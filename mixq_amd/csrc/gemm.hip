@@ -857,7 +857,7 @@ int launch_gemm(GemmArgs& a, int mode, hipStream_t st) {
 int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                       const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                       const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int K,
-                      int act, int layout, int bit, mixq_stream_t stream)
+                      int act, int layout, int bit, mixq_stream_t stream, uint32_t* row_amax = nullptr, const uint32_t* amax_mask = nullptr)
 {
     if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED | MIXQ_W_F16X64)) return MIXQ_EINVAL;
     if ((layout & MIXQ_W_PACKED) && (layout & MIXQ_W_F16X64)) return MIXQ_EINVAL;
@@ -891,9 +891,11 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
         const bool both_packed = a.x_packed && (a.w_packed || wf16);
         // (wide layers with fragment-order int8 weights: the 32 x 64 weights-in-registers tiling streams faster, gemm_wreg.hip)
         const bool wide_wr = wf16 && bit == 8 && N >= 8192 && g_forced < 0;
-        if (!wide_wr && (g_forced < 0 || g_forced == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed))
+        if (!wide_wr && (g_forced < 0 || g_forced == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed)) {
+            if (row_amax) return MIXQ_ESHAPE;                    // the row-maximum side output lives in the weights-in-registers kernels
             return mixq_skinny_launch(bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                                       ldy, M, N, KB, act, wf16 ? 1 : 0, mixq_stream(stream));
+        }
         if (g_forced == skinny_id) return MIXQ_EINVAL;
     }
     // fragment-order weights: the weights-in-registers kernels (gemm_wreg.hip)
@@ -903,8 +905,9 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
         else if (g_forced >= 0) return MIXQ_EINVAL;  // a P16X64 / plain tiling was forced: wrong operand layout
         else c = mixq_wr_pick(bit, M, N, KB);
         return mixq_wr_launch(c, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
-                              ldy, M, N, KB, act, g_trace, mixq_stream(stream));
+                              ldy, M, N, KB, act, g_trace, mixq_stream(stream), row_amax, amax_mask);
     }
+    if (row_amax) return MIXQ_ESHAPE;                            // (only the fragment-order-weights route computes it)
     if (g_forced >= wr0) return MIXQ_EINVAL;
     // stream-K form (gemm_sk.hip): packed operands, workspace registered, chosen explicitly or by the shape rule
     if (a.x_packed && a.w_packed && act != MIXQ_ACT_SILU_MUL) {       // (the stream-K epilogue has no multiplier form)
@@ -927,6 +930,28 @@ extern "C" int mixq_gemm_i8_fused(const int8_t* q_x, const int8_t* q_w, const ui
 {
     return gemm_fused_common(q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                              ldy, M, N, K, act, layout, 8, stream);
+}
+
+// The same GEMM that also leaves, for the quantiser of the NEXT layer, the per-row maximum of |y| over the columns that layer does not
+// treat as outliers (include/mixq_hip.h).  int8, fragment-order weights, batches the weights-in-registers kernels serve.
+extern "C" int mixq_gemm_i8_fused_amax(const int8_t* q_x, const int8_t* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
+                                       const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out,
+                                       const int32_t* n_out_dev, const uint16_t* addend, int lda, const uint16_t* bias,
+                                       uint16_t* y, int ldy, int M, int N, int K, int act, int layout, uint32_t* row_amax,
+                                       const uint32_t* col_mask, mixq_stream_t stream)
+{
+    if (!row_amax) return MIXQ_EINVAL;
+    if (!(layout & MIXQ_W_F16X64)) return MIXQ_ESHAPE;
+    return gemm_fused_common(q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+                             ldy, M, N, K, act, layout, 8, stream, row_amax, col_mask);
+}
+// 1 when mixq_gemm_i8_fused_amax serves (M, N, K) with this layout, else 0 (the caller then quantises the next layer the usual way)
+extern "C" int mixq_gemm_amax_supported(int M, int N, int K, int layout)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || !(layout & MIXQ_W_F16X64) || !(layout & MIXQ_X_PACKED)) return 0;
+    const bool wide_wr = N >= 8192;
+    if (!wide_wr && mixq_skinny_applies(8, M, N, K, true, true)) return 0;
+    return 1;
 }
 
 extern "C" int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x_scale, const uint16_t* scale_col,

@@ -11,4 +11,4 @@ int mixq_wr_pick(int bit, int M, int N, int KB);
 int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
-                   unsigned long long* trace, hipStream_t st);
+                   unsigned long long* trace, hipStream_t st, uint32_t* row_amax = nullptr, const uint32_t* amax_mask = nullptr);

@@ -46,6 +46,10 @@ struct WrArgs {
     int krot;                                         // k-step rotation between neighbouring N tiles (0: every tile starts at k = 0)
     int gm;                                           // M tiles per group of the tile order (see the tile map in the kernel)
     unsigned long long* trace;
+    // optional side output for the NEXT layer's quantiser (down_proj behind gate_proj): row_amax[m] = max over the columns n whose bit in
+    // amax_mask is clear of |fp16 bits of y[m,n]| (atomic max of bit patterns: order-independent, exact); amax_mask: bit n of a uint32 array
+    uint32_t* row_amax;
+    const uint32_t* amax_mask;
 };
 
 constexpr int WR_CW = 4;
@@ -86,6 +90,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int ISSUERS = SELF ? CW : LOADERS;
     constexpr int LOADS = MB / ISSUERS;                  // DMA pieces per issuing wave and stage
     constexpr int OPITCH = BN * 2 + 16;
+    constexpr int AMAX_OFF = (BM * OPITCH + 15) & ~15;   // LDS: [CW][4][BM] row maxima (one slot per wave and lane group), behind the staging tile
     constexpr int TQ = SELF ? 0 : 2;                     // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS
     constexpr int TAILX = NSTAGE * STAGE_BYTES;          // LDS offset of those blocks: behind the ring, [TQ][MB] x 1 KiB
     static_assert(MB % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
@@ -557,6 +562,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         constexpr float PRE = I4 ? (1.f / 256.f) : 1.f;
         const bool has_add = a.addend != nullptr, has_bias = a.bias != nullptr, do_silu = a.act != MIXQ_ACT_NONE;
         const bool mul_add = a.act == MIXQ_ACT_SILU_MUL;
+        const bool has_amax = a.row_amax != nullptr;
         auto unpack4 = [](u32x2 v, float* o) MIXQ_INL {
             o[0] = h2f(static_cast<uint16_t>(v.x & 0xffffu)); o[1] = h2f(static_cast<uint16_t>(v.x >> 16));
             o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
@@ -663,6 +669,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 // (block order is left to the scheduler)
             }
         };
+        uint32_t rmax[MB];                                                       // running max of |fp16 bits| per tile row (two halves packed)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) rmax[j] = 0u;
         auto finish_tile = [&](auto staged_c, auto opt_c, auto p_c) MIXQ_INL {
             constexpr bool ST = decltype(staged_c)::value, OPT = decltype(opt_c)::value;
             constexpr int p = decltype(p_c)::value;
@@ -672,6 +681,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 const int nc = n < a.N ? n : a.N - 4;
                 float bv[4];
                 if (OPT && has_bias) unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+                uint32_t keep_lo = 0x7fff7fffu, keep_hi = 0x7fff7fffu;            // |.| of the 4 halves; the next layer's outlier columns drop out
+                if (OPT && has_amax) {
+                    // (columns past N are computed from clamped operands - values that exist nowhere in y - and count for nothing)
+                    const uint32_t mb = n >= a.N ? 0xfu : (a.amax_mask ? (a.amax_mask[nc >> 5] >> (nc & 31)) & 0xfu : 0u);
+                    if (mb & 1u) keep_lo &= 0xffff0000u;
+                    if (mb & 2u) keep_lo &= 0x0000ffffu;
+                    if (mb & 4u) keep_hi &= 0xffff0000u;
+                    if (mb & 8u) keep_hi &= 0x0000ffffu;
+                }
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
                     const int mloc = j * 16 + lm, m = m0 + mloc;
@@ -699,6 +717,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     u32x2 o;
                     o.x = static_cast<uint32_t>(f2h(f[0])) | (static_cast<uint32_t>(f2h(f[1])) << 16);
                     o.y = static_cast<uint32_t>(f2h(f[2])) | (static_cast<uint32_t>(f2h(f[3])) << 16);
+                    if (OPT && has_amax) {
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        const us2 m = __builtin_elementwise_max(__builtin_bit_cast(us2, o.x & keep_lo), __builtin_bit_cast(us2, o.y & keep_hi));
+                        rmax[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, rmax[j]), m));
+                    }
                     if constexpr (ST) {
                         *reinterpret_cast<u32x2*>(lds + mloc * OPITCH + nloc * 2) = o;
                     } else {
@@ -707,7 +730,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 }
             }
         };
-        const bool opt = has_add || has_bias || do_silu;
+        const bool opt = has_add || has_bias || do_silu || has_amax;
         wr_static_for<0, NP>([&](auto p_c) MIXQ_INL {
             constexpr int p = decltype(p_c)::value;
             if constexpr (TD == 1) {
@@ -740,10 +763,26 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if (staged) { if (opt) finish_tile(std::true_type{}, std::true_type{}, p_c); else finish_tile(std::true_type{}, std::false_type{}, p_c); }
             else        { if (opt) finish_tile(std::false_type{}, std::true_type{}, p_c); else finish_tile(std::false_type{}, std::false_type{}, p_c); }
         });
+        if (has_amax) {                                                          // one slot per (wave, lane group, row): no atomics, no initialisation
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                const uint32_t lo = rmax[j] & 0xffffu, hi = rmax[j] >> 16;
+                *reinterpret_cast<uint32_t*>(lds + AMAX_OFF + ((wave * 4 + lq) * BM + j * 16 + lm) * 4) = lo > hi ? lo : hi;
+            }
+        }
         stamp(7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // ds_write is asynchronous; s_barrier does not wait for it
         __builtin_amdgcn_s_barrier();                                            // staging tile complete
         stamp(3);
+    }
+    if (a.row_amax != nullptr && tid < BM) {                                     // (after the barrier above: every wave's slots are written)
+        uint32_t v = 0u;
+#pragma unroll
+        for (int sl = 0; sl < CW * 4; ++sl) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(lds + AMAX_OFF + (sl * BM + tid) * 4);
+            v = w > v ? w : v;
+        }
+        if (m0 + tid < a.M) atomicMax(a.row_amax + m0 + tid, v);
     }
     if (staged) {
         // all waves (loader included): 16 bytes per lane, 16 / 24 / 32 consecutive lanes cover one row segment of the tile.  Every
@@ -876,7 +915,7 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
 int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
-                   unsigned long long* trace, hipStream_t st)
+                   unsigned long long* trace, hipStream_t st, uint32_t* row_amax, const uint32_t* amax_mask)
 {
     if (c < 0 || c >= NUM_WR) return MIXQ_EINVAL;
     const WrConfig& g = g_wr[c];
@@ -896,9 +935,10 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
         if (a.gm > a.tiles_m) a.gm = a.tiles_m;
     }
     a.trace = trace;
+    a.row_amax = row_amax; a.amax_mask = amax_mask;
     void (*k)(const WrArgs) = bit == 8 ? g.k8 : g.k4;
     if (!k) return MIXQ_EINVAL;                                                  // (the prefill tiles have no nibble form)
-    const size_t ring = static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = static_cast<size_t>(bm) * (bn * 2 + 16);   // ring + the tail's X_out blocks
+    const size_t ring = static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
     const size_t shm = ring > stg ? ring : stg;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3((WR_CW + g.loaders) * 64), shm, st, a);

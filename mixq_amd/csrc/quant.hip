@@ -277,6 +277,78 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
 }
 
 
+// One-pass form for a row whose masked |x| maximum is already KNOWN (the GEMM that produced x left it in row_amax, as fp16 bit
+// patterns maximised with atomics - mixq_gemm_i8_fused_amax): no reduction, no column-mask build (col_mask is the bit-per-column mask
+// the producer used), one barrier that only orders "everybody has read the maximum" before it is cleared for the next forward.
+// Same bytes out as quant_rows2_kernel on the same row: the scale is fp16(amax / qmax) either way.
+template <int BIT, int TPR, int NCH>
+__global__ __launch_bounds__(TPR) void quant_known_kernel(
+    uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
+    uint32_t* __restrict__ row_amax, const uint32_t* __restrict__ col_mask, uint16_t* __restrict__ x_scale, void* __restrict__ q,
+    uint16_t* __restrict__ x_out, int ldo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt)
+{
+    const int row = blockIdx.x, t = threadIdx.x;
+    uint16_t* xr = x + static_cast<size_t>(row) * ldx;
+    const int nchunk = K >> 3;
+    const uint4* xv = reinterpret_cast<const uint4*>(xr);
+    uint4 keep[NCH];
+    uint32_t m8[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = t + i * TPR;
+        const bool in = c < nchunk;
+        keep[i] = in ? xv[c] : make_uint4(0, 0, 0, 0);
+        m8[i] = (in && col_mask) ? ((col_mask[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
+    }
+    int n = n_cap;
+    if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
+    const bool have_out = (n > 0) && ind != nullptr;
+    // the outlier values of this row are requested now and consumed (x_out, in-place zero) after the quantised row has been written
+    constexpr int GQ = 2;
+    int gcol[GQ] = {-1, -1};
+    uint16_t gval[GQ] = {0, 0};
+    if (have_out) {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) { const int j = t + g * TPR; if (j < n) { gcol[g] = ind[j]; gval[g] = xr[gcol[g]]; } }
+    }
+    const uint32_t abits = row_amax[row] & 0x7fffu;
+    __syncthreads();                                                      // every thread of the row has read the maximum ...
+    if (t == 0) row_amax[row] = 0u;                                       // ... before it is cleared for the producer's next run
+    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
+    const uint16_t sh = f2h(__fdiv_rn(h2f(static_cast<uint16_t>(abits)), QMAX));
+    const float s = h2f(sh);
+    const float rs = s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;
+    if (t == 0) {
+        x_scale[row] = sh;
+        if (flag && s > thr_scale) atomicOr(flag, 1);
+    }
+    void* qrow = fmt ? q : static_cast<void*>(static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1)));
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = t + i * TPR;
+        if (c < nchunk) {
+            (void)amax8_masked(keep[i], m8[i], 0u);                        // zero the outlier columns of the chunk (whatever the load saw there)
+            quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
+        }
+    }
+    if (have_out) {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+            if (gcol[g] >= 0) {
+                if (x_out) x_out[static_cast<size_t>(row) * ldo + t + g * TPR] = gval[g];
+                xr[gcol[g]] = 0;                                           // the reference zeroes the caller's tensor in place
+            }
+        }
+        for (int j = t + GQ * TPR; j < n; j += TPR) {
+            const int c = ind[j];
+            const uint16_t v = xr[c];
+            if (x_out) x_out[static_cast<size_t>(row) * ldo + j] = v;
+            xr[c] = 0;
+        }
+    }
+    if (x_out) for (int j = (have_out ? n : 0) + t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = 0;
+}
+
 __global__ __launch_bounds__(QT) void extract_kernel(uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind,
                                                      int n, uint16_t* __restrict__ x_out, int ldo)
 {
@@ -525,6 +597,38 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
     uint16_t* xo = (n > 0) ? x_out : nullptr;
     if (bit == 8) return launch_quant_rows<8>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream));
     return launch_quant_rows<4>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream));
+}
+
+extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint32_t* row_amax,
+                                     const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K,
+                                     int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream)
+{
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
+    if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !x_scale || !q || !row_amax))) return MIXQ_EINVAL;
+    if (bit != 8 && bit != 4) return MIXQ_EINVAL;
+    if (n > 0 && (!ind || !x_out || ldo < n || !col_mask)) return MIXQ_EINVAL;      // outlier columns need their bit mask
+    if ((K & 7) || (ldx & 7) || ldx < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
+    if (K > 16 * 512 * 8) return MIXQ_ESHAPE;                                       // a row lives in the registers of one workgroup
+    if (M == 0) return MIXQ_OK;
+    const float qmax = static_cast<float>((1 << (bit - 1)) - 1);
+    const float thr = fp16_round(fp16_round(sigma) / qmax);
+    uint16_t* xo = (n > 0) ? x_out : nullptr;
+    const int rows16 = qfmt ? ((M + 15) & ~15) : 0, nchunk = K >> 3;
+    hipStream_t st = mixq_stream(stream);
+#define MIXQ_QK(BITv, TPRv, NCHv) hipLaunchKernelGGL((quant_known_kernel<BITv, TPRv, NCHv>), dim3(M), dim3(TPRv), 0, st, x, ldx, ind, n, n_dev, \
+                                                     row_amax, col_mask, x_scale, q, xo, ldo, flag, K, thr, rows16, qfmt)
+#define MIXQ_QK_BY_SIZE(BITv)                                             \
+    if      (nchunk <= 256)      MIXQ_QK(BITv, 256, 1);                   \
+    else if (nchunk <= 512)      MIXQ_QK(BITv, 512, 1);                   \
+    else if (nchunk <= 2 * 512)  MIXQ_QK(BITv, 512, 2);                   \
+    else if (nchunk <= 4 * 512)  MIXQ_QK(BITv, 512, 4);                   \
+    else if (nchunk <= 8 * 512)  MIXQ_QK(BITv, 512, 8);                   \
+    else                         MIXQ_QK(BITv, 512, 16);
+    if (bit == 8) { MIXQ_QK_BY_SIZE(8) } else { MIXQ_QK_BY_SIZE(4) }
+#undef MIXQ_QK_BY_SIZE
+#undef MIXQ_QK
+    return mixq_launch_status();
 }
 
 extern "C" int mixq_extract_outliers_zero(uint16_t* x, const int32_t* ind, int n, uint16_t* x_out, int M, int K, int ldx,

@@ -14,6 +14,8 @@ import torch.nn as nn
 from . import mixlib as _hip_mixlib
 
 _backend = _hip_mixlib
+# gate_proj's GEMM also emits down_proj's per-row |x| maxima (include/mixq_hip.h: mixq_gemm_i8_fused_amax); False = the two-pass quantiser
+FUSE_DOWN_AMAX = True
 
 
 def set_backend(mod):
@@ -72,5 +74,7 @@ class MixLlamaMLP(nn.Module):
     def forward(self, x):
         up_output = self.up_proj_(x, self.MLPCache)
         # silu(gate(x)) * up(x) in gate_proj's epilogue (the reference multiplies in a separate pass, mlp.py:61-63)
-        gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache, mul=up_output)
+        # ... and down_proj's pre-pass row maxima leave the same epilogue (its quantiser then needs one pass over the activation)
+        extra = {"amax_for": self.down_proj_} if FUSE_DOWN_AMAX else {}
+        gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache, mul=up_output, **extra)
         return self.down_proj_(gate_output, None, True)

@@ -175,6 +175,10 @@ class MixLinear_GEMM(nn.Module):
         self._silu_calls = 0
         self._plan = None            # argument block of the one-call forward of the frozen layer (mixq_linear_forward)
         self._plan_key = None
+        self._cmask = None           # bit-per-input-column mask of `ind` (int32 words) for a producer's row-maximum side output
+        self._cmask_key = None
+        self._amax_buf = None        # int32 [M]: this layer's row maxima as left by the GEMM that produced its input
+        self._amax_dirty = False     # written by a producer and not yet consumed (and cleared) by this layer's quantiser
 
     # ------------------------------------------------------------------------------------------------------
     @classmethod
@@ -366,7 +370,37 @@ class MixLinear_GEMM(nn.Module):
             self._n_dev_host = n
         return buf[:_pad16(n)], self._n_dev
 
-    def _gemm(self, cache, M, act, addend=None):
+    # ---- this layer's pre-pass maximum as a side output of the GEMM that produces its input (fused/mlp.py:57-70) --------
+    def _col_mask(self):
+        """int32 words, bit k set <=> input column k is one of this layer's outlier columns; None without outliers."""
+        n = int(self.ind.shape[0])
+        if n == 0:
+            return None
+        ind = self.ind
+        key = (id(ind), ind.data_ptr(), ind._version, n)
+        if self._cmask is None or self._cmask_key != key:
+            words = (self.in_features + 31) // 32
+            bits = torch.zeros(words * 32, dtype=torch.int64, device=ind.device)
+            bits[ind.long()] = 1
+            w = (bits.view(words, 32) << torch.arange(32, device=ind.device, dtype=torch.int64)).sum(dim=1)
+            w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)       # the same 32 bits as a signed word
+            self._cmask, self._cmask_key = w, key
+        return self._cmask
+
+    def amax_target(self, M, device):
+        """(row_amax buffer, column mask) a producing GEMM should fill for this layer's next forward of M rows, or None when this
+        layer cannot use it (outlier search still running, weight-only).  The buffer is zero when handed out."""
+        if self.weight_only or self.add_outliers or not ONE_CALL_FORWARD or not hasattr(_backend, "amax_supported"):
+            return None
+        if self._amax_buf is None or self._amax_buf.numel() < M or self._amax_buf.device != torch.device(device):
+            self._amax_buf = torch.zeros((max(M, 16),), dtype=torch.int32, device=device)
+            self._amax_dirty = False
+        if self._amax_dirty:
+            self._amax_buf.zero_()                           # a producer ran and nobody consumed: start clean
+        self._amax_dirty = True
+        return self._amax_buf, self._col_mask()
+
+    def _gemm(self, cache, M, act, addend=None, row_amax=None, col_mask=None):
         n = int(self.ind.shape[0])
         xo = wo = n_dev = None
         cap = 0
@@ -400,11 +434,12 @@ class MixLinear_GEMM(nn.Module):
                 qx = _backend.UnpackOperand(qx, M)
             if want != FMT_PLAIN:
                 qx = _backend.PackOperand(qx[:M].contiguous(), want)
+        extra = {} if row_amax is None else {"row_amax": row_amax, "col_mask": col_mask}
         if n:
             return _backend.FusedLinear(qx, w, cache.x_scale, self.scale_col, _wide(xo, n_cap), _wide(wo, n_cap), n_cap, self.bias, M, self.out_features, self.in_features, bit=self.bit,
-                                        act=act, addend=addend, n_out_dev=n_dev)
+                                        act=act, addend=addend, n_out_dev=n_dev, **extra)
         return _backend.FusedLinear(qx, w, cache.x_scale, self.scale_col, None, None, 0, self.bias, M, self.out_features,
-                                    self.in_features, bit=self.bit, act=act, addend=addend)
+                                    self.in_features, bit=self.bit, act=act, addend=addend, **extra)
 
     # ---- frozen steady state: the whole forward behind ONE foreign call (include/mixq_hip.h: mixq_linear_forward) ------
     def _frozen_key(self, cache, inputs, M):
@@ -464,7 +499,12 @@ class MixLinear_GEMM(nn.Module):
                 self._plan_key = self._frozen_key(cache, inputs, M)
             plan = self._plan
             if plan is not None:
-                y1, cache.q_xcache, xo = plan.run(inputs)
+                tag = getattr(x, "_mixq_row_amax", None)     # left by the GEMM that produced x (forward_without_preconditionFusedSilu)
+                if tag is not None and tag[1] is self and self._amax_dirty and tag[0] is self._amax_buf and tag[0].numel() >= M:
+                    y1, cache.q_xcache, xo = plan.run(inputs, row_amax=tag[0], col_mask=self._col_mask())
+                    self._amax_dirty = False                 # the quantiser cleared the buffer
+                else:
+                    y1, cache.q_xcache, xo = plan.run(inputs)
                 if xo is not None:
                     cache.activation_outliers = xo
                 cache.n_dev = plan.keep[1]
@@ -526,11 +566,13 @@ class MixLinear_GEMM(nn.Module):
         return y1.reshape(cache.shape)
 
     @torch.no_grad()
-    def forward_without_preconditionFusedSilu(self, x, cache, mul=None):
+    def forward_without_preconditionFusedSilu(self, x, cache, mul=None, amax_for=None):
         """gate_proj path (linear.py:292-376): reuse the activation quantised for up_proj, SiLU in the epilogue.
         `mul` (an extension): an fp16 [..., N] tensor multiplied in after the SiLU and the bias, i.e.
         (silu(gate(x)) + bias) * up(x) leaves the GEMM directly and the `gate_output *= up_output` pass of
-        modules/fused/mlp.py:61-63 disappears."""
+        modules/fused/mlp.py:61-63 disappears.
+        `amax_for` (an extension): the layer that consumes this output next (down_proj, mlp.py:66-67).  The GEMM then also leaves that
+        layer's pre-pass row maxima (over the columns it does not extract), and its forward quantises in one pass instead of two."""
         inputs = x.reshape(-1, x.shape[-1])
         M = inputs.shape[0]
         if not self.forward_without_precondition_len == cache.ind.shape[0]:
@@ -549,14 +591,24 @@ class MixLinear_GEMM(nn.Module):
             raise RuntimeError("int4 mod should have outliers !")
         if getattr(cache, "n_dev", None) is not None:
             self._n_dev = cache.n_dev                        # the count of the layer whose activation this one shares
+        target = None
+        if amax_for is not None and self.bit == 8 and amax_for.in_features == self.out_features:
+            wpk = self._packed_weight()
+            if wpk is not None and hasattr(_backend, "amax_supported") and \
+                    _backend.amax_supported(M, self.out_features, self.in_features, _fmt_of(cache.q_xcache), _fmt_of(wpk)):
+                target = amax_for.amax_target(M, x.device)
+        extra = {} if target is None else {"row_amax": target[0], "col_mask": target[1]}
         if mul is not None:
-            y1 = self._gemm(cache, M, ACT_SILU_MUL, addend=mul.reshape(-1, self.out_features))
+            y1 = self._gemm(cache, M, ACT_SILU_MUL, addend=mul.reshape(-1, self.out_features), **extra)
         else:
-            y1 = self._gemm(cache, M, ACT_SILU)
+            y1 = self._gemm(cache, M, ACT_SILU, **extra)
         self._silu_calls += 1
         if COMPACT_WEIGHTS and self._silu_calls >= self.cache.stop:
             self.compact_weights_()
-        return y1.reshape(cache.shape)
+        out = y1.reshape(cache.shape)
+        if target is not None:
+            out._mixq_row_amax = (target[0], amax_for)       # rides on the tensor handed to the consumer
+        return out
 
 
 def _unpack_host(packed, R, fmt):

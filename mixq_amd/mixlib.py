@@ -650,13 +650,23 @@ def DequantWeightCols(q_w, scale_col, ind, bit, out=None):
     return out
 
 
+def amax_supported(M, N, K, x_fmt, w_fmt):
+    """True when the GEMM can leave the next layer's row maxima as a side output for this problem (mixq_gemm_amax_supported)."""
+    if x_fmt != FMT_P16X64 or w_fmt != FMT_F16X64:
+        return False
+    return bool(_capi.load().mixq_gemm_amax_supported(M, N, K, X_PACKED | W_F16X64))
+
+
 def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K, bit=8, act=ACT_NONE, n_out_dev=None,
-                addend=None, out=None, x_packed=None, w_packed=None):
+                addend=None, out=None, x_packed=None, w_packed=None, row_amax=None, col_mask=None):
     """(iii)+(iv): int8/int4 MFMA GEMM + dequant + fp16 outlier correction + addend + act + bias -> fp16 [M,N].
     The operand layouts come from the tensors' own format tags (set_fmt / the packing and quantising functions above);
     x_packed / w_packed = True/False force P16x64 / plain for untagged buffers.  `n_out_dev` (device int32[1]) overrides the
-    outlier count: n_out then is the capacity of x_out / w_out (columns >= the device count are ignored, whatever they hold)."""
-    _dev_check(q_x, q_w, x_scale, scale_col)
+    outlier count: n_out then is the capacity of x_out / w_out (columns >= the device count are ignored, whatever they hold).
+    `row_amax` (device int32 [>= M], zero on entry): also maximise, per row, the fp16 bit patterns |y| over the columns whose bit in
+    `col_mask` (int32 words, bit n) is clear - the next layer's pre-pass maximum (mixq_gemm_i8_fused_amax; int8, fragment-order
+    weights only)."""
+    _dev_check(q_x, q_w, x_scale, scale_col, row_amax, col_mask)
     if x_scale.numel() < M or scale_col.numel() < N:
         raise RuntimeError("FusedLinear: x_scale / scale_col are shorter than M / N")
     x_fmt = fmt_of(q_x) if x_packed is None else (FMT_P16X64 if x_packed else FMT_PLAIN)
@@ -681,6 +691,13 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
             addend._materialize()
         _dev_check(addend)
         ap, lda = _rows(addend, "addend")
+    if row_amax is not None:
+        if bit != 8 or row_amax.numel() < M or row_amax.element_size() != 4:
+            raise RuntimeError("FusedLinear: row_amax needs an int8 GEMM and a 4-byte buffer of at least M entries")
+        _capi.call("mixq_gemm_i8_fused_amax", q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(), xop, ldxo, wop, ldwo,
+                   n_out, _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act, _layout_bits(x_fmt, w_fmt),
+                   row_amax.data_ptr(), _ptr(col_mask), _stream())
+        return y
     fn = "mixq_gemm_i8_fused" if bit == 8 else "mixq_gemm_i4_fused"
     _capi.call(fn, q_x.data_ptr(), q_w.data_ptr(), x_scale.data_ptr(), scale_col.data_ptr(), xop, ldxo, wop, ldwo, n_out,
                _ptr(n_out_dev), ap, lda, _ptr(bias), y.data_ptr(), y.stride(0), M, N, K, act, _layout_bits(x_fmt, w_fmt), _stream())
@@ -719,9 +736,12 @@ class ForwardPlan:
         KB = K if bit == 8 else K // 2
         self.q_shape, self.q_dtype = (packed_rows(M) if qfmt else M, KB), (torch.int8 if bit == 8 else torch.uint8)
 
-    def run(self, x):
-        """x: fp16 [M,K] with the row stride the plan was built for.  Returns (y [M,N], q_x, x_out [M,n] or None)."""
+    def run(self, x, row_amax=None, col_mask=None):
+        """x: fp16 [M,K] with the row stride the plan was built for.  Returns (y [M,N], q_x, x_out [M,n] or None).
+        row_amax (int32 [>= M] on the device): the rows' masked maxima left by the GEMM that produced x (FusedLinear(row_amax=...));
+        the quantise pass is then the one-pass known-maximum kernel, which also clears the buffer."""
         a = self.args
+        a.row_amax, a.col_mask = _ptr(row_amax), _ptr(col_mask)
         dev = self.device
         q = torch.empty(self.q_shape, dtype=self.q_dtype, device=dev)
         y = torch.empty((self.M, self.N), dtype=torch.float16, device=dev)

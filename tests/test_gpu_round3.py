@@ -202,3 +202,130 @@ def test_compacted_layer_state_dict_edge_cases():
     cache2 = MixLibCache(32, device=DEV)
     layer.cache = cache2
     assert torch.equal(layer(x.to(DEV), cache2, True), y0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# down_proj's pre-pass maximum as a side output of gate_proj's GEMM (mlp.py:57-70 + linear.py:187-193)
+# ---------------------------------------------------------------------------------------------------------------
+def _mask_words(K, cols, dev=DEV):
+    bits = np.zeros(((K + 31) // 32) * 32, dtype=np.uint64)
+    bits[list(cols)] = 1
+    w = (bits.reshape(-1, 32) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+    return torch.from_numpy(w.view(np.int32).copy()).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K,act,bias,masked", [(100, 260, 512, 0, True, 7), (512, 1536, 1024, 2, False, 41), (33, 64, 128, 1, True, 0),
+                                                     (257, 1000, 256, 2, True, 110), (16, 8192, 256, 0, False, 5)])
+def test_gemm_row_amax_side_output_is_the_exact_masked_maximum(M, N, K, act, bias, masked):
+    """mixq_gemm_i8_fused_amax on every weights-in-registers tiling: y is bit-identical to the plain entry point and row_amax[m] is
+    exactly max over the unmasked columns of the fp16 bit patterns |y[m, :]| (integer atomics: order-independent)."""
+    rng = np.random.default_rng(M + N + K)
+    qx = torch.from_numpy(rng.integers(-127, 128, size=(M, K), dtype=np.int8)).to(DEV)
+    qw = torch.from_numpy(rng.integers(-127, 128, size=(N, K), dtype=np.int8)).to(DEV)
+    sx = (torch.rand(M, 1) * 0.01 + 0.001).half().to(DEV)
+    sw = (torch.rand(1, N) * 0.01 + 0.001).half().to(DEV)
+    b = torch.randn(N).half().to(DEV) if bias else None
+    add = torch.randn(M, N).half().to(DEV) if act == 2 else None
+    cols = sorted(rng.choice(N, size=masked, replace=False).tolist()) if masked else []
+    mask = _mask_words(N, cols) if masked else None
+    xp, wp = mixlib.PackOperand(qx, 1), mixlib.PackOperand(qw, 2)
+    lib = _capi.load()
+    names = _capi.gemm_config_names()
+    try:
+        for cfg in [-1] + [i for i, nm in enumerate(names) if nm.startswith("wr")]:
+            assert lib.mixq_gemm_set_config(cfg) == 0
+            if not mixlib.amax_supported(M, N, K, 1, 2) and cfg == -1:
+                continue
+            y0 = mixlib.FusedLinear(xp, wp, sx, sw, None, None, 0, b, M, N, K, act=act, addend=add)
+            buf = torch.zeros(M + 3, dtype=torch.int32, device=DEV)
+            y1 = mixlib.FusedLinear(xp, wp, sx, sw, None, None, 0, b, M, N, K, act=act, addend=add, row_amax=buf, col_mask=mask)
+            assert torch.equal(y0, y1), names[cfg]
+            bits = n(y1).view(np.uint16).astype(np.int64) & 0x7fff
+            if cols:
+                bits[:, cols] = 0
+            assert np.array_equal(n(buf)[:M].astype(np.int64), bits.max(axis=1)), names[cfg]
+            assert (n(buf)[M:] == 0).all()
+    finally:
+        lib.mixq_gemm_set_config(-1)
+
+
+@pytest.mark.parametrize("M,K,ncols,bit,fmt", [(64, 4096, 41, 8, 1), (33, 11008, 110, 8, 1), (16, 256, 0, 8, 0), (40, 1024, 130, 4, 1), (7, 28672, 287, 8, 1)])
+def test_known_maximum_quantiser_writes_the_same_bytes(M, K, ncols, bit, fmt):
+    """mixq_quant_known_amax (one pass, maxima handed over) against mixq_quant_fused (two passes): q, x_scale, the extracted outliers and
+    the zeroed x agree bit for bit, and the maxima buffer comes back cleared."""
+    rng = np.random.default_rng(K + ncols)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    cols = np.sort(rng.choice(K, size=ncols, replace=False)).astype(np.int32)
+    x[:, cols] *= 20
+    x[M // 2] = 0                                                       # an all-zero row: scale 0, q 0
+    ind = torch.from_numpy(cols).to(DEV) if ncols else None
+    xa, xb = torch.from_numpy(x).to(DEV), torch.from_numpy(x).to(DEV)
+    sa, sb = torch.zeros(M, 1, dtype=torch.float16, device=DEV), torch.zeros(M, 1, dtype=torch.float16, device=DEV)
+    qa, xoa = mixlib.QuantFused(xa, ind, sa, bit, 6.0, fmt=fmt)
+    xm = np.abs(x.astype(np.float32))
+    if ncols:
+        xm[:, cols] = 0
+    amax = torch.from_numpy(xm.max(axis=1).astype(np.float16).view(np.uint16).astype(np.int32)).to(DEV)
+    mask = _mask_words(K, cols.tolist()) if ncols else None
+    qb = torch.empty_like(qa)
+    ldo = (ncols + 15) // 16 * 16
+    xob = torch.empty((M, ldo), dtype=torch.float16, device=DEV) if ncols else None
+    _capi.call("mixq_quant_known_amax", xb.data_ptr(), None if ind is None else ind.data_ptr(), ncols, None, amax.data_ptr(),
+               None if mask is None else mask.data_ptr(), sb.data_ptr(), qb.data_ptr(), None if xob is None else xob.data_ptr(), None,
+               M, K, K, ldo, bit, 6.0, fmt, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(sa, sb) and torch.equal(xa, xb) and (n(amax) == 0).all()
+    ua = mixlib.UnpackOperand(mixlib.set_fmt(qa, fmt), M, fmt) if fmt else qa
+    ub = mixlib.UnpackOperand(mixlib.set_fmt(qb, fmt), M, fmt) if fmt else qb
+    assert torch.equal(ua, ub)
+    if ncols:
+        assert torch.equal(xoa, xob[:, :ncols])
+
+
+def test_mlp_block_with_the_fused_row_maximum_is_bit_identical():
+    """MixLlamaMLP with down_proj's pre-pass maximum taken from gate_proj's epilogue against the two-pass quantiser: same output bits,
+    same down_proj x_scale, the hand-over buffer is consumed (cleared) every forward, also under hipGraph replay."""
+    from mixq_amd import FasterTransformerRMSNorm, MixLlamaMLP, fused
+    M, H, F = 96, 512, 1536
+    torch.manual_seed(0)
+    cache = MixLibCache(M, device=DEV)
+    mk = lambda k, nn_: MixLinear_GEMM.from_linear(torch.nn.Linear(k, nn_, bias=True).half(), 8, cache=cache, dev=DEV)
+    gate, up, down = mk(H, F), mk(H, F), mk(F, H)
+    inner = MixLlamaMLP(gate, down, up, cache)
+    norm = FasterTransformerRMSNorm((torch.rand(H) + 0.5).half().to(DEV), 1e-5, cache)      # fills the cache for up_proj (norm.py:24-33)
+    norm.next_layer = up
+    mlp = lambda x: inner(norm(x))
+    g = torch.Generator().manual_seed(1)
+    cols = torch.randperm(H, generator=g)[:5]
+    xs = []
+    for c in range(4):
+        x = torch.randn(M, H, generator=g).half()
+        x[:, cols] *= 20
+        xs.append(x)
+    prev = fused.FUSE_DOWN_AMAX
+    try:
+        fused.FUSE_DOWN_AMAX = False
+        for x in xs[:3]:
+            mlp(x.clone().to(DEV))                                    # freeze every layer's outlier search
+        assert not down.add_outliers and not up.add_outliers
+        y_ref = mlp(xs[3].clone().to(DEV))
+        sx_ref = cache.x_scale[:M].clone()
+        fused.FUSE_DOWN_AMAX = True
+        y = mlp(xs[3].clone().to(DEV))
+        assert down._amax_buf is not None and not down._amax_dirty, "down_proj did not take the hand-over"
+        assert torch.equal(y, y_ref) and torch.equal(cache.x_scale[:M], sx_ref)
+        assert int(down._amax_buf.abs().sum()) == 0
+        side = torch.cuda.Stream()
+        xg = xs[3].clone().to(DEV)
+        keep = xg.clone()
+        with torch.cuda.stream(side):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                yg = mlp(xg)
+            for _ in range(3):
+                xg.copy_(keep)
+                gr.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(yg, y_ref)
+    finally:
+        fused.FUSE_DOWN_AMAX = prev

@@ -8,7 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP  # noqa: E402
+from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP, fused  # noqa: E402
 
 M, H, F = 512, 4096, 11008
 dev = "cuda"
@@ -36,13 +36,15 @@ def block(x, fused_mul):
     return down(go, None, True)
 
 
+fused.FUSE_DOWN_AMAX = False
 for _ in range(3):                       # outlier prediction warm-up (host syncs allowed here)
     block(base.clone(), True)
 torch.cuda.synchronize()
 ya, yb = block(base.clone(), True), block(base.clone(), False)
 print("max |fused - two-step| =", float((ya.float() - yb.float()).abs().max()))
 steps = 50
-for fused_mul in (False, True):
+for fused_mul, amax in ((False, False), (True, False), (True, True)):
+    fused.FUSE_DOWN_AMAX = amax
     xs = base.unsqueeze(0).repeat(steps, 1, 1).contiguous()
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -56,5 +58,5 @@ for fused_mul in (False, True):
         gr.replay(); torch.cuda.synchronize()
         us = (time.perf_counter() - t0) * 1e6 / steps
     flops = 2.0 * M * (2 * H * F + F * H)
-    print(f"norm + MLP block, gate*up {'in the gate epilogue' if fused_mul else 'as a separate pass'}: {us:7.1f} us  "
+    print(f"norm + MLP block, gate*up {'in the gate epilogue' if fused_mul else 'as a separate pass'}{', down_proj row maxima from the same epilogue' if amax else ''}: {us:7.1f} us  "
           f"({flops / us / 1e6:6.0f} effective TFLOPS)")
