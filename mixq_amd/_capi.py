@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libmixq_hip.so")
 # (`make -C mixq_amd/csrc tuning`); the package itself never asks for it
 if os.environ.get("MIXQ_TUNING_LIB") == "1":
     LIB_PATH = os.path.join(_HERE, "libmixq_hip_tuning.so")
+if os.environ.get("MIXQ_LIB_FILE"):                     # development aid: time another BUILD of the library (before / after A/B runs)
+    LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ["MIXQ_LIB_FILE"]))
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mixq_hip.h")
 
 MIXQ_OK = 0

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""profiles/rNN_hbm_traffic.json from the two rocprofv3 PMC summaries (tools/rocprof_summary.py output of separate --pmc FETCH_SIZE and
+--pmc WRITE_SIZE passes over `bench.py --no-graph`): HBM bytes per launch of the dominant GEMM kernel, FETCH_SIZE doubled (the gfx950
+correction of MI355X_MICROARCH.md, HBM section).  Usage: make_traffic_json.py fetch.txt write.txt out.json 'source note'"""
+import json
+import re
+import sys
+
+
+def counter(path, name, kernel_pat="gemm_wreg_kernel"):
+    txt = open(path).read().split("# PMC counters")[-1]
+    blocks = re.split(r"\n(?=\S)", txt)
+    for b in blocks:
+        if kernel_pat in b.splitlines()[0]:
+            m = re.search(rf"{name}\s+([0-9.]+)", b)
+            if m:
+                return b.splitlines()[0].strip(), float(m.group(1))
+    raise SystemExit(f"{name} for {kernel_pat} not found in {path}")
+
+
+fetch_txt, write_txt, out, note = sys.argv[1:5]
+kname, fetch_kb = counter(fetch_txt, "FETCH_SIZE")
+_, write_kb = counter(write_txt, "WRITE_SIZE")
+M, K, N = 512, 4096, 11008
+alg = M * K + N * K + 2 * M * N
+hbm = int(round((2 * fetch_kb + write_kb) * 1024))
+json.dump({"kernel": kname + ", 512 x 4096 -> 11008, 41 outlier columns", "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+           "correction": "gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported",
+           "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "source": note, "ratio_to_algorithmic": round(hbm / alg, 3)},
+          open(out, "w"), indent=1)
+print(open(out).read())
