@@ -161,7 +161,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         auto stage = [&](int slot) MIXQ_INL {
             if constexpr (ABL != 2 && ABL != 3) {
 #pragma unroll
-                for (int i = 0; i < LOADS; ++i) wr_glds16(src[i] + xoff, lds + slot * STAGE_BYTES + dsto[i]);
+                for (int i = 0; i < LOADS; ++i) {
+                    wr_glds16(src[i] + xoff, lds + slot * STAGE_BYTES + dsto[i]);
+                    if constexpr (ABL == 22 || ABL == 23) __builtin_amdgcn_s_sleep(1);     // probe: the loader's pieces spread over the k-step
+                    if constexpr (ABL == 24) __builtin_amdgcn_s_sleep(2);
+                }
             }
             xoff += xks;
             if (++xk == nk) { xk = 0; xoff = 0; }
@@ -377,7 +381,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             auto loads_behind = [&](int j) MIXQ_INL {                                     // j: compile-time after unrolling
 #pragma unroll
                 for (int i = 0; i < WNB; ++i) {
-                    const int pos = (WNB >= MB) ? (i % MB) : ((2 * i + 1) * MB) / (2 * WNB);      // spread evenly over the MB groups
+                    int pos = (WNB >= MB) ? (i % MB) : ((2 * i + 1) * MB) / (2 * WNB);      // spread evenly over the MB groups
+                    if constexpr (ABL == 20 || ABL == 23) pos = MB - WNB + i;            // probe: behind the last groups (away from the loaders' burst after the barrier)
+                    if constexpr (ABL == 21) pos = (i * MB) / WNB;                        // probe: 0, 2, 5: earlier
                     if (pos == j) { if constexpr (FULL) wload1_always(LC{}, i); else wload1(LC{}, i, issue); }
                 }
             };
@@ -858,6 +864,11 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// cfg 0 with ordinary (not nt) stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 9, "128x192_abl9_empty"),  // returns at entry: the launch floor of this grid and LDS footprint
     MIXQ_WR(8, 3, 16, 4, 2, 12, "128x192_abl12_noramp"),// cfg 0 with all LOOK stages requested at once (the form before the ramp)
+    MIXQ_WR(8, 3, 16, 4, 2, 20, "128x192_p20_wlate"),  // probes of WHEN requests are issued inside a k-step (results are correct)
+    MIXQ_WR(8, 3, 16, 4, 2, 21, "128x192_p21_wearly"),
+    MIXQ_WR(8, 3, 16, 4, 2, 22, "128x192_p22_paced"),
+    MIXQ_WR(8, 3, 16, 4, 2, 23, "128x192_p23_wlate_paced"),
+    MIXQ_WR(8, 3, 16, 4, 2, 24, "128x192_p24_paced2"),
     // EXPERIMENT (round 3, kept for the record, not shipped): the vendor library's prefill shape - 256 x 256 tiles, four fat
     // self-loading waves with 256 accumulator registers each (SELF form of the kernel), (16 + 16) KB of operands per k-step for
     // 4 x 64 MFMAs, half the L1 / L2 bytes per MFMA of 128 x 256.  Measured at 4096 x 11008 x 4096 without outlier columns: 186.1 us
