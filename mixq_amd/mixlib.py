@@ -84,7 +84,25 @@ _packed_operands = False
 _wpacked = {}          # (data_ptr, version, shape) -> (weight, fragment-order copy); the entry pins the weight: see eetq._packed
 
 
+# The three tensor-subclass handles below (and PendingGemmI32) sit on torch's __torch_function__ protocol and two private helpers
+# (torch.Tensor._make_subclass, torch._C.DisableTorchFunctionSubclass).  They were written and tested against this torch series; on
+# another one they are still opt-in, and say so once.
+_TESTED_TORCH = "2.10"
+_warned_torch = False
+
+
+def _check_torch_for_handles():
+    global _warned_torch
+    if not _warned_torch and not torch.__version__.startswith(_TESTED_TORCH):
+        import warnings
+        _warned_torch = True
+        warnings.warn(f"mixq_amd.mixlib: the deferred-tensor switches (set_lazy_gemm / set_packed_operands / set_fused_outliers / "
+                      f"set_fused_prepass) were tested with torch {_TESTED_TORCH}.x; this is torch {torch.__version__}", RuntimeWarning, stacklevel=3)
+
+
 def set_packed_operands(enabled):
+    if enabled:
+        _check_torch_for_handles()
     global _packed_operands
     prev, _packed_operands = _packed_operands, bool(enabled)
     if not enabled:
@@ -155,6 +173,8 @@ _wo_padded = {}        # (data_ptr, version, shape, stride) -> (weight_cache vie
 
 
 def set_fused_outliers(enabled):
+    if enabled:
+        _check_torch_for_handles()
     global _fused_outliers
     prev, _fused_outliers = _fused_outliers, bool(enabled)
     if not enabled:
@@ -179,6 +199,8 @@ _pending_extract = None        # the OutlierActivations whose extraction is stil
 
 
 def set_fused_prepass(enabled):
+    if enabled:
+        _check_torch_for_handles()
     global _fused_prepass
     _flush_pending_extract()
     prev, _fused_prepass = _fused_prepass, bool(enabled)
@@ -464,6 +486,8 @@ def set_lazy_gemm(enabled):
     opt-in like the switches above, because a consumer that bypasses __torch_function__ (a C++ extension taking at::Tensor) would
     read the not-yet-computed storage.  set_packed_operands(True) / set_fused_outliers(True) imply it: their handles only make sense
     when `gemm` + `dequantizeInt8` run as one kernel."""
+    if enabled:
+        _check_torch_for_handles()
     global _lazy_gemm
     prev, _lazy_gemm = _lazy_gemm, bool(enabled)
     return prev

@@ -125,6 +125,16 @@ def test_forced_configuration_round_trips():
     assert lib.mixq_quant_set_config(9) == 0 and lib.mixq_quant_set_config(10) == _capi.MIXQ_EINVAL and lib.mixq_quant_set_config(-1) == 0
 
 
+def test_forced_rebuild_of_one_object(tmp_path):
+    """`make -B` on one object (the forced-rebuild path of __graft_entry__.build(force=True), on the smallest source): hipcc cross-
+    compiles gfx950 from the tracked sources without a GPU, and the object carries the entry point."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(root, "build", "obj", "forward.o")
+    r = subprocess.run(["make", "-C", os.path.join(root, "mixq_amd", "csrc"), "-B", "../../build/obj/forward.o"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "hipcc" in r.stdout and os.path.exists(obj) and b"mixq_linear_forward" in open(obj, "rb").read()
+
+
 def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_capi, "_lib", None)
     monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "nope.so"))
