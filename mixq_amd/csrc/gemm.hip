@@ -52,6 +52,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int x_packed, w_packed;                           // operand stored in the P16x64 tile-major layout
     int xrows16, wrows16;                             // rows rounded up to 16 (packed operands)
+    int gm;                                           // M tiles per group of the tile order (as in gemm_wreg.hip)
+    int w_f16;                                        // the (packed) weight operand is stored in MIXQ_FMT_F16X64, not P16X64
     unsigned long long* trace;                        // diagnostics: 2 x 8 timestamps per workgroup, or null
 };
 
@@ -112,7 +114,15 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
         const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, x = b & 7, s = b >> 3;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;          // bijective for any ntiles
     }
-    const int tn = tile / a.tiles_m, tm = tile - tn * a.tiles_m;               // m fastest: weight panel shared
+    // groups of gm M tiles, M fastest inside a group, then N (gemm_wreg.hip explains why: at prefill sizes the CUs of an XCD then share
+    // a few weight panels AND a few activation slabs instead of one panel and 32 slabs)
+    int tm, tn;
+    {
+        const int per_group = a.gm * a.tiles_n, grp = tile / per_group, first_m = grp * a.gm;
+        const int gsz = a.tiles_m - first_m < a.gm ? a.tiles_m - first_m : a.gm;
+        const int r = tile - grp * per_group;
+        tn = r / gsz; tm = first_m + (r - tn * gsz);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -154,7 +164,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64) void gemm_kerne
             const bool packed = is_w ? a.w_packed : a.x_packed;
             if (packed) {
                 int rb = (row0 + r) >> 4; rb = rb < (rows16 >> 4) ? rb : (rows16 >> 4) - 1;
-                nsrc[i] = base + static_cast<size_t>(rb) * 1024 + (r & 15) * 64 + pc * 16;
+                // P16X64: the memory image of a block IS the LDS image (row r, physical chunk pc at r*64 + pc*16).  F16X64 (the one
+                // weight image an operator keeps, fragment order c*256 + r*16): the same bytes sit at logical chunk c = swz(r, pc) -
+                // 16-byte pieces of one KiB block, still whole cache lines per wave instruction - and land in the same LDS image
+                if (is_w && a.w_f16) nsrc[i] = base + static_cast<size_t>(rb) * 1024 + swz(r & 15, pc) * 256 + (r & 15) * 16;
+                else                 nsrc[i] = base + static_cast<size_t>(rb) * 1024 + (r & 15) * 64 + pc * 16;
                 kstr[i] = rows16 * 64;
             } else {
                 int gr = row0 + r; gr = gr < rows ? gr : rows - 1;
@@ -839,13 +853,24 @@ int pick_stream_k(int M, int N, int KB) {
     return 3;                                            // sk128x128_w2x2_s5
 }
 
-int launch_gemm(GemmArgs& a, int mode, hipStream_t st) {
+// Prefill rule (M >= 1024, int8, fragment-order weights): rounds over the 256 CUs of the 256 x 256 tiling, at 2 x 0.9 of a 128 x 256
+// round each (measured: 4096 x 11008 x 4096 181 vs 200 us, 8192 x 11008 358 vs 368, 4096 x 4096 69.6 vs 72.6; 2048 x 11008 111 vs 103 and
+// 2048 x 28672 x 8192 433 vs 411 the other way - there the 128 x 256 tile count fills its last round better)
+constexpr int LDS256 = 13;                           // 256x256_w4x2_s5_l0
+bool prefill_prefers_lds256(int M, int N) {
+    if (M < 1024) return false;
+    const int t256 = cdiv(M, 256) * cdiv(N, 256), t128 = cdiv(M, 128) * cdiv(N, 256);
+    return t256 >= 200 && 1.8 * cdiv(t256, 256) < 1.0 * cdiv(t128, 256);
+}
+
+int launch_gemm(GemmArgs& a, int mode, hipStream_t st, int cfg = -1) {
     const bool packed = a.x_packed && a.w_packed;
     const int forced = g_forced_cfg.get();
-    const int c = (forced >= 0 && forced < NUM_CFGS) ? forced : pick_config(a.M, a.N, a.KB, packed);
+    const int c = cfg >= 0 ? cfg : ((forced >= 0 && forced < NUM_CFGS) ? forced : pick_config(a.M, a.N, a.KB, packed));
     const GemmConfig* g = &g_cfgs[c];
     a.tiles_m = cdiv(a.M, g->bm);
     a.tiles_n = cdiv(a.N, g->bn);
+    a.gm = a.tiles_m <= 8 ? a.tiles_m : 8;
     a.trace = g_trace;
     void (*k)(const GemmArgs) = mode == 0 ? g->k8 : (mode == 1 ? g->k4 : g->k32);
     const size_t shm = static_cast<size_t>(g->bm + g->bn) * BKB * g->nstage;
@@ -898,11 +923,18 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
         }
         if (g_forced == skinny_id) return MIXQ_EINVAL;
     }
-    // fragment-order weights: the weights-in-registers kernels (gemm_wreg.hip)
+    // fragment-order weights: the weights-in-registers kernels (gemm_wreg.hip) - except at prefill sizes, where the LDS-staged
+    // 256 x 256 tiling of this file (8 waves of 64 x 128, cfg LDS256) is 2.5-9 % ahead once its tile count quantises no worse
+    // (profiles/r03_prefill_ab.txt); it reads the same F16X64 weight image through a remapped DMA source
     if (wf16) {
         int c;
         if (g_forced >= wr0) c = g_forced - wr0;
-        else if (g_forced >= 0) return MIXQ_EINVAL;  // a P16X64 / plain tiling was forced: wrong operand layout
+        else if (g_forced >= NUM_CFGS) return MIXQ_EINVAL;               // a stream-K form was forced: it takes P16X64 weights only
+        else if (g_forced >= 0 || (bit == 8 && !row_amax && prefill_prefers_lds256(M, N))) {
+            if (row_amax) return MIXQ_ESHAPE;
+            a.w_packed = 1; a.w_f16 = 1;
+            return launch_gemm(a, bit == 8 ? 0 : 1, mixq_stream(stream), g_forced >= 0 ? g_forced : LDS256);
+        }
         else c = mixq_wr_pick(bit, M, N, KB);
         return mixq_wr_launch(c, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                               ldy, M, N, KB, act, g_trace, mixq_stream(stream), row_amax, amax_mask);
@@ -951,6 +983,7 @@ extern "C" int mixq_gemm_amax_supported(int M, int N, int K, int layout)
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || !(layout & MIXQ_W_F16X64) || !(layout & MIXQ_X_PACKED)) return 0;
     const bool wide_wr = N >= 8192;
     if (!wide_wr && mixq_skinny_applies(8, M, N, K, true, true)) return 0;
+    if (prefill_prefers_lds256(M, N)) return 0;                  // the LDS-staged prefill tiling is worth more than the side output
     return 1;
 }
 
@@ -1034,7 +1067,7 @@ extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) 
     const int dec = NUM_CFGS + mixq_sk_num_configs();
     const bool wide_wr = fmt == MIXQ_FMT_F16X64 && bit == 8 && N >= 8192;                 // as in gemm_fused_common
     if (!wide_wr && fmt != MIXQ_FMT_PLAIN && mixq_skinny_applies(bit, M, N, KB, true, true)) return dec;
-    if (fmt == MIXQ_FMT_F16X64) return dec + 1 + mixq_wr_pick(bit, M, N, KB);
+    if (fmt == MIXQ_FMT_F16X64) return (bit == 8 && prefill_prefers_lds256(M, N)) ? LDS256 : dec + 1 + mixq_wr_pick(bit, M, N, KB);
     return mixq_gemm_pick_config(M, N, K, bit);
 }
 

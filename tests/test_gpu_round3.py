@@ -329,3 +329,57 @@ def test_mlp_block_with_the_fused_row_maximum_is_bit_identical():
                 assert torch.equal(yg, y_ref)
     finally:
         fused.FUSE_DOWN_AMAX = prev
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the LDS-staged tilings read the operator's ONE weight image (fragment order) too; prefill batches route to the 256 x 256 one
+# ---------------------------------------------------------------------------------------------------------------
+def test_lds_staged_tilings_read_fragment_order_weights_bit_identically():
+    """Every tiling of gemm.hip with the weights in MIXQ_FMT_F16X64 (remapped DMA source) against the same tiling with P16X64 weights:
+    int8 and int4, ragged shapes, outlier tail, addend / SiLU / bias - identical bits (it is the same LDS image)."""
+    from test_gpu_parity import _fused_case, _run_fused, _tiled_configs, bits
+    lib = _capi.load()
+    names = _capi.gemm_config_names()
+    cases = [(100, 260, 512, 8, 17, True, True, 1), (257, 1000, 1024, 8, 41, False, False, 0), (33, 36, 320, 8, 3, True, False, 2),
+             (64, 128, 1024, 4, 128, False, False, 0), (130, 200, 512, 4, 16, True, True, 1), (512, 384, 256, 8, 0, False, False, 0)]
+    try:
+        for (M, N, K, bit, n_out, bias, addend, act) in cases:
+            c = _fused_case(M, N, K, bit, seed=M + N + K, n_out=n_out, bias=bias, addend=addend or act == 2, act=act)
+            for cfg in _tiled_configs():
+                assert lib.mixq_gemm_set_config(cfg) == 0
+                y1 = n(_run_fused(c, 1))
+                y2 = n(_run_fused(c, 2))
+                assert np.array_equal(bits(y1), bits(y2)), (names[cfg], M, N, K, bit)
+    finally:
+        lib.mixq_gemm_set_config(-1)
+
+
+def test_prefill_batches_route_to_the_256x256_tiling_and_stay_exact():
+    """4096 tokens x 4096 -> 4096 with fragment-order weights: the automatic choice is the LDS-staged 256 x 256 tiling (same weight image),
+    the product is exact against the integer reference, and the operator agrees with the oracle on sampled rows."""
+    lib = _capi.load()
+    names = _capi.gemm_config_names()
+    M, N, K = 4096, 4096, 4096
+    assert names[lib.mixq_gemm_pick_config_fmt(M, N, K, 8, 2)] == "256x256_w4x2_s5_l0"
+    assert names[lib.mixq_gemm_pick_config_fmt(2048, 11008, 4096, 8, 2)].startswith("wr128x256")
+    assert lib.mixq_gemm_amax_supported(M, N, K, _capi.X_PACKED | _capi.W_F16X64) == 0
+    g = torch.Generator().manual_seed(3)
+    qx = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    qw = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    sx = torch.full((M, 1), 2.0 ** -8, dtype=torch.float16, device=DEV)
+    sw = torch.full((1, N), 2.0 ** -8, dtype=torch.float16, device=DEV)
+    y = mixlib.FusedLinear(mixlib.PackOperand(qx, 1), mixlib.PackOperand(qw, 2), sx, sw, None, None, 0, None, M, N, K)
+    rows = torch.tensor([0, 1, 255, 256, 2047, 4095], device=DEV)
+    want = ((qx[rows].double() @ qw.double().T) * 2.0 ** -16).to(torch.float16)
+    assert torch.equal(y[rows], want)
+    layer, cache, cols = frozen_layer(M, K, N, 8, 41, False)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(12)).half()
+    x[:, cols] *= 20
+    yo = layer(x.to(DEV), None, True)
+    rs = [0, 2047, 4095]
+    xh = x.numpy()[rs].copy()
+    ind = n(layer.ind).astype(np.int32)
+    xo = O.extract_outliers_zero(xh, ind)
+    qxo, sxo = O.find_row_scale(xh, 8)
+    ref = O.linear_fused(qxo, n(layer.q_weight), sxo, n(layer.scale_col), xo=xo, wo=n(layer.weight_cache)).astype(np.float32)
+    assert (np.abs(n(yo)[rs].astype(np.float32) - ref) <= ulp_tol(ref)).all()

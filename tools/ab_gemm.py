@@ -26,7 +26,11 @@ names = _capi.gemm_config_names()
 M, N, K = (int(v) for v in args.shape.split("x"))
 g = torch.Generator().manual_seed(0)
 KB = K if args.bit == 8 else K // 2
-qx = torch.randint(-127, 128, (M, KB), generator=g, dtype=torch.int8).to(dev)
+if os.environ.get("AB_UNIFORM_X"):
+    qx = torch.randint(-127, 128, (M, KB), generator=g, dtype=torch.int8).to(dev)
+else:                                                   # the bench's operand statistics: activations quantised from N(0,1) rows (|q| <= 127,
+    xf = torch.randn(M, KB, generator=g)                # typically ~30): uniform +-127 bytes toggle more and cost clock (power limit)
+    qx = torch.round(xf / (xf.abs().amax(dim=1, keepdim=True) / 127)).to(torch.int8).to(dev)
 qw = torch.randint(-127, 128, (N, KB), generator=g, dtype=torch.int8).to(dev)
 if args.bit == 4:
     qx, qw = qx.view(torch.uint8), qw.view(torch.uint8)
