@@ -366,7 +366,7 @@ def main(argv=None):
         # ---- secondary timings, outside the timed region of `value` --------------------------------------
         eager_ms = cold_ms = None
         cold_note = None
-        if not args.no_secondary:
+        if not args.no_secondary and rank == 0:                 # (rank 0 only: the other ranks wait for it in the counter gather)
             # (a) the reference's own protocol, examples/benchbitsand.py:534-550: NO graph, 10 warm-up + 100 timed back-to-back
             # `layer(x)` calls from Python between two events - what a plain Hugging Face loop pays per layer, host cost included
             esteps = 100
