@@ -90,6 +90,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int ISSUERS = SELF ? CW : LOADERS;
     constexpr int LOADS = MB / ISSUERS;                  // DMA pieces per issuing wave and stage
     constexpr int OPITCH = BN * 2 + 16;
+    constexpr bool PREBIAS = !SELF && (MB * WNB * 4 + (D + 1) * WNB * 4 * (I4 ? 2 : 1) + MB * 4 + 40 <= 232);   // registers to spare for the bias prefetch
     constexpr int AMAX_OFF = (BM * OPITCH + 15) & ~15;   // LDS: [CW][4][BM] row maxima (one slot per wave and lane group), behind the staging tile
     constexpr int TQ = SELF ? 0 : 2;                     // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS
     constexpr int TAILX = NSTAGE * STAGE_BYTES;          // LDS offset of those blocks: behind the ring, [TQ][MB] x 1 KiB
@@ -177,7 +178,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         int nxt, kt = 0;
         if (RP < LOOK && nk >= 2 * LOOK) {
 #pragma unroll
-            for (int s = 0; s < RP; ++s) stage(s);
+            for (int s = 0; s < RP; ++s) { stage(s); if constexpr (ABL == 26 || ABL == 27) { if (s == 0) __builtin_amdgcn_s_sleep(8); } }
             wr_wait_vmcnt<LOADS * (RP - 1)>();
             __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
             wr_static_for<0, LOOK - RP>([&](auto i_c) MIXQ_INL {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     const int nw0 = n0 + wave * WN;                                              // first weight row of this wave (wave < CW)
     i32x4 acc[MB][WNB];
     uint16_t sxh[MB];
-    u32x2 swp[WNB];
+    u32x2 swp[WNB], bvp[WNB];                                                    // scale_col and bias of this wave's columns, requested with the scales
     int n_out_dev_v = 0;
 
     if (wave < CW) {
@@ -430,6 +431,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             for (int i = 0; i < WNB; ++i) {
                 const int n = nw0 + i * 16 + lq * 4;                             // N % 4 == 0: 4 columns are all in or all out
                 swp[i] = *reinterpret_cast<const u32x2_u*>(a.sw + (n < a.N ? n : a.N - 4));
+                // (in the epilogue this load is an exposed round trip: 1.7 us per forward with a bias; tiles without 8 spare registers keep it there)
+                if constexpr (PREBIAS) bvp[i] = a.bias ? *reinterpret_cast<const u32x2_u*>(a.bias + (n < a.N ? n : a.N - 4)) : u32x2{0u, 0u};
             }
         };
         if constexpr (!SELF) load_scales();
@@ -515,6 +518,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
             for (int i = 0; i < WNB; ++i) wload1(d_c, i, decltype(d_c)::value < nk ? 1 : 0);
             wadvance(decltype(d_c)::value < nk ? 1 : 0);
+            // probes: hold the requests of k-steps 1.. back so every CU's first k-step is served first
+            if constexpr (ABL == 25 || ABL == 26) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(8); }
+            if constexpr (ABL == 27) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(16); }
         };
         wr_static_for<0, D>(prologue_w);
         static_assert(D >= 2 && D <= 16 && WNB * (D - 1) < 64, "weight ring depth: run-time wait table / vmcnt range");
@@ -686,7 +692,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 const int nloc = wave * WN + i * 16 + lq * 4, n = n0 + nloc;
                 const int nc = n < a.N ? n : a.N - 4;
                 float bv[4];
-                if (OPT && has_bias) unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+                if (OPT && has_bias) {
+                    if constexpr (PREBIAS) unpack4(bvp[i], bv);
+                    else unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+                }
                 uint32_t keep_lo = 0x7fff7fffu, keep_hi = 0x7fff7fffu;            // |.| of the 4 halves; the next layer's outlier columns drop out
                 if (OPT && has_amax) {
                     // (columns past N are computed from clamped operands - values that exist nowhere in y - and count for nothing)
@@ -869,6 +878,9 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 22, "128x192_p22_paced"),
     MIXQ_WR(8, 3, 16, 4, 2, 23, "128x192_p23_wlate_paced"),
     MIXQ_WR(8, 3, 16, 4, 2, 24, "128x192_p24_paced2"),
+    MIXQ_WR(8, 3, 16, 4, 2, 25, "128x192_p25_w0first"),
+    MIXQ_WR(8, 3, 16, 4, 2, 26, "128x192_p26_w0x0first"),
+    MIXQ_WR(8, 3, 16, 4, 2, 27, "128x192_p27_w0x0first_long"),
     // EXPERIMENT (round 3, kept for the record, not shipped): the vendor library's prefill shape - 256 x 256 tiles, four fat
     // self-loading waves with 256 accumulator registers each (SELF form of the kernel), (16 + 16) KB of operands per k-step for
     // 4 x 64 MFMAs, half the L1 / L2 bytes per MFMA of 128 x 256.  Measured at 4096 x 11008 x 4096 without outlier columns: 186.1 us
