@@ -10,6 +10,11 @@ step    : ONE full forward of MixLinear_GEMM over one 512-token batch already re
           operator zeroes outlier columns in place, as the reference does), so no restore copy sits in the timed region.
 timing  : the K steps are ONE hipGraph; barrier + synchronize on both sides of the timed region; the clock is a pair of HIP
           events on the launch stream (the host wall time around the same region is reported beside it); MAX over ranks.
+          The metric is SUSTAINED throughput, and an MI355X needs 15-25 ms of continuous work to reach the clock it sustains
+          (measured: the same graph replayed from idle runs 33-34 us per step for its first 2-3 ms, 30.9 us from ~12 ms on), so
+          after the W warm-up steps and before the timed region the captured graph is replayed, untimed, for ~40 ms
+          (CLOCK_SETTLE_MS; the inputs are restored afterwards).  The timed region is still exactly the K steps; the figure of the
+          FIRST replay after idle is reported beside it (timing.first_replay_ms_per_step).
 N GPUs  : one process per GPU, no data-path collective, one all_gather of {elapsed, flops} at the end.
           --scaling weak (default): every rank runs the same K steps on its own 512-token batches;
           --scaling strong: the 512 rows are split over the ranks (bench.shard_rows), weights replicated.
@@ -36,6 +41,7 @@ PEAK_INT8_TOPS = 5033.0      # 256 CU x 8192 int8 op/clk/CU x 2.4 GHz (dense; MI
 M, K, N = 512, 4096, 11008   # BASELINE.json metric shape (Llama-2-7b up/gate projection, batch x seq = 512)
 OUTLIER_FRAC = 0.01
 SIGMA = 6
+CLOCK_SETTLE_MS = 40.0       # untimed graph replays in front of the timed region: the chip's clock needs this long to settle under load
 
 
 def parse(argv=None):
@@ -310,6 +316,7 @@ def main(argv=None):
 
     side = torch.cuda.Stream(device=device)
     graph = None
+    first_replay_ms, settle_reps = None, 0
     with torch.cuda.stream(side):
         for i in range(min(warm, steps)):                       # untimed warm-up steps (on buffers restored below)
             one_step(i)
@@ -321,7 +328,15 @@ def main(argv=None):
                 for i in range(steps):
                     one_step(i)
             torch.cuda.synchronize()
-            graph.replay()                                      # one untimed replay: graph upload, clocks
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(side)
+            graph.replay()                                      # first replay after idle: graph upload, cold clocks (reported, not `value`)
+            f1.record(side)
+            torch.cuda.synchronize()
+            first_replay_ms = f0.elapsed_time(f1)
+            settle_reps = min(4000, max(1, int(CLOCK_SETTLE_MS / max(first_replay_ms, 1e-3))))
+            for _ in range(settle_reps):                        # untimed: bring the chip to the clock it sustains under this load
+                graph.replay()
             torch.cuda.synchronize()
             pristine.copy_(base.unsqueeze(0).expand_as(pristine))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -354,7 +369,13 @@ def main(argv=None):
             for _ in range(gsteps):
                 layer._gemm(cache, rows, 0)
         torch.cuda.synchronize()
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record(side)
         gg.replay()
+        w1.record(side)
+        torch.cuda.synchronize()
+        for _ in range(0 if args.no_graph else min(4000, max(1, int(CLOCK_SETTLE_MS / max(w0.elapsed_time(w1), 1e-3))))):
+            gg.replay()                                         # the same clock conditioning as for the step (untimed)
         torch.cuda.synchronize()
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record(side)
@@ -445,6 +466,8 @@ def main(argv=None):
                        "weight_bytes_resident": int(layer._wpk.numel() + (0 if layer._buffers['q_weight'] is None else layer._buffers['q_weight'].numel()))},
             "timing": {"clock": "HIP events on the launch stream around the K steps", "host_wall_ms_per_step": round(max_host * 1e3 / steps, 5),
                        "per_rank_ms_per_step": [round(v * 1e3 / steps, 5) for v in per_rank],
+                       "clock_settle": None if graph is None else f"{settle_reps} untimed replays of the captured graph (~{CLOCK_SETTLE_MS:.0f} ms) between the warm-up and the timed region",
+                       "first_replay_ms_per_step": None if first_replay_ms is None else round(first_replay_ms / steps, 5),
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 5),
                        "eager_protocol": "no graph: 10 warm-up + 100 back-to-back layer(x) calls from Python between two events (examples/benchbitsand.py:534-550), rank 0",
                        "cold_weights_ms_per_step": None if cold_ms is None else round(cold_ms, 5), "cold_weights_protocol": cold_note},
