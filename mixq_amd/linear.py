@@ -490,7 +490,7 @@ class MixLinear_GEMM(nn.Module):
         M = inputs.shape[0]
         if unfused and not self.add_outliers and self.weight_only is False and ONE_CALL_FORWARD:
             # prediction frozen: extract + quantise + GEMM enqueued by one C call on a kept argument block; bit-identical to the
-            # route below (tests/test_gpu_parity.py::test_one_call_forward_is_bit_identical)
+            # route below (tests/test_gpu_round3.py::test_one_call_forward_is_bit_identical)
             key = self._frozen_key(cache, inputs, M)
             if self._plan_key != key:
                 self._plan = self._build_plan(cache, inputs, M)
@@ -500,7 +500,8 @@ class MixLinear_GEMM(nn.Module):
             plan = self._plan
             if plan is not None:
                 tag = getattr(x, "_mixq_row_amax", None)     # left by the GEMM that produced x (forward_without_preconditionFusedSilu)
-                if tag is not None and tag[1] is self and self._amax_dirty and tag[0] is self._amax_buf and tag[0].numel() >= M:
+                if tag is not None and tag[1] is self and self._amax_dirty and tag[0] is self._amax_buf and tag[0].numel() >= M \
+                        and tag[2] == x._version:            # (an in-place edit of x since the GEMM wrote it makes the maxima stale)
                     y1, cache.q_xcache, xo = plan.run(inputs, row_amax=tag[0], col_mask=self._col_mask())
                     self._amax_dirty = False                 # the quantiser cleared the buffer
                 else:
@@ -607,7 +608,7 @@ class MixLinear_GEMM(nn.Module):
             self.compact_weights_()
         out = y1.reshape(cache.shape)
         if target is not None:
-            out._mixq_row_amax = (target[0], amax_for)       # rides on the tensor handed to the consumer
+            out._mixq_row_amax = (target[0], amax_for, out._version)      # rides on the tensor handed to the consumer
         return out
 
 

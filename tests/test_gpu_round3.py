@@ -383,3 +383,41 @@ def test_prefill_batches_route_to_the_256x256_tiling_and_stay_exact():
     qxo, sxo = O.find_row_scale(xh, 8)
     ref = O.linear_fused(qxo, n(layer.q_weight), sxo, n(layer.scale_col), xo=xo, wo=n(layer.weight_cache)).astype(np.float32)
     assert (np.abs(n(yo)[rs].astype(np.float32) - ref) <= ulp_tol(ref)).all()
+
+
+def test_row_maximum_hand_over_is_dropped_when_the_activation_was_edited():
+    """The maxima gate_proj's GEMM leaves for down_proj describe the tensor as the GEMM wrote it: an in-place edit in between (what the
+    reference's own `gate_output *= up_output` would be) must send down_proj back to the two-pass quantiser - and the stale buffer is
+    cleaned before the next producer run."""
+    from mixq_amd import FasterTransformerRMSNorm
+    M, H, F = 64, 512, 1024
+    torch.manual_seed(0)
+    cache = MixLibCache(M, device=DEV)
+    mk = lambda k, nn_: MixLinear_GEMM.from_linear(torch.nn.Linear(k, nn_, bias=False).half(), 8, cache=cache, dev=DEV)
+    gate, up, down = mk(H, F), mk(H, F), mk(F, H)
+    norm = FasterTransformerRMSNorm(torch.ones(H).half().to(DEV), 1e-5, cache)
+    norm.next_layer = up
+    x = torch.randn(M, H, generator=torch.Generator().manual_seed(1)).half().to(DEV)
+    for _ in range(3):
+        h = norm(x.clone())
+        u = up(h, cache)
+        g = gate.forward_without_preconditionFusedSilu(h, cache)
+        g *= u
+        down(g, None, True)
+    assert not down.add_outliers
+    h = norm(x.clone())
+    u = up(h, cache)
+    g = gate.forward_without_preconditionFusedSilu(h, cache, amax_for=down)      # maxima of silu(gate) alone ...
+    assert getattr(g, "_mixq_row_amax", None) is not None and down._amax_dirty
+    g *= u                                                                        # ... but down_proj sees silu(gate) * up
+    y = down(g, None, True)
+    assert down._amax_dirty, "the stale maxima must not have been consumed"
+    h = norm(x.clone()); u = up(h, cache)                                         # (up_proj fills the shared cache again: shape, q_x)
+    g2 = gate.forward_without_preconditionFusedSilu(h, cache)
+    g2 *= u
+    assert torch.equal(y, down(g2, None, True))
+    h = norm(x.clone()); u = up(h, cache)
+    g3 = gate.forward_without_preconditionFusedSilu(h, cache, mul=u, amax_for=down)   # the next producer run starts from a clean buffer
+    y3 = down(g3, None, True)
+    assert not down._amax_dirty and int(down._amax_buf.abs().sum()) == 0
+    assert (y3.float() - y.float()).abs().max() < 0.05                              # (fused product: one rounding fewer than g *= u)
