@@ -249,6 +249,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     int n_out_dev_v = 0;
 
     if (wave < CW) {
+        if constexpr (ABL == 28) __builtin_amdgcn_s_setprio(3);                  // probe: the MFMA waves above the loaders
         if (a.n_out_dev) n_out_dev_v = *a.n_out_dev;
 #pragma unroll
         for (int j = 0; j < MB; ++j)
@@ -878,6 +879,9 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 22, "128x192_p22_paced"),
     MIXQ_WR(8, 3, 16, 4, 2, 23, "128x192_p23_wlate_paced"),
     MIXQ_WR(8, 3, 16, 4, 2, 24, "128x192_p24_paced2"),
+    MIXQ_WR(8, 3, 16, 4, 2, 28, "128x192_p28_prio"),
+    MIXQ_WR(8, 3, 16, 5, 2, 0, "128x192_s16_d5_l2"),
+    MIXQ_WR(8, 3, 16, 4, 4, 0, "128x192_s16_d4_l4"),
     MIXQ_WR(8, 3, 16, 4, 2, 25, "128x192_p25_w0first"),
     MIXQ_WR(8, 3, 16, 4, 2, 26, "128x192_p26_w0x0first"),
     MIXQ_WR(8, 3, 16, 4, 2, 27, "128x192_p27_w0x0first_long"),

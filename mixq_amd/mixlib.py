@@ -741,6 +741,8 @@ class ForwardPlan:
         if x_scale.numel() < M or scale_col.numel() < N:
             raise RuntimeError("ForwardPlan: x_scale / scale_col are shorter than M / N")
         n_cap = 0 if ind_buf is None else int(ind_buf.numel())
+        if n_cap:
+            ind_buf = _check_ind(ind_buf, "ForwardPlan")                # (int32, contiguous - before its address is taken)
         a = _capi.LinearArgs()
         a.ldx, a.M, a.N, a.K, a.bit, a.sigma, a.act = ldx, M, N, K, bit, float(sigma), act
         a.qfmt, a.wfmt = qfmt, fmt_of(q_w)
@@ -748,7 +750,6 @@ class ForwardPlan:
         a.x_scale, a.q_w, a.scale_col, a.bias = x_scale.data_ptr(), q_w.data_ptr(), scale_col.data_ptr(), _ptr(bias)
         self.ldxo = a.ldxo = _pad16(n_cap) if n_cap else 0
         if n_cap:
-            ind_buf = _check_ind(ind_buf, "ForwardPlan")
             wop, ldwo = _rows(w_out, "w_out")
             if ldwo < n_cap or ldwo % 8:
                 raise RuntimeError("ForwardPlan: w_out row stride must be >= the outlier capacity and a multiple of 8")
@@ -774,7 +775,7 @@ class ForwardPlan:
             xo = torch.empty((self.M, self.ldxo), dtype=torch.float16, device=dev)
             a.x_out = xo.data_ptr()
         a.x, a.q_x, a.y = x.data_ptr(), q.data_ptr(), y.data_ptr()
-        rc = self.fn(self.ref, torch.cuda.current_stream().cuda_stream)
+        rc = self.fn(self.ref, torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
             raise _capi.MixqError("mixq_linear_forward", rc)
         q._mixq_fmt = self.qfmt
