@@ -279,6 +279,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         constexpr int NSLOT = D + 1;
         i32x4 wq[NSLOT][WNB];
         i32x4 xf[MB];
+        i32x4 xc[2];                                     // (probe ABL 30: copies of the last two fragments)
 #pragma unroll
         for (int d = 0; d < NSLOT; ++d)
 #pragma unroll
@@ -392,6 +393,48 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (!I4) {
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
+                    if constexpr (ABL == 30 && MB >= 4 && WNB >= 3) {
+                        // probe: the k-step boundary drains ALL fragment reads (the compiler's lgkmcnt(0)), so the last re-read,
+                        // issued a few cycles before it, is an exposed LDS round trip per k-step.  The last two groups therefore run on
+                        // COPIES of their fragments taken at the top of the step, and those two fragments are re-read early (behind the
+                        // second MFMA of groups 0 and 1): the youngest read at the boundary is then six MFMAs old.
+                        if (j == 0) { xc[0] = xf[MB - 2]; xc[1] = xf[MB - 1]; asm volatile("" : "+v"(xc[0]), "+v"(xc[1])); }
+                        const i32x4 xb = j >= MB - 2 ? xc[j - (MB - 2)] : xf[j];
+                        acc[j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][0], xb, acc[j][0], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        loads_behind(j);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][1], xb, acc[j][1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (refill && j < 2) xread(rslot, MB - 2 + j);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 2; i < WNB; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][i], xb, acc[j][i], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (refill && j < MB - 2) xread(rslot, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
+                    if constexpr (ABL != 31) {
+                        // At most ONE memory instruction per MFMA gap: a wave issues in order and a 16-cycle MFMA leaves ~12 cycles in
+                        // which one fragment read or one weight load can be issued for free.  The weight load goes behind the group's
+                        // FIRST MFMA, the fragment's re-read behind its last use (round 2 put both behind the last).  Measured: -1.6 %
+                        // against the old order compiled into the same (tuning) library, 26.69 vs 26.79 us between two product builds
+                        // (profiles/r03_gemm_ab_issue_timing.txt, r03_ab_order_builds.txt): at the noise floor - co-compiled variants
+                        // perturb each other's code placement (cdna_hip_programming.md 5.4 rule 19) - kept because it is never worse.
+                        acc[j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][0], xf[j], acc[j][0], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        loads_behind(j);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 1; i < WNB; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][i], xf[j], acc[j][i], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (refill) xread(rslot, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
 #pragma unroll
                     for (int i = 0; i < WNB; ++i)
                         acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][i], xf[j], acc[j][i], 0, 0, 0);
@@ -880,6 +923,8 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 23, "128x192_p23_wlate_paced"),
     MIXQ_WR(8, 3, 16, 4, 2, 24, "128x192_p24_paced2"),
     MIXQ_WR(8, 3, 16, 4, 2, 28, "128x192_p28_prio"),
+    MIXQ_WR(8, 3, 16, 4, 2, 31, "128x192_p31_r2order"),   // round 2's order: re-read and weight load in the same gap
+    MIXQ_WR(8, 3, 16, 4, 2, 30, "128x192_p30_earlyreread"),
     MIXQ_WR(8, 3, 16, 5, 2, 0, "128x192_s16_d5_l2"),
     MIXQ_WR(8, 3, 16, 4, 4, 0, "128x192_s16_d4_l4"),
     MIXQ_WR(8, 3, 16, 4, 2, 25, "128x192_p25_w0first"),
