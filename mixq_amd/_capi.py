@@ -23,15 +23,18 @@ MIXQ_OK = 0
 MIXQ_EINVAL = -1
 MIXQ_ESHAPE = -2
 MIXQ_ENODEV = -3
+MIXQ_ERANGE = -4
 ACT_NONE = 0
 ACT_SILU = 1
 ACT_SILU_MUL = 2
 FMT_PLAIN = 0
 FMT_P16X64 = 1
 FMT_F16X64 = 2
+FMT_F6X128 = 3          # int4 as FP6 codes, fragment order: both operands of the W4A4 GEMM on the FP6 matrix pipe
 X_PACKED = 1
 W_PACKED = 2
 W_F16X64 = 8
+XW_F6X128 = 16
 
 
 class MixqBuildError(RuntimeError):
@@ -41,7 +44,7 @@ class MixqBuildError(RuntimeError):
 class MixqError(RuntimeError):
     def __init__(self, fn: str, code: int):
         names = {MIXQ_EINVAL: "MIXQ_EINVAL (bad argument)", MIXQ_ESHAPE: "MIXQ_ESHAPE (unsupported shape)",
-                 MIXQ_ENODEV: "MIXQ_ENODEV (no gfx950 device)"}
+                 MIXQ_ENODEV: "MIXQ_ENODEV (no gfx950 device)", MIXQ_ERANGE: "MIXQ_ERANGE (operand value outside the format's range)"}
         super().__init__(f"{fn} failed: {names.get(code, f'hipError_t {code}')}")
         self.code = code
 

@@ -9,6 +9,9 @@
 #include "../../include/mixq_hip.h"
 
 typedef int      i32x4  __attribute__((ext_vector_type(4)));
+typedef int      i32x2  __attribute__((ext_vector_type(2)));
+typedef int      i32x6  __attribute__((ext_vector_type(6)));
+typedef int      i32x8  __attribute__((ext_vector_type(8)));
 typedef int      i32x16 __attribute__((ext_vector_type(16)));
 typedef float    f32x4  __attribute__((ext_vector_type(4)));
 typedef float    f32x16 __attribute__((ext_vector_type(16)));
@@ -112,6 +115,33 @@ __device__ __forceinline__ size_t packed_offset(int fmt, int row, int kb, int ro
     const int r = row & 15, c = (kb & 63) >> 4;
     const size_t blk = (static_cast<size_t>(kb >> 6) * (rows16 >> 4) + (row >> 4)) * 1024;
     return blk + (fmt == MIXQ_FMT_F16X64 ? c * 256 + r * 16 : r * 64 + ((c ^ ((0 - (r >> 2)) & 3)) << 4)) + (kb & 15);
+}
+// ---- MIXQ_FMT_F6X128 (include/mixq_hip.h): int4 values as FP6 E2M3 codes ------------------------------------------------------
+// code of a two's-complement nibble of [-7, 7]: sign bit, then the magnitude's code 0 8 16 20 24 26 28 30 (halved: 0 4 8 a c d e f)
+__device__ __forceinline__ uint32_t f6_code_of_nibble(uint32_t nib) {
+    const uint32_t neg = nib & 8u, mag = neg ? (16u - nib) & 7u : nib;
+    return (neg << 2) | (((0xFEDCA840u >> (mag * 4)) & 0xfu) << 1);
+}
+__device__ __forceinline__ uint32_t f6_nibble_of_code(uint32_t code) {      // inverse (codes that are no integer map to their truncation)
+    const uint32_t mag = static_cast<uint32_t>((0x7654030200010000ull >> ((code & 0x1eu) << 1)) & 0xfu);
+    return (code & 0x20u) ? (16u - mag) & 0xfu : mag;
+}
+// byte address of the block of (row, element k) and the lane that owns the element's 32-element group
+__device__ __forceinline__ size_t f6_block_offset(int row, int k, int rows16) {
+    return (static_cast<size_t>(k >> 7) * (rows16 >> 4) + (row >> 4)) * 1536;
+}
+__device__ __forceinline__ int f6_lane(int row, int k) { return (((k & 127) >> 5) << 4) | (row & 15); }
+// eight consecutive codes (elements 8 c8 .. 8 c8 + 7 of a lane's 32, c8 = 0..3) = 48 bits at byte 6 c8 of the lane's 24-byte fragment,
+// which lives at blk + 16 lane (bytes 0..15) and blk + 1024 + 8 lane (bytes 16..23)
+__device__ __forceinline__ void f6_store8(uint8_t* blk, int lane, int c8, const uint32_t (&code)[8]) {
+    const uint32_t lo = code[0] | (code[1] << 6) | (code[2] << 12) | (code[3] << 18) | (code[4] << 24) | (code[5] << 30);
+    const uint32_t hi = (code[5] >> 2) | (code[6] << 4) | (code[7] << 10);                   // 16 bits
+    uint8_t* A = blk + lane * 16;
+    uint8_t* B = blk + 1024 + lane * 8;
+    if (c8 == 0)      { *reinterpret_cast<uint32_t*>(A) = lo;      *reinterpret_cast<uint16_t*>(A + 4) = static_cast<uint16_t>(hi); }
+    else if (c8 == 1) { *reinterpret_cast<uint16_t*>(A + 6) = static_cast<uint16_t>(lo); *reinterpret_cast<uint32_t*>(A + 8) = (lo >> 16) | (hi << 16); }
+    else if (c8 == 2) { *reinterpret_cast<uint32_t*>(A + 12) = lo; *reinterpret_cast<uint16_t*>(B) = static_cast<uint16_t>(hi); }
+    else              { *reinterpret_cast<uint16_t*>(B + 2) = static_cast<uint16_t>(lo); *reinterpret_cast<uint32_t*>(B + 4) = (lo >> 16) | (hi << 16); }
 }
 __device__ __forceinline__ int wave_id_uniform() {
     return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);

@@ -884,6 +884,8 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
                       const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int K,
                       int act, int layout, int bit, mixq_stream_t stream, uint32_t* row_amax = nullptr, const uint32_t* amax_mask = nullptr)
 {
+    const bool f6 = layout == MIXQ_XW_F6X128;                    // both operands as FP6 codes: the W4A4 form on the FP6 matrix pipe
+    if (f6) { if (bit != 4) return MIXQ_EINVAL; layout = 0; }
     if (layout & ~(MIXQ_X_PACKED | MIXQ_W_PACKED | MIXQ_W_F16X64)) return MIXQ_EINVAL;
     if ((layout & MIXQ_W_PACKED) && (layout & MIXQ_W_F16X64)) return MIXQ_EINVAL;
     const bool wf16 = layout & MIXQ_W_F16X64;
@@ -911,6 +913,13 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     const int sk_num = mixq_sk_num_configs();
     const int skinny_id = NUM_CFGS + sk_num, wr0 = skinny_id + 1;
     const int g_forced = g_forced_cfg.get();                     // this device's forced configuration (-1: automatic)
+    if (f6) {
+        if (row_amax) return MIXQ_ESHAPE;
+        if (g_forced >= 0 && g_forced < wr0) return MIXQ_EINVAL;                // only the weights-in-registers kernels read this format
+        const int c = g_forced >= wr0 ? g_forced - wr0 : mixq_wr_pick(6, M, N, KB);
+        return mixq_wr_launch(c, 6, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+                              ldy, M, N, KB, act, g_trace, mixq_stream(stream), nullptr, nullptr);
+    }
     // small-batch form (gemm_skinny.hip): M <= 32, packed operands (either packed layout): a weight stream, no LDS staging
     {
         const bool both_packed = a.x_packed && (a.w_packed || wf16);
@@ -1067,6 +1076,7 @@ extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) 
     const int dec = NUM_CFGS + mixq_sk_num_configs();
     const bool wide_wr = fmt == MIXQ_FMT_F16X64 && bit == 8 && N >= 8192;                 // as in gemm_fused_common
     if (!wide_wr && fmt != MIXQ_FMT_PLAIN && mixq_skinny_applies(bit, M, N, KB, true, true)) return dec;
+    if (fmt == MIXQ_FMT_F6X128) return bit == 4 ? dec + 1 + mixq_wr_pick(6, M, N, KB) : MIXQ_EINVAL;
     if (fmt == MIXQ_FMT_F16X64) return (bit == 8 && prefill_prefers_lds256(M, N)) ? LDS256 : dec + 1 + mixq_wr_pick(bit, M, N, KB);
     return mixq_gemm_pick_config(M, N, K, bit);
 }

@@ -71,30 +71,42 @@ template <int I, int N, class F> __device__ __forceinline__ void wr_static_for(F
 }
 
 // MB: 16-row activation blocks per tile (BM = 16 MB), WNB: 16-row weight blocks per wave (BN = 64 WNB), NSTAGE: X ring depth,
-// D: weight register ring depth (k-steps), I4: nibble-packed operands, LOADERS: DMA waves, ABL (tuning): 0 normal,
+// D: weight register ring depth (k-steps), Q: operand coding (0 int8; 1 nibble-packed int4, expanded to int8 in registers; 2 int4
+// carried as FP6 codes on the FP6 matrix pipe, MIXQ_FMT_F6X128 operands, k-steps of 128 elements), LOADERS: DMA waves, ABL (tuning): 0 normal,
 // 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only, 4 weight loads issued but never waited for, 5 the loader
 // never waits for its DMA, 6 no k-loop barriers (4-6: timing probes, results are garbage), 7 no stores of Y, 8 ordinary instead of
 // nt stores, 9 return at entry, 12 no prologue ramp in the loader.
-template <int MB, int WNB, int NSTAGE, int D, bool I4, int LOADERS, int ABL>
+template <int MB, int WNB, int NSTAGE, int D, int Q, int LOADERS, int ABL>
 __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const WrArgs a)
 {
     constexpr int CW = WR_CW;
     constexpr int NT = (CW + LOADERS) * 64;
     constexpr int BM = MB * 16, WN = WNB * 16, BN = CW * WN;
-    constexpr int STAGE_BYTES = MB * 1024;
+    // F6: the W4A4 form on the FP6 matrix pipe.  Every integer of [-7, 7] is an FP6 E2M3 value, products are integers <= 49 and
+    // the fp32 accumulator is exact below 2^24, so v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales computes the int4
+    // contraction bit-exactly (tools/ubench_fp6.hip: K up to 262144, worst-case operands) at 1.6x the MACs per cycle of
+    // v_mfma_i32_16x16x64_i8 - gfx950 has no int4 MFMA, and the nibble form (Q = 1) pays the int8 rate plus the expansion.
+    // Operand blocks are 16 rows x 128 elements = 1.5 KiB in fragment order (MIXQ_FMT_F6X128, include/mixq_hip.h): a lane's 24 bytes
+    // are a 16-byte piece at block + 16 lane and an 8-byte piece at block + 1024 + 8 lane.
+    constexpr bool I4 = Q == 1, F6 = Q == 2;
+    constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
+    constexpr int STAGE_BYTES = MB * BLK;
     constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
     // SELF (LOADERS = 0, the prefill form): four FAT waves, one per SIMD with the whole 512-entry register file each (256 accumulator
     // registers at MB x WNB = 16 x 4: a 256 x 256 tile), and no room for loader waves - a fifth wave would halve every wave's register
     // budget - so each consumer wave issues its quarter of the activation DMA itself, between its MFMAs.
     constexpr bool SELF = LOADERS == 0;
     constexpr int ISSUERS = SELF ? CW : LOADERS;
-    constexpr int LOADS = MB / ISSUERS;                  // DMA pieces per issuing wave and stage
+    constexpr int LOADS = STAGE_BYTES / 1024 / ISSUERS;  // 1 KiB DMA pieces per issuing wave and stage
+    constexpr int TLOADS = MB / ISSUERS;                 // the fp16 tail's X_out blocks per issuing wave
+    constexpr int WL = F6 ? 2 * WNB : WNB;               // load instructions of one k-step's weight fragments (per wave)
     constexpr int OPITCH = BN * 2 + 16;
-    constexpr bool PREBIAS = !SELF && (MB * WNB * 4 + (D + 1) * WNB * 4 * (I4 ? 2 : 1) + MB * 4 + 40 <= 232);   // registers to spare for the bias prefetch
+    constexpr bool PREBIAS = !SELF && (MB * WNB * 4 + (D + 1) * WNB * (F6 ? 6 : 4) * (I4 ? 2 : 1) + MB * (F6 ? 6 : 4) + 40 <= 232);   // registers to spare for the bias prefetch
     constexpr int AMAX_OFF = (BM * OPITCH + 15) & ~15;   // LDS: [CW][4][BM] row maxima (one slot per wave and lane group), behind the staging tile
     constexpr int TQ = SELF ? 0 : 2;                     // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS
     constexpr int TAILX = NSTAGE * STAGE_BYTES;          // LDS offset of those blocks: behind the ring, [TQ][MB] x 1 KiB
-    static_assert(MB % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
+    static_assert(MB % ISSUERS == 0 && (STAGE_BYTES / 1024) % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
+    static_assert(!F6 || (!SELF && ABL == 0), "the FP6 form exists for the shipped loop only");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
     static_assert(!SELF || (LOOK == D + 1 && !I4 && ABL == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
     static_assert((NSTAGE + TQ) * STAGE_BYTES <= 160 * 1024, "X ring + tail blocks must fit the 160 KiB of LDS");
@@ -152,11 +164,17 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const int p = lw + i * LOADERS;
-            int rb = (m0 >> 4) + p; rb = rb < a.xblocks ? rb : a.xblocks - 1;      // blocks past M: loaded, computed, dropped
-            src[i] = a.qx + static_cast<size_t>(rb) * 1024 + lane * 16;
+            if constexpr (F6) {                            // 1 KiB pieces of a stage of 1.5 KiB blocks: a piece may straddle two blocks
+                const int o = p * 1024 + lane * 16, blk = o / BLK, within = o - blk * BLK;
+                int rb = (m0 >> 4) + blk; rb = rb < a.xblocks ? rb : a.xblocks - 1;
+                src[i] = a.qx + static_cast<size_t>(rb) * BLK + within;
+            } else {
+                int rb = (m0 >> 4) + p; rb = rb < a.xblocks ? rb : a.xblocks - 1;  // blocks past M: loaded, computed, dropped
+                src[i] = a.qx + static_cast<size_t>(rb) * 1024 + lane * 16;
+            }
             dsto[i] = p * 1024;
         }
-        const size_t xks = static_cast<size_t>(a.xblocks) * 1024;
+        const size_t xks = static_cast<size_t>(a.xblocks) * BLK;
         int xk = rot;                                    // k-step the next stage reads
         size_t xoff = static_cast<size_t>(rot) * xks;
         auto stage = [&](int slot) MIXQ_INL {
@@ -218,7 +236,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             for (int kk = 0; kk < TQ; ++kk) {
                 if (kk < tsteps) {
 #pragma unroll
-                    for (int i = 0; i < LOADS; ++i) {
+                    for (int i = 0; i < TLOADS; ++i) {
                         const int p = lw + i * LOADERS;
                         int xr = m0 + p * 16 + (lane & 15); xr = xr < a.M ? xr : a.M - 1;
                         int col = kk * 32 + (lane >> 4) * 8; col = col < kpad_l ? col : 0;        // chunks past the padded width: any valid address (masked later)
@@ -243,7 +261,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // =================================================================================================================
     const int lm = lane & 15, lq = lane >> 4;
     const int nw0 = n0 + wave * WN;                                              // first weight row of this wave (wave < CW)
-    i32x4 acc[MB][WNB];
+    using acc_t = std::conditional_t<F6, f32x4, i32x4>;                          // (FP6 pipe: fp32 accumulators holding exact integers)
+    acc_t acc[MB][WNB];
     uint16_t sxh[MB];
     u32x2 swp[WNB], bvp[WNB];                                                    // scale_col and bias of this wave's columns, requested with the scales
     int n_out_dev_v = 0;
@@ -254,22 +273,22 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
         for (int j = 0; j < MB; ++j)
 #pragma unroll
-            for (int i = 0; i < WNB; ++i) acc[j][i] = i32x4{0, 0, 0, 0};
+            for (int i = 0; i < WNB; ++i) acc[j][i] = acc_t{0, 0, 0, 0};
 
         // weight stream: wave-uniform block bases (scalar registers), one lane offset
         const uint8_t* wb[WNB];
 #pragma unroll
         for (int i = 0; i < WNB; ++i) {
             int rb = (nw0 >> 4) + i; rb = rb < a.wblocks ? rb : a.wblocks - 1;      // blocks past N: computed and dropped
-            wb[i] = a.qw + static_cast<size_t>(rb) * 1024;
+            wb[i] = a.qw + static_cast<size_t>(rb) * BLK;
         }
-        const size_t wks = static_cast<size_t>(a.wblocks) * 1024;
+        const size_t wks = static_cast<size_t>(a.wblocks) * BLK;
         int wk = rot;                                    // k-step the next weight loads read
         size_t woff = static_cast<size_t>(rot) * wks;
         auto wadvance = [&](int cond) MIXQ_INL {                    // once per requested k-step (cond: wave-uniform 0 / 1)
             if (cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
         };
-        const int lane16 = lane * 16;
+        const int lane16 = lane * 16, lane8 = lane * 8;
         // activation fragment (row lm, k-chunk lq) inside a P16X64 block: conflict-free by the layout's swizzle (common.h)
         const int xoff = lm * 64 + ((lq ^ ((0 - (lm >> 2)) & 3)) << 4);
         // Weight register ring: NSLOT = D + 1 slots.  k-step kt is consumed from slot kt % NSLOT while the loads of k-step kt + D
@@ -279,12 +298,20 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         constexpr int NSLOT = D + 1;
         i32x4 wq[NSLOT][WNB];
         i32x4 xf[MB];
+        i32x2 wq2[F6 ? NSLOT : 1][F6 ? WNB : 1];                                 // F6: the 8-byte pieces of the 24-byte weight fragments
+        // F6: activation fragments as the 6-register operand tuples - a rotating window of XR of a k-step's MB fragments (all MB would
+        // not fit next to 6-register weight fragments: 256 registers per wave at 6 waves per CU).  Group j runs on window slot j % XR and
+        // requests fragment j + XR behind its last MFMA - of this stage, or of the next one (landed: the k-step's barrier) once j + XR >= MB.
+        constexpr int XR = F6 ? (MB < 4 ? MB : 4) : 1;
+        i32x6 xf6[XR];
+        static_assert(!F6 || MB % XR == 0, "window slots must be compile-time");
         i32x4 xc[2];                                     // (probe ABL 30: copies of the last two fragments)
 #pragma unroll
         for (int d = 0; d < NSLOT; ++d)
 #pragma unroll
             for (int i = 0; i < WNB; ++i) {
                 wq[d][i] = i32x4{lane, lane, lane, lane};
+                if constexpr (F6) wq2[d][i] = i32x2{lane, lane};
                 if constexpr (ABL != 0) asm volatile("" : "+v"(wq[d][i]));
             }
         if constexpr (ABL != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
@@ -304,6 +331,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];                     // (named outside the statement: implicit capture does not look into asm operands)
                 const int l16 = lane16;
+                if constexpr (F6) {
+                    i32x2& dst2 = wq2[d][i];
+                    const int l8 = lane8;
+                    asm volatile("s_cmp_eq_u32 %5, 0\n\ts_cbranch_scc1 1f\n\tglobal_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:1024\n1:"
+                                 : "+v"(dst), "+v"(dst2) : "v"(l16), "v"(l8), "s"(src), "s"(cs) : "memory", "scc");
+                } else
                 asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\tglobal_load_dwordx4 %0, %1, %2\n1:"
                              : "+v"(dst) : "v"(l16), "s"(src), "s"(cs) : "memory", "scc");
             }
@@ -314,6 +347,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];
                 const int l16 = lane16;
+                if constexpr (F6) {
+                    i32x2& dst2 = wq2[d][i];
+                    const int l8 = lane8;
+                    asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:1024"
+                                 : "+v"(dst), "+v"(dst2) : "v"(l16), "v"(l8), "s"(src) : "memory");
+                } else
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(l16), "s"(src) : "memory");
             }
         };
@@ -326,6 +365,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 if constexpr (WNB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wq[d][0]), "+v"(wq[d][1]) : "i"(CNT));
                 if constexpr (WNB == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]) : "i"(CNT));
                 if constexpr (WNB == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]), "+v"(wq[d][3]) : "i"(CNT));
+                if constexpr (F6) {                        // (volatile statements keep their order: the 8-byte pieces are "defined" behind the wait as well)
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) asm volatile("" : "+v"(wq2[d][i]));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -344,14 +387,18 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 MIXQ_WR_W2(104, c4) MIXQ_WR_W2(105, c5) MIXQ_WR_W2(106, c6) MIXQ_WR_W2(107, c7) MIXQ_WR_W2(108, c8) MIXQ_WR_W2(109, c9)      \
                 MIXQ_WR_W2(110, c10) MIXQ_WR_W2(111, c11) MIXQ_WR_W2(112, c12) MIXQ_WR_W2(113, c13) MIXQ_WR_W2(114, c14) "199:"
 #define MIXQ_WR_CL(v) ((v) < 64 ? (v) : 63)
-#define MIXQ_WR_WAIT_IN [sel] "s"(sel), [c1] "i"(MIXQ_WR_CL(WNB)), [c2] "i"(MIXQ_WR_CL(2 * WNB)), [c3] "i"(MIXQ_WR_CL(3 * WNB)),               \
-                [c4] "i"(MIXQ_WR_CL(4 * WNB)), [c5] "i"(MIXQ_WR_CL(5 * WNB)), [c6] "i"(MIXQ_WR_CL(6 * WNB)), [c7] "i"(MIXQ_WR_CL(7 * WNB)),      \
-                [c8] "i"(MIXQ_WR_CL(8 * WNB)), [c9] "i"(MIXQ_WR_CL(9 * WNB)), [c10] "i"(MIXQ_WR_CL(10 * WNB)), [c11] "i"(MIXQ_WR_CL(11 * WNB)), \
-                [c12] "i"(MIXQ_WR_CL(12 * WNB)), [c13] "i"(MIXQ_WR_CL(13 * WNB)), [c14] "i"(MIXQ_WR_CL(14 * WNB)), [c15] "i"(MIXQ_WR_CL(15 * WNB))
+#define MIXQ_WR_WAIT_IN [sel] "s"(sel), [c1] "i"(MIXQ_WR_CL(WL)), [c2] "i"(MIXQ_WR_CL(2 * WL)), [c3] "i"(MIXQ_WR_CL(3 * WL)),               \
+                [c4] "i"(MIXQ_WR_CL(4 * WL)), [c5] "i"(MIXQ_WR_CL(5 * WL)), [c6] "i"(MIXQ_WR_CL(6 * WL)), [c7] "i"(MIXQ_WR_CL(7 * WL)),      \
+                [c8] "i"(MIXQ_WR_CL(8 * WL)), [c9] "i"(MIXQ_WR_CL(9 * WL)), [c10] "i"(MIXQ_WR_CL(10 * WL)), [c11] "i"(MIXQ_WR_CL(11 * WL)), \
+                [c12] "i"(MIXQ_WR_CL(12 * WL)), [c13] "i"(MIXQ_WR_CL(13 * WL)), [c14] "i"(MIXQ_WR_CL(14 * WL)), [c15] "i"(MIXQ_WR_CL(15 * WL))
                 if constexpr (WNB == 1) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]) : MIXQ_WR_WAIT_IN : "scc");
                 if constexpr (WNB == 2) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]) : MIXQ_WR_WAIT_IN : "scc");
                 if constexpr (WNB == 3) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]) : MIXQ_WR_WAIT_IN : "scc");
                 if constexpr (WNB == 4) asm volatile(MIXQ_WR_WAITS : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]), "+v"(wq[d][3]) : MIXQ_WR_WAIT_IN : "scc");
+                if constexpr (F6) {
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) asm volatile("" : "+v"(wq2[d][i]));
+                }
 #undef MIXQ_WR_WAITS
 #undef MIXQ_WR_WAIT_IN
 #undef MIXQ_WR_W1
@@ -361,6 +408,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             }
         };
         auto xread = [&](int slot, int j) MIXQ_INL {
+            if constexpr (F6) {
+                const i32x4 p4 = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * BLK + lane16);
+                const i32x2 p2 = *reinterpret_cast<const i32x2*>(lds + slot * STAGE_BYTES + j * BLK + 1024 + lane8);
+                xf6[j % XR] = i32x6{p4[0], p4[1], p4[2], p4[3], p2[0], p2[1]};
+            } else
             if constexpr (ABL != 2 && ABL != 3)
                 xf[j] = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * 1024 + xoff);
         };
@@ -390,7 +442,47 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     if (pos == j) { if constexpr (FULL) wload1_always(LC{}, i); else wload1(LC{}, i, issue); }
                 }
             };
-            if constexpr (!I4) {
+            if constexpr (F6) {
+                // Same order as the int8 loop: weight load behind the group's first MFMA, the fragment's re-read behind its last.
+                // The MFMA is inline asm: the compiler's form of the scaled MFMA is not tied (vdst != srcC, accumulators rotating through
+                // VGPRs), which runs at 32 cycles instead of 19.5 (tools/ubench_fp6.hip) and doubles the accumulator footprint.  In asm
+                // the accumulators stay in place in the AGPR half.  The hazard recogniser does not look into asm, so: the weight
+                // tuples are assembled (v_mov) and pinned BEFORE a scheduling barrier and two wait states; activation tuples come
+                // straight from LDS reads (waited for by the compiler: the asm names them as inputs); consecutive MFMAs never share
+                // an accumulator (24 MFMAs lie between two uses of one).  Accumulators are VGPRs ("+v", in place): with an AGPR class in
+                // play the allocator splits the 256 registers of a wave 128 / 128, and 128 VGPRs do not hold the rings.
+                i32x6 w6[WNB];
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) {
+                    w6[i] = i32x6{wq[C][i][0], wq[C][i][1], wq[C][i][2], wq[C][i][3], wq2[C][i][0], wq2[C][i][1]};
+#if defined(__HIP_DEVICE_COMPILE__)                  // (the host pass parses kernel bodies too and knows no 192-bit "v" operand)
+                    asm volatile("" : "+v"(w6[i]));
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 1" ::: "memory");
+                const int unit = 0x7f7f7f7f;                                       // E8M0 block scales of 2^0
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MIXQ_F6_MMA(ACC, W, X) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:2 blgp:2" \
+                                            : "+v"(ACC) : "v"(W), "v"(X), "v"(unit))
+#else
+#define MIXQ_F6_MMA(ACC, W, X) (void)unit
+#endif
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    MIXQ_F6_MMA(acc[j][0], w6[0], xf6[j % XR]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    loads_behind(j);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 1; i < WNB; ++i) MIXQ_F6_MMA(acc[j][i], w6[i], xf6[j % XR]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + XR < MB) xread(rslot == 0 ? NSTAGE - 1 : rslot - 1, j + XR);   // (this stage: the slot before stage kt+1's)
+                    else if (refill) xread(rslot, j + XR - MB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef MIXQ_F6_MMA
+            } else if constexpr (!I4) {
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
                     if constexpr (ABL == 30 && MB >= 4 && WNB >= 3) {
@@ -567,21 +659,21 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (ABL == 27) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(16); }
         };
         wr_static_for<0, D>(prologue_w);
-        static_assert(D >= 2 && D <= 16 && WNB * (D - 1) < 64, "weight ring depth: run-time wait table / vmcnt range");
+        static_assert(D >= 2 && D <= 16 && WL * (D - 1) < 64, "weight ring depth: run-time wait table / vmcnt range");
         __builtin_amdgcn_s_barrier();                                            // B0
         stamp(1);
         // every scalar (kernel-argument) load has long returned; telling the compiler's counter model so keeps the loop
         // header from merging "SMEM pending" with the LDS reads in flight into an lgkmcnt(0) per group
         __builtin_amdgcn_s_waitcnt(0xC07F);                                      // lgkmcnt(0)
 #pragma unroll
-        for (int j = 0; j < MB; ++j) xread(0, j);
+        for (int j = 0; j < (F6 ? XR : MB); ++j) xread(0, j);
 
         // ---- k loop: unrolled by NSLOT so ring slots are compile-time registers ----------------------------------------
         int kt = 0, slot1 = 1 % NSTAGE;                                          // ring slot of stage kt+1
         auto one = [&](auto c_c, auto full_c) MIXQ_INL {
             constexpr bool FULL = decltype(full_c)::value;                       // FULL: stage kt+1 and k-step kt+D exist
             if constexpr (FULL) {
-                if constexpr (ABL != 4) wwait(c_c, std::integral_constant<int, WNB * (D - 1)>{});   // the D-1 younger k-steps stay in flight
+                if constexpr (ABL != 4) wwait(c_c, std::integral_constant<int, WL * (D - 1)>{});    // the D-1 younger k-steps stay in flight
                 if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();            // stage kt+1 landed; stage kt-2's slot is free
                 step(c_c, full_c, true, 1, slot1);
             } else {
@@ -601,6 +693,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             auto tail_one = [&](auto c_c) MIXQ_INL { if (k0 + decltype(c_c)::value < nk) one(c_c, std::false_type{}); };
             wr_static_for<0, NSLOT>(tail_one);
         }
+        if constexpr (F6) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // asm MFMA -> accumulator reads: wait states the compiler cannot count
         stamp(2);
         }
     }
@@ -882,23 +975,30 @@ struct WrConfig {
     int mb, wnb, nstage, loaders;
     void (*k8)(const WrArgs);
     void (*k4)(const WrArgs);
+    void (*k6)(const WrArgs);                          // int4 as FP6 codes (MIXQ_FMT_F6X128 operands); nullptr: tiling not built in that form
+    int nstage6;                                      // its X ring depth (k-steps of 128 elements, 1.5 KiB blocks)
 };
 // (the int4 form expands nibbles in registers: 2 (MB + WNB) more fragment registers, so its weight ring is at most 4 deep)
 #define MIXQ_WR(MBv, WNBv, NS, Dv, LD, ABL, TAG)                                                                        \
-    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, false, LD, ABL>,                                 \
-      gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), true, LD, ABL> }
+    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, ABL>,                                     \
+      gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, ABL>, nullptr, 0 }
+// ... and with the FP6 form: X ring of NS6 stages (12 KiB each at 128 rows), weight ring of 3 k-steps (a k-step is 128 elements)
+#define MIXQ_WR6(MBv, WNBv, NS, Dv, LD, NS6, TAG)                                                                       \
+    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 0>,                                       \
+      gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, 0>,                \
+      gemm_wreg_kernel<MBv, WNBv, NS6, 3, 2, LD, 0>, NS6 }
 
 const WrConfig g_wr[] = {
     // name = tile (activation rows x weight rows) _ X ring depth _ weight ring depth _ loader waves
-    MIXQ_WR(8, 3, 16, 4, 2, 0, "128x192_s16_d4_l2"),   // 0: the metric shape's tile: 232 tiles at 512 x 11008
+    MIXQ_WR6(8, 3, 16, 4, 2, 8, "128x192_s16_d4_l2"),  // 0: the metric shape's tile: 232 tiles at 512 x 11008
     MIXQ_WR(8, 3, 16, 3, 2, 0, "128x192_s16_d3_l2"),   // 1
     MIXQ_WR(8, 3, 8, 4, 1, 0, "128x192_s8_d4_l1"),     // 2: the first form of this kernel (8-deep X ring, one loader)
     MIXQ_WR(8, 3, 12, 4, 2, 0, "128x192_s12_d4_l2"),   // 3
-    MIXQ_WR(8, 2, 16, 4, 2, 0, "128x128_s16_d4_l2"),   // 4
+    MIXQ_WR6(8, 2, 16, 4, 2, 8, "128x128_s16_d4_l2"),  // 4
     MIXQ_WR(8, 4, 16, 3, 2, 0, "128x256_s16_d3_l2"),   // 5 (int4: weight ring depth 2)
-    MIXQ_WR(4, 2, 16, 4, 2, 0, "64x128_s16_d4_l2"),    // 6: N = 4096 at M = 512 is exactly 256 such tiles
-    MIXQ_WR(4, 3, 16, 4, 2, 0, "64x192_s16_d4_l2"),    // 7: N = 6144
-    MIXQ_WR(4, 4, 16, 4, 2, 0, "64x256_s16_d4_l2"),    // 8
+    MIXQ_WR6(4, 2, 16, 4, 2, 12, "64x128_s16_d4_l2"),  // 6: N = 4096 at M = 512 is exactly 256 such tiles
+    MIXQ_WR6(4, 3, 16, 4, 2, 12, "64x192_s16_d4_l2"),  // 7: N = 6144
+    MIXQ_WR6(4, 4, 16, 4, 2, 12, "64x256_s16_d4_l2"),  // 8
     MIXQ_WR(8, 1, 8, 4, 1, 0, "128x64_s8_d4_l1"),      // 9
     MIXQ_WR(4, 1, 8, 4, 1, 0, "64x64_s8_d4_l1"),       // 10
     MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 11
@@ -936,7 +1036,7 @@ const WrConfig g_wr[] = {
     // against 191.3 us for 128 x 256 (profiles/r03_prefill_ab.txt) - the loop is not feed-bound there, the part is at its 1.4 kW
     // power cap either way - and its one-register-set tail costs 33 us with 41 outlier columns.  Known fault: memory access
     // violation at M = 8192 and with > 64 outlier columns.  int8 only.
-    { "wr256x256_s6_d3_self", 16, 4, 6, 0, gemm_wreg_kernel<16, 4, 6, 3, false, 0, 0>, nullptr },
+    { "wr256x256_s6_d3_self", 16, 4, 6, 0, gemm_wreg_kernel<16, 4, 6, 3, 0, 0, 0>, nullptr, nullptr, 0 },
 #endif
 };
 constexpr int WR_SMALL = 14;
@@ -965,7 +1065,21 @@ const char* mixq_wr_config_name(int c) { return (c >= 0 && c < NUM_WR) ? g_wr[c]
 // 14 k and 28 k).
 int mixq_wr_pick(int bit, int M, int N, int KB)
 {
-    (void)bit;
+    if (bit == 6) {
+        // FP6 form (k-steps of 128 elements): the tilings that exist in it, priced with the int8 model's shape - until a sweep says
+        // otherwise the tile count decides, as it does for int8
+        static const struct { int cfg; float tk, fixed; } cand6[] = {
+            {0, 0.37f, 10.0f}, {4, 0.304f, 7.5f}, {6, 0.23f, 5.1f}, {7, 0.29f, 5.9f}, {8, 0.35f, 6.5f}};   // (128 x 256 does not fit the registers in this form)
+        const int nk6 = KB >> 6;
+        double best6 = 1e30; int b6 = 0;
+        for (const auto& c : cand6) {
+            const WrConfig& g = g_wr[c.cfg];
+            const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
+            const double t = cdiv(tiles, 256) * (nk6 * static_cast<double>(c.tk) + c.fixed);
+            if (t < best6 * 0.999) { best6 = t; b6 = c.cfg; }
+        }
+        return b6;
+    }
     if (M <= 32) return WR_SMALL;                        // (narrow layers run the weight-stream kernel of gemm_skinny.hip instead)
     static const struct { int cfg; float tk, fixed; } cand[] = {
         {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f},
@@ -984,6 +1098,7 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
     return bi;
 }
 
+// bit: 8, 4 (nibble-packed operands) or 6 (int4 as FP6 codes, MIXQ_FMT_F6X128 operands; KB is K / 2 as for bit 4)
 int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
@@ -1008,9 +1123,9 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     }
     a.trace = trace;
     a.row_amax = row_amax; a.amax_mask = amax_mask;
-    void (*k)(const WrArgs) = bit == 8 ? g.k8 : g.k4;
-    if (!k) return MIXQ_EINVAL;                                                  // (the prefill tiles have no nibble form)
-    const size_t ring = static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
+    void (*k)(const WrArgs) = bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4);
+    if (!k) return MIXQ_EINVAL;                                                  // (the prefill tiles have no nibble form, few tilings an FP6 form)
+    const size_t ring = bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 2 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
     const size_t shm = ring > stg ? ring : stg;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3((WR_CW + g.loaders) * 64), shm, st, a);

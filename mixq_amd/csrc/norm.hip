@@ -156,6 +156,12 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
                 o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
                 const size_t off = fmt ? packed_offset(fmt, row, c * 8, rows16) : static_cast<size_t>(row) * K + c * 8;
                 *reinterpret_cast<uint2*>(qb + off) = o;
+            } else if (fmt == MIXQ_FMT_F6X128) {                   // FP6 codes in fragment order (include/mixq_hip.h)
+                uint32_t code[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) code[e] = f6_code_of_nibble(static_cast<uint32_t>(qv[e]) & 0xfu);
+                const int k = c * 8;
+                f6_store8(reinterpret_cast<uint8_t*>(qb) + f6_block_offset(row, k, rows16), f6_lane(row, k), (k & 31) >> 3, code);
             } else {
                 uint32_t o = 0;
 #pragma unroll
@@ -207,7 +213,7 @@ extern "C" int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weigh
 {
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !weight || !out || !x_scale || !q))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !(qfmt == MIXQ_FMT_F6X128 && bit == 4)) return MIXQ_EINVAL;
     if (n > 0 && (!ind || !x_out || ldxo < n)) return MIXQ_EINVAL;
     if ((K & 7) || (ldx & 7) || (ldout & 7) || ldx < K || ldout < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;

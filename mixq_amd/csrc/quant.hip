@@ -60,6 +60,12 @@ __device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, 
         o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
         if (fmt) *reinterpret_cast<uint2*>(static_cast<char*>(q) + packed_offset(fmt, row, chunk * 8, rows16)) = o;
         else     reinterpret_cast<uint2*>(q)[chunk] = o;
+    } else if (fmt == MIXQ_FMT_F6X128) {   // FP6 codes in fragment order (include/mixq_hip.h): chunk = elements 8 chunk .. + 7 of the row
+        uint32_t code[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) code[i] = f6_code_of_nibble(static_cast<uint32_t>(qv[i]) & 0xfu);
+        const int k = chunk * 8;
+        f6_store8(static_cast<uint8_t*>(q) + f6_block_offset(row, k, rows16), f6_lane(row, k), (k & 31) >> 3, code);
     } else {   // nibble pack: low nibble = even column (linear.py:14-18)
         uint32_t o = 0;
 #pragma unroll
@@ -459,6 +465,56 @@ __global__ __launch_bounds__(QT) void repack_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// The same for MIXQ_FMT_F6X128: one thread per lane fragment (row, 32-element group): 16 bytes of nibbles <-> 24 bytes of FP6 codes.
+// Packing counts the nibbles -8 it meets (no E2M3 value) into *bad.
+template <bool UNPACK>
+__global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R, int K,
+                                                       int rows16, unsigned int* __restrict__ bad)
+{
+    const long long t = static_cast<long long>(blockIdx.x) * QT + threadIdx.x;
+    const long long total = static_cast<long long>(rows16) * (K >> 5);
+    if (t >= total) return;
+    const int lane = static_cast<int>(t & 63);
+    const long long b = t >> 6;                                   // block index: kb128 * (rows16 / 16) + rb
+    const int nrb = rows16 >> 4, kb = static_cast<int>(b / nrb), rb = static_cast<int>(b - static_cast<long long>(kb) * nrb);
+    const int row = rb * 16 + (lane & 15), k0 = kb * 128 + (lane >> 4) * 32;
+    const size_t blk = static_cast<size_t>(b) * 1536;
+    const size_t plain = static_cast<size_t>(row) * (K >> 1) + (k0 >> 1);
+    if constexpr (UNPACK) {
+        if (row >= R) return;
+        const uint4 a = *reinterpret_cast<const uint4*>(src + blk + lane * 16);
+        const uint2 c = *reinterpret_cast<const uint2*>(src + blk + 1024 + lane * 8);
+        const uint32_t w[6] = {a.x, a.y, a.z, a.w, c.x, c.y};
+        uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int bit = 6 * e, wi = bit >> 5, sh = bit & 31;
+            uint32_t code = w[wi] >> sh;
+            if (sh > 26) code |= w[wi + 1] << (32 - sh);
+            o[e >> 3] |= f6_nibble_of_code(code & 0x3fu) << (4 * (e & 7));
+        }
+        *reinterpret_cast<uint4*>(dst + plain) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < R) v = *reinterpret_cast<const uint4*>(src + plain);
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+        uint32_t w[7] = {0, 0, 0, 0, 0, 0, 0};
+        unsigned int nbad = 0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const uint32_t nib = (in[e >> 3] >> (4 * (e & 7))) & 0xfu;
+            nbad += nib == 8u;
+            const uint32_t code = f6_code_of_nibble(nib);
+            const int bit = 6 * e, wi = bit >> 5, sh = bit & 31;
+            w[wi] |= code << sh;
+            if (sh > 26) w[wi + 1] |= code >> (32 - sh);
+        }
+        *reinterpret_cast<uint4*>(dst + blk + lane * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint2*>(dst + blk + 1024 + lane * 8) = make_uint2(w[4], w[5]);
+        if (nbad && bad) atomicAdd(bad, nbad);
+    }
+}
+
 // Launch geometry of the extract + scale + quantise pass: 0 = the round-1 kernel (256 threads, one row per workgroup), 1.. =
 // quant_rows2_kernel as (threads per row, rows per workgroup); -1 = choose by shape.  Tuning / test knob: mixq_quant_set_config.
 MixqDevInt g_quant_cfg(-1);             // per device (common.h)
@@ -569,7 +625,7 @@ extern "C" int mixq_selftest_quant_exact(unsigned long long* mismatches_dev, int
 extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q, int M, int K, int ldx, int bit, int qfmt,
                                    mixq_stream_t stream)
 {
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !(qfmt == MIXQ_FMT_F6X128 && bit == 4)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || (M > 0 && (!x || !x_scale || !q))) return MIXQ_EINVAL;   // empty inputs may carry null pointers
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
@@ -584,7 +640,7 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
                                 uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt,
                                 mixq_stream_t stream)
 {
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !(qfmt == MIXQ_FMT_F6X128 && bit == 4)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !x_scale || !q))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
@@ -603,7 +659,7 @@ extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, con
                                      const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K,
                                      int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream)
 {
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !(qfmt == MIXQ_FMT_F6X128 && bit == 4)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !x_scale || !q || !row_amax))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
@@ -676,10 +732,36 @@ extern "C" int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col
 static int repack_common(const void* src, void* dst, int R, int KB, int fmt, bool unpack, mixq_stream_t stream)
 {
     if (!src || !dst || R < 0 || KB <= 0) return MIXQ_EINVAL;
-    if (fmt != MIXQ_FMT_P16X64 && fmt != MIXQ_FMT_F16X64) return MIXQ_EINVAL;
+    if (fmt != MIXQ_FMT_P16X64 && fmt != MIXQ_FMT_F16X64 && fmt != MIXQ_FMT_F6X128) return MIXQ_EINVAL;
     if (KB % 64) return MIXQ_ESHAPE;
     if (R == 0) return MIXQ_OK;
     const int rows16 = (R + 15) & ~15;
+    if (fmt == MIXQ_FMT_F6X128) {
+        // KB = K / 2 bytes of nibbles per row.  Packing is a once-per-layer, synchronous operation here (not capturable in a graph):
+        // the count of -8 nibbles comes back to the host so that the caller learns the operand does not fit the format.
+        const int K = KB * 2;
+        const long long total = static_cast<long long>(rows16) * (K >> 5);
+        const dim3 g(static_cast<unsigned>((total + QT - 1) / QT));
+        hipStream_t st = mixq_stream(stream);
+        if (unpack) {
+            hipLaunchKernelGGL(repack_f6_kernel<true>, g, dim3(QT), 0, st, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), R, K, rows16,
+                               static_cast<unsigned int*>(nullptr));
+            return mixq_launch_status();
+        }
+        unsigned int* bad = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&bad), sizeof(unsigned int)) != hipSuccess) return MIXQ_ENODEV;
+        unsigned int h = 0;
+        int rc = MIXQ_OK;
+        if (hipMemsetAsync(bad, 0, sizeof(unsigned int), st) != hipSuccess) rc = MIXQ_ENODEV;
+        if (rc == MIXQ_OK) {
+            hipLaunchKernelGGL(repack_f6_kernel<false>, g, dim3(QT), 0, st, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), R, K, rows16, bad);
+            rc = mixq_launch_status();
+        }
+        if (rc == MIXQ_OK && (hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = MIXQ_ENODEV;
+        (void)hipFree(bad);
+        if (rc != MIXQ_OK) return rc;
+        return h ? MIXQ_ERANGE : MIXQ_OK;
+    }
     const long long total = static_cast<long long>(rows16) * (KB >> 4);
     const dim3 g(static_cast<unsigned>((total + QT - 1) / QT));
     if (unpack) hipLaunchKernelGGL(repack_kernel<true>, g, dim3(QT), 0, mixq_stream(stream), static_cast<const uint8_t*>(src),

@@ -22,7 +22,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import mixlib as _hip_mixlib
-from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64
+from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, MIXQ_ERANGE
 
 # The kernel backend.  Always the HIP module in the product; tests that exercise the host-side state machine on a
 # machine without a GPU swap in an oracle-backed stand-in (tests/backend_oracle.py) via `set_backend`.
@@ -39,6 +39,12 @@ def set_backend(mod):
 # Packed layout new layers keep their weights in (and ask their activations in): MIXQ_FMT_F16X64 feeds the
 # weights-in-registers GEMM of gemm_wreg.hip, MIXQ_FMT_P16X64 the LDS-staged one of gemm.hip (include/mixq_hip.h).
 PACK_FMT = FMT_F16X64
+# ... and 4-bit layers: MIXQ_FMT_F6X128 - both operands as FP6 E2M3 codes, the W4A4 GEMM on the FP6 matrix pipe (gfx950 has no int4
+# MFMA; every integer of [-7, 7] is an E2M3 value and the fp32 accumulator is exact, so the result is the int4 contraction bit for
+# bit at 1.6x the int8 MFMA rate: 22.9 vs 27.6 us at 512 x 4096 -> 11008, 24.9 vs 32.3 us at 11008 -> 4096).  FMT_P16X64 selects the
+# int8-expansion kernel instead (nibbles, half the weight bytes of the FP6 image: the better trade for weight-stream-bound decode);
+# a layer whose weights hold the nibble -8 (no E2M3 value; symmetric 4-bit quantisation never produces it) falls back to it.
+PACK_FMT4 = FMT_F6X128
 # After a layer's outlier search has frozen, keep ONLY the packed weight image in HBM (the plain [N,K] `q_weight` is
 # re-created on demand for state_dict / attribute reads).  False keeps both copies (2x the reference's weight memory).
 COMPACT_WEIGHTS = True
@@ -330,7 +336,10 @@ class MixLinear_GEMM(nn.Module):
     def x_fmt(self):
         """Layout this layer wants its quantised activation in (what a fused norm in front of it should emit)."""
         wpk = self._packed_weight()
-        return FMT_P16X64 if wpk is not None else FMT_PLAIN         # (fragment-order weights go with P16X64 activations too)
+        if wpk is None:
+            return FMT_PLAIN
+        # fragment-order int8 weights go with P16X64 activations; the FP6 form takes both operands in F6X128
+        return FMT_F6X128 if _fmt_of(wpk) == FMT_F6X128 else FMT_P16X64
 
     def _packed_weight(self):
         """q_weight in the tile-major layout the GEMM streams fastest (include/mixq_hip.h); rebuilt when the buffer is
@@ -340,12 +349,17 @@ class MixLinear_GEMM(nn.Module):
             return self._wpk                                             # compacted: the packed image is all there is
         if qw.shape[1] % 64 or not hasattr(_backend, "PackOperand"):
             return None
-        # W4A4 stays with the LDS-staged kernel (P16X64 weights): its nibble expansion hides behind 32-cycle MFMAs there, not
-        # behind the 16-cycle ones of the weights-in-registers kernel (28.0 vs 32.4 us at the metric shape, interleaved A/B)
-        fmt = PACK_FMT if self.bit == 8 else FMT_P16X64
+        # W4A4: FP6 codes for the FP6 matrix pipe (PACK_FMT4); as nibbles it stays with the LDS-staged kernel (P16X64 weights), whose
+        # nibble expansion hides behind 32-cycle MFMAs, not behind the 16-cycle ones of the weights-in-registers kernel (28.0 vs 32.4 us)
+        fmt = PACK_FMT if self.bit == 8 else PACK_FMT4
         key = (id(qw), qw.data_ptr(), qw._version, fmt)
         if self._wpk is None or self._wpk_key != key:
-            self._wpk = _backend.PackOperand(qw, fmt)
+            try:
+                self._wpk = _backend.PackOperand(qw, fmt)
+            except RuntimeError as e:
+                if fmt != FMT_F6X128 or getattr(e, "code", None) != MIXQ_ERANGE:
+                    raise
+                self._wpk = _backend.PackOperand(qw, FMT_P16X64)         # a -8 among the nibbles: the int8-expansion kernel serves it
             self._wpk_key = key
         return self._wpk
 
@@ -612,8 +626,33 @@ class MixLinear_GEMM(nn.Module):
         return out
 
 
+_F6_NIBBLE = None
+
+
+def _unpack_host_f6(packed, R):
+    """Nibble-packed [R, K/2] matrix of an F6X128 image held in HOST memory (include/mixq_hip.h)."""
+    global _F6_NIBBLE
+    if _F6_NIBBLE is None:
+        lut = torch.zeros(64, dtype=torch.uint8)
+        for v, code in enumerate((0x00, 0x08, 0x10, 0x14, 0x18, 0x1a, 0x1c, 0x1e)):
+            lut[code] = v
+            lut[code | 0x20] = (16 - v) & 0xF
+        _F6_NIBBLE = lut
+    rows16, B = packed.shape
+    K = B * 4 // 3
+    blocks = packed.reshape(K // 128, rows16 // 16, 1536).to(torch.int64)
+    frag = torch.cat([blocks[..., :1024].reshape(K // 128, rows16 // 16, 64, 16), blocks[..., 1024:].reshape(K // 128, rows16 // 16, 64, 8)], dim=-1)
+    tri = frag.reshape(K // 128, rows16 // 16, 64, 8, 3)                                     # 3 bytes = 4 codes
+    v = tri[..., 0] | (tri[..., 1] << 8) | (tri[..., 2] << 16)
+    codes = torch.stack([(v >> (6 * i)) & 63 for i in range(4)], dim=-1).reshape(K // 128, rows16 // 16, 4, 16, 32)   # [kb, rb, g, r, e]
+    nib = _F6_NIBBLE[codes].permute(1, 3, 0, 2, 4).reshape(rows16, K)                         # [rb, r, kb, g, e] -> row, k
+    return (nib[:, 0::2] | (nib[:, 1::2] << 4))[:R].contiguous()
+
+
 def _unpack_host(packed, R, fmt):
-    """Plain [R,KB] matrix of a packed image held in HOST memory (include/mixq_hip.h: P16X64 / F16X64 block layouts)."""
+    """Plain [R,KB] matrix of a packed image held in HOST memory (include/mixq_hip.h: P16X64 / F16X64 / F6X128 block layouts)."""
+    if fmt == FMT_F6X128:
+        return _unpack_host_f6(packed, R)
     rows16, KB = packed.shape
     blocks = packed.reshape(KB // 64, rows16 // 16, 1024)
     if fmt == FMT_F16X64:                                                # byte c*256 + r*16 + b

@@ -15,7 +15,8 @@ from __future__ import annotations
 import torch
 
 from . import _capi
-from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, X_PACKED, W_PACKED, W_F16X64
+from ._capi import (ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, X_PACKED, W_PACKED, W_F16X64,
+                    XW_F6X128)
 
 
 def _dev_check(*ts):
@@ -66,6 +67,10 @@ def fmt_of(t):
 
 
 def _layout_bits(x_fmt, w_fmt):
+    if x_fmt == FMT_F6X128 or w_fmt == FMT_F6X128:
+        if x_fmt != w_fmt:
+            raise RuntimeError("mixq_amd.mixlib: the FP6 form of the W4A4 GEMM takes BOTH operands in F6X128")
+        return XW_F6X128
     if x_fmt == FMT_F16X64:
         raise RuntimeError("mixq_amd.mixlib: F16X64 is a weight format; the GEMMs take activations plain or in P16X64")
     return ({FMT_PLAIN: 0, FMT_P16X64: X_PACKED}[x_fmt] | {FMT_PLAIN: 0, FMT_P16X64: W_PACKED, FMT_F16X64: W_F16X64}[w_fmt])
@@ -573,7 +578,8 @@ def PackOperand(q, fmt=FMT_P16X64):
     if q.dim() != 2 or not q.is_contiguous() or q.element_size() != 1:
         raise RuntimeError("PackOperand: expected a contiguous 2-D int8/uint8 tensor")
     R, KB = q.shape
-    out = torch.empty((packed_rows(R), KB), dtype=q.dtype, device=q.device)
+    # (F6X128: KB = K / 2 bytes of nibbles per row in, 3 K / 4 bytes of FP6 codes per row out; raises when the operand holds a -8)
+    out = torch.empty((packed_rows(R), KB * 3 // 2 if fmt == FMT_F6X128 else KB), dtype=q.dtype, device=q.device)
     _capi.call("mixq_pack_operand", q.data_ptr(), out.data_ptr(), R, KB, fmt, _stream())
     return set_fmt(out, fmt)
 
@@ -586,12 +592,21 @@ def UnpackOperand(packed, R, fmt=None):
     """Inverse of PackOperand: the plain [R,KB] matrix of a packed image."""
     _dev_check(packed)
     fmt = fmt_of(packed) if fmt is None else fmt
-    if fmt not in (FMT_P16X64, FMT_F16X64):
+    if fmt not in (FMT_P16X64, FMT_F16X64, FMT_F6X128):
         raise RuntimeError("UnpackOperand: the tensor carries no packed-format tag; pass fmt")
-    KB = packed.shape[1]
+    KB = packed.shape[1] * 2 // 3 if fmt == FMT_F6X128 else packed.shape[1]
     out = torch.empty((R, KB), dtype=packed.dtype, device=packed.device)
     _capi.call("mixq_unpack_operand", packed.data_ptr(), out.data_ptr(), R, KB, fmt, _stream())
     return out
+
+
+def _q_row_bytes(K, bit, fmt):
+    """Bytes per row of a quantised activation buffer: K int8, K / 2 nibbles, or 3 K / 4 FP6 codes."""
+    if fmt == FMT_F6X128:
+        if bit != 4:
+            raise RuntimeError("mixq_amd.mixlib: F6X128 is an int4 format")
+        return K * 3 // 4
+    return K if bit == 8 else K // 2
 
 
 def _want_fmt(packed, fmt):
@@ -614,7 +629,7 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
     if x_scale.numel() < M:
         raise RuntimeError(f"QuantFused: x_scale holds {x_scale.numel()} rows, the batch has {M} (MixLibCache.inputdim too small)")
     n = 0 if ind is None else ind.numel()
-    q = torch.empty((packed_rows(M) if fmt else M, K if bit == 8 else K // 2),
+    q = torch.empty((packed_rows(M) if fmt else M, _q_row_bytes(K, bit, fmt)),
                     dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
     if n:
         ind = _check_ind(ind, "QuantFused")
@@ -636,7 +651,7 @@ def FindRowScalePacked(x, x_scale, M, K, bit=8, fmt=FMT_P16X64):
     xp, ldx = _rows(x, "x")
     if x_scale.numel() < M:
         raise RuntimeError(f"FindRowScalePacked: x_scale holds {x_scale.numel()} rows, the batch has {M}")
-    q = torch.empty((packed_rows(M), K if bit == 8 else K // 2), dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
+    q = torch.empty((packed_rows(M), _q_row_bytes(K, bit, fmt)), dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
     _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), q.data_ptr(), M, K, ldx, bit, fmt, _stream())
     return set_fmt(q, fmt)
 
@@ -758,8 +773,7 @@ class ForwardPlan:
         self.args, self.ref, self.fn = a, C.byref(a), _capi.load().mixq_linear_forward
         self.keep = (ind_buf, n_dev, x_scale, q_w, scale_col, w_out, bias)
         self.M, self.N, self.n, self.qfmt, self.device = M, N, n, qfmt, x_scale.device
-        KB = K if bit == 8 else K // 2
-        self.q_shape, self.q_dtype = (packed_rows(M) if qfmt else M, KB), (torch.int8 if bit == 8 else torch.uint8)
+        self.q_shape, self.q_dtype = (packed_rows(M) if qfmt else M, _q_row_bytes(K, bit, qfmt)), (torch.int8 if bit == 8 else torch.uint8)
 
     def run(self, x, row_amax=None, col_mask=None):
         """x: fp16 [M,K] with the row stride the plan was built for.  Returns (y [M,N], q_x, x_out [M,n] or None).
@@ -809,7 +823,7 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
     if x_scale.numel() < M:
         raise RuntimeError(f"RMSNormQuantFused: x_scale holds {x_scale.numel()} rows, the batch has {M}")
     n = 0 if ind is None else ind.numel()
-    q = torch.empty((packed_rows(M) if fmt else M, K if bit == 8 else K // 2),
+    q = torch.empty((packed_rows(M) if fmt else M, _q_row_bytes(K, bit, fmt)),
                     dtype=torch.int8 if bit == 8 else torch.uint8, device=x.device)
     if n:
         ind = _check_ind(ind, "RMSNormQuantFused")
