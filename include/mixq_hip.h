@@ -37,7 +37,6 @@ extern "C" {
 #define MIXQ_EINVAL (-1)     /* bad argument (null pointer, bit not in {4,8}, negative size ...) */
 #define MIXQ_ESHAPE (-2)     /* shape not supported by the kernels (see each function) */
 #define MIXQ_ENODEV (-3)     /* no gfx950 device / kernel image not loadable on the current device */
-#define MIXQ_ERANGE (-4)     /* operand value outside what the requested format can hold (mixq_pack_operand to MIXQ_FMT_F6X128) */
 
 #define MIXQ_ACT_NONE 0
 #define MIXQ_ACT_SILU 1      /* SiLU on (dequant + outlier + addend), bias added afterwards (linear.py:324-373) */
@@ -63,18 +62,18 @@ extern "C" {
  *                   global_load_dwordx4 with no LDS round trip.  (Activations stay in P16X64: the quantise kernels write a
  *                   row's 64 bytes contiguously.) */
 #define MIXQ_FMT_F16X64 2
-/* MIXQ_FMT_F6X128 : int4 operands (bit = 4 only, values of [-7, 7] - what symmetric 4-bit quantisation produces) stored as FP6 E2M3
- *                   codes in fragment order, for BOTH operands of the W4A4 GEMM on the FP6 matrix pipe: gfx950 has no int4 MFMA, but
- *                   every integer of [-7, 7] is an E2M3 value (sign | 2-bit exponent, bias 1 | 3-bit mantissa: 0 1 2 3 4 5 6 7 =
- *                   0x00 0x08 0x10 0x14 0x18 0x1a 0x1c 0x1e), the products are integers and the fp32 accumulator is exact below
- *                   2^24, so v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales returns the int4 x int4 -> int32 contraction
- *                   bit for bit at 1.6x the rate of the int8 MFMA (profiles/r03_ubench_fp6.txt).  [K/128][rows16/16] blocks of
- *                   16 rows x 128 elements = 1536 bytes.  Lane l of a wave owns row l & 15, elements 32 (l >> 4) .. + 31 of the
- *                   block: 32 six-bit codes as a little-endian bit stream (element e at bit 6 e) = 24 bytes, stored as a 16-byte
- *                   piece at block + 16 l and an 8-byte piece at block + 1024 + 8 l (one dwordx4 + one dwordx2 per lane, both
- *                   fully coalesced).  The image of an [R, K] operand takes rows16 x 3K/4 bytes.  K % 128 == 0.
- *                   mixq_pack_operand(fmt = MIXQ_FMT_F6X128) converts a plain nibble-packed [R, K/2] matrix and returns
- *                   MIXQ_ERANGE when it holds the nibble -8 (no E2M3 value; such an operand stays on the int8-expansion path). */
+/* MIXQ_FMT_F6X128 : int4 operands (bit = 4 only) stored as FP6 E3M2 codes in fragment order, for BOTH operands of the W4A4 GEMM on
+ *                   the FP6 matrix pipe: gfx950 has no int4 MFMA, but every integer of [-8, 8] is an E3M2 value (sign | 3-bit exponent,
+ *                   bias 3 | 2-bit mantissa: 0 1 2 3 4 5 6 7 8 = 0x00 0x0c 0x10 0x12 0x14 0x15 0x16 0x17 0x18; the reference's 4-bit
+ *                   weights are clamp(round(w / scale), -8, 7), linear.py:139), the products are integers and the fp32 accumulator is
+ *                   exact below 2^24 (K < 262144), so v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales returns the
+ *                   int4 x int4 -> int32 contraction bit for bit at 1.6x the rate of the int8 MFMA (profiles/r03_ubench_fp6.txt).
+ *                   [K/128][rows16/16] blocks of 16 rows x 128 elements = 1536 bytes.  Lane l of a wave owns row l & 15, elements
+ *                   32 (l >> 4) .. + 31 of the block: 32 six-bit codes as a little-endian bit stream (element e at bit 6 e) = 24
+ *                   bytes, stored as a 16-byte piece at block + 16 l and an 8-byte piece at block + 1024 + 8 l (one dwordx4 + one
+ *                   dwordx2 per lane, both fully coalesced).  The image of an [R, K] operand takes rows16 x 3K/4 bytes.  K % 128 == 0.
+ *                   mixq_pack_operand / mixq_unpack_operand (fmt = MIXQ_FMT_F6X128) convert from / to the plain nibble-packed
+ *                   [R, K/2] matrix (KB = K/2 in their signature). */
 #define MIXQ_FMT_F6X128 3
 /* `layout` bits of the GEMM entry points */
 #define MIXQ_X_PACKED 1      /* q_x is MIXQ_FMT_P16X64 */

@@ -23,7 +23,6 @@ MIXQ_OK = 0
 MIXQ_EINVAL = -1
 MIXQ_ESHAPE = -2
 MIXQ_ENODEV = -3
-MIXQ_ERANGE = -4
 ACT_NONE = 0
 ACT_SILU = 1
 ACT_SILU_MUL = 2
@@ -44,7 +43,7 @@ class MixqBuildError(RuntimeError):
 class MixqError(RuntimeError):
     def __init__(self, fn: str, code: int):
         names = {MIXQ_EINVAL: "MIXQ_EINVAL (bad argument)", MIXQ_ESHAPE: "MIXQ_ESHAPE (unsupported shape)",
-                 MIXQ_ENODEV: "MIXQ_ENODEV (no gfx950 device)", MIXQ_ERANGE: "MIXQ_ERANGE (operand value outside the format's range)"}
+                 MIXQ_ENODEV: "MIXQ_ENODEV (no gfx950 device)"}
         super().__init__(f"{fn} failed: {names.get(code, f'hipError_t {code}')}")
         self.code = code
 

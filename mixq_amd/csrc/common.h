@@ -116,15 +116,17 @@ __device__ __forceinline__ size_t packed_offset(int fmt, int row, int kb, int ro
     const size_t blk = (static_cast<size_t>(kb >> 6) * (rows16 >> 4) + (row >> 4)) * 1024;
     return blk + (fmt == MIXQ_FMT_F16X64 ? c * 256 + r * 16 : r * 64 + ((c ^ ((0 - (r >> 2)) & 3)) << 4)) + (kb & 15);
 }
-// ---- MIXQ_FMT_F6X128 (include/mixq_hip.h): int4 values as FP6 E2M3 codes ------------------------------------------------------
-// code of a two's-complement nibble of [-7, 7]: sign bit, then the magnitude's code 0 8 16 20 24 26 28 30 (halved: 0 4 8 a c d e f)
+// ---- MIXQ_FMT_F6X128 (include/mixq_hip.h): int4 values as FP6 E3M2 codes ------------------------------------------------------
+// code of a two's-complement nibble (-8 .. 7): sign bit 0x20, then the magnitude's code (3-bit exponent of bias 3, 2-bit mantissa):
+// 0 1 2 3 4 5 6 7 8 = 0x00 0x0c 0x10 0x12 0x14 0x15 0x16 0x17 0x18
 __device__ __forceinline__ uint32_t f6_code_of_nibble(uint32_t nib) {
-    const uint32_t neg = nib & 8u, mag = neg ? (16u - nib) & 7u : nib;
-    return (neg << 2) | (((0xFEDCA840u >> (mag * 4)) & 0xfu) << 1);
+    const uint32_t neg = nib & 8u, mag = neg ? 16u - nib : nib;
+    return (neg << 2) | (static_cast<uint32_t>(0x18bdab494180ull >> (mag * 5)) & 0x1fu);
 }
-__device__ __forceinline__ uint32_t f6_nibble_of_code(uint32_t code) {      // inverse (codes that are no integer map to their truncation)
-    const uint32_t mag = static_cast<uint32_t>((0x7654030200010000ull >> ((code & 0x1eu) << 1)) & 0xfu);
-    return (code & 0x20u) ? (16u - mag) & 0xfu : mag;
+__device__ __forceinline__ uint32_t f6_nibble_of_code(uint32_t code) {      // inverse (codes that are no integer of [-8, 8] map to 0)
+    const uint32_t c = code & 0x1fu;
+    const uint32_t mag = static_cast<uint32_t>(((c & 16u) ? 0x876540302ull : 0x1000000000000ull) >> ((c & 15u) * 4)) & 0xfu;
+    return (code & 0x20u) ? (16u - mag) & 0xfu : mag & 0xfu;
 }
 // byte address of the block of (row, element k) and the lane that owns the element's 32-element group
 __device__ __forceinline__ size_t f6_block_offset(int row, int k, int rows16) {

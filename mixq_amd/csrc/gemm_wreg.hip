@@ -82,7 +82,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int CW = WR_CW;
     constexpr int NT = (CW + LOADERS) * 64;
     constexpr int BM = MB * 16, WN = WNB * 16, BN = CW * WN;
-    // F6: the W4A4 form on the FP6 matrix pipe.  Every integer of [-7, 7] is an FP6 E2M3 value, products are integers <= 49 and
+    // F6: the W4A4 form on the FP6 matrix pipe.  Every integer of [-8, 8] is an FP6 E3M2 value, products are integers <= 64 and
     // the fp32 accumulator is exact below 2^24, so v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales computes the int4
     // contraction bit-exactly (tools/ubench_fp6.hip: K up to 262144, worst-case operands) at 1.6x the MACs per cycle of
     // v_mfma_i32_16x16x64_i8 - gfx950 has no int4 MFMA, and the nibble form (Q = 1) pays the int8 rate plus the expansion.
@@ -103,13 +103,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int OPITCH = BN * 2 + 16;
     constexpr bool PREBIAS = !SELF && (MB * WNB * 4 + (D + 1) * WNB * (F6 ? 6 : 4) * (I4 ? 2 : 1) + MB * (F6 ? 6 : 4) + 40 <= 232);   // registers to spare for the bias prefetch
     constexpr int AMAX_OFF = (BM * OPITCH + 15) & ~15;   // LDS: [CW][4][BM] row maxima (one slot per wave and lane group), behind the staging tile
-    constexpr int TQ = SELF ? 0 : 2;                     // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS
+    // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS: two; four in the FP6 form - 4-bit layers carry 128
+    // static fp16 columns (linear.py:100, fp_features_num), and k-steps beyond TQ cost every wave a global round trip for the same rows
+    constexpr int TQ = SELF ? 0 : (F6 ? 4 : 2);
     constexpr int TAILX = NSTAGE * STAGE_BYTES;          // LDS offset of those blocks: behind the ring, [TQ][MB] x 1 KiB
     static_assert(MB % ISSUERS == 0 && (STAGE_BYTES / 1024) % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
-    static_assert(!F6 || (!SELF && ABL == 0), "the FP6 form exists for the shipped loop only");
+    static_assert(!F6 || (!SELF && (ABL == 0 || ABL == 1 || ABL == 2 || ABL == 3)), "the FP6 form exists for the shipped loop (and its feed ablations) only");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
     static_assert(!SELF || (LOOK == D + 1 && !I4 && ABL == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
-    static_assert((NSTAGE + TQ) * STAGE_BYTES <= 160 * 1024, "X ring + tail blocks must fit the 160 KiB of LDS");
+    static_assert(NSTAGE * STAGE_BYTES + TQ * MB * 1024 <= 160 * 1024, "X ring + tail blocks must fit the 160 KiB of LDS");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (ABL == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
@@ -317,6 +319,14 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         if constexpr (ABL != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
 #pragma unroll
             for (int j = 0; j < MB; ++j) { xf[j] = i32x4{lane, 1, lane, 1}; asm volatile("" : "+v"(xf[j])); }
+            if constexpr (F6) {
+#pragma unroll
+                for (int j = 0; j < XR; ++j) xf6[j] = i32x6{lane, 1, lane, 1, 2, 3};
+#pragma unroll
+                for (int d = 0; d < NSLOT; ++d)
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) asm volatile("" : "+v"(wq2[d][i]));
+            }
         }
         // The weight loads are inline asm with hand-counted waits: left to the compiler, the loop header of the unrolled k loop
         // gets `s_waitcnt vmcnt(0)` (its counter model merges the preheader and latch states conservatively), which drains the
@@ -408,7 +418,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             }
         };
         auto xread = [&](int slot, int j) MIXQ_INL {
-            if constexpr (F6) {
+            if constexpr (F6 && (ABL == 2 || ABL == 3)) {
+                // (ablation: no LDS reads)
+            } else if constexpr (F6) {
                 const i32x4 p4 = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * BLK + lane16);
                 const i32x2 p2 = *reinterpret_cast<const i32x2*>(lds + slot * STAGE_BYTES + j * BLK + 1024 + lane8);
                 xf6[j % XR] = i32x6{p4[0], p4[1], p4[2], p4[3], p2[0], p2[1]};
@@ -463,7 +475,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 asm volatile("s_nop 1" ::: "memory");
                 const int unit = 0x7f7f7f7f;                                       // E8M0 block scales of 2^0
 #if defined(__HIP_DEVICE_COMPILE__)
-#define MIXQ_F6_MMA(ACC, W, X) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:2 blgp:2" \
+#define MIXQ_F6_MMA(ACC, W, X) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:3 blgp:3" \
                                             : "+v"(ACC) : "v"(W), "v"(X), "v"(unit))
 #else
 #define MIXQ_F6_MMA(ACC, W, X) (void)unit
@@ -1010,6 +1022,12 @@ const WrConfig g_wr[] = {
     // (profiles/r02_decode.txt)
     MIXQ_WR(2, 1, 8, 6, 1, 0, "32x64_s8_d6_l1"),       // 14 (WR_SMALL)
 #ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): only in the tools build (make tuning)
+    { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
+    { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 2, 2>, 8 },
+    { "wr128x192_f6_abl3_mfma", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 2, 3>, 8 },
+    { "wr128x192_f6_s10", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 10, 3, 2, 2, 0>, 10 },         // deeper X ring
+    { "wr128x192_f6_d2", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 0>, 8 },            // shallower weight ring
+    { "wr128x192_f6_l4", 8, 3, 16, 4, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 4, 0>, 8 },            // four loader waves
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic
     MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // cfg 0, MFMA + epilogue only
@@ -1125,7 +1143,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     a.row_amax = row_amax; a.amax_mask = amax_mask;
     void (*k)(const WrArgs) = bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4);
     if (!k) return MIXQ_EINVAL;                                                  // (the prefill tiles have no nibble form, few tilings an FP6 form)
-    const size_t ring = bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 2 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
+    const size_t ring = bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 4 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
     const size_t shm = ring > stg ? ring : stg;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3((WR_CW + g.loaders) * 64), shm, st, a);

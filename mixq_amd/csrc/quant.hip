@@ -466,10 +466,8 @@ __global__ __launch_bounds__(QT) void repack_kernel(const uint8_t* __restrict__ 
 }
 
 // The same for MIXQ_FMT_F6X128: one thread per lane fragment (row, 32-element group): 16 bytes of nibbles <-> 24 bytes of FP6 codes.
-// Packing counts the nibbles -8 it meets (no E2M3 value) into *bad.
 template <bool UNPACK>
-__global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R, int K,
-                                                       int rows16, unsigned int* __restrict__ bad)
+__global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R, int K, int rows16)
 {
     const long long t = static_cast<long long>(blockIdx.x) * QT + threadIdx.x;
     const long long total = static_cast<long long>(rows16) * (K >> 5);
@@ -499,19 +497,15 @@ __global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict
         if (row < R) v = *reinterpret_cast<const uint4*>(src + plain);
         const uint32_t in[4] = {v.x, v.y, v.z, v.w};
         uint32_t w[7] = {0, 0, 0, 0, 0, 0, 0};
-        unsigned int nbad = 0;
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
-            const uint32_t nib = (in[e >> 3] >> (4 * (e & 7))) & 0xfu;
-            nbad += nib == 8u;
-            const uint32_t code = f6_code_of_nibble(nib);
+            const uint32_t code = f6_code_of_nibble((in[e >> 3] >> (4 * (e & 7))) & 0xfu);
             const int bit = 6 * e, wi = bit >> 5, sh = bit & 31;
             w[wi] |= code << sh;
             if (sh > 26) w[wi + 1] |= code >> (32 - sh);
         }
         *reinterpret_cast<uint4*>(dst + blk + lane * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         *reinterpret_cast<uint2*>(dst + blk + 1024 + lane * 8) = make_uint2(w[4], w[5]);
-        if (nbad && bad) atomicAdd(bad, nbad);
     }
 }
 
@@ -736,31 +730,15 @@ static int repack_common(const void* src, void* dst, int R, int KB, int fmt, boo
     if (KB % 64) return MIXQ_ESHAPE;
     if (R == 0) return MIXQ_OK;
     const int rows16 = (R + 15) & ~15;
-    if (fmt == MIXQ_FMT_F6X128) {
-        // KB = K / 2 bytes of nibbles per row.  Packing is a once-per-layer, synchronous operation here (not capturable in a graph):
-        // the count of -8 nibbles comes back to the host so that the caller learns the operand does not fit the format.
+    if (fmt == MIXQ_FMT_F6X128) {                          // KB = K / 2 bytes of nibbles per row of the plain side
         const int K = KB * 2;
-        const long long total = static_cast<long long>(rows16) * (K >> 5);
-        const dim3 g(static_cast<unsigned>((total + QT - 1) / QT));
-        hipStream_t st = mixq_stream(stream);
-        if (unpack) {
-            hipLaunchKernelGGL(repack_f6_kernel<true>, g, dim3(QT), 0, st, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), R, K, rows16,
-                               static_cast<unsigned int*>(nullptr));
-            return mixq_launch_status();
-        }
-        unsigned int* bad = nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&bad), sizeof(unsigned int)) != hipSuccess) return MIXQ_ENODEV;
-        unsigned int h = 0;
-        int rc = MIXQ_OK;
-        if (hipMemsetAsync(bad, 0, sizeof(unsigned int), st) != hipSuccess) rc = MIXQ_ENODEV;
-        if (rc == MIXQ_OK) {
-            hipLaunchKernelGGL(repack_f6_kernel<false>, g, dim3(QT), 0, st, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), R, K, rows16, bad);
-            rc = mixq_launch_status();
-        }
-        if (rc == MIXQ_OK && (hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = MIXQ_ENODEV;
-        (void)hipFree(bad);
-        if (rc != MIXQ_OK) return rc;
-        return h ? MIXQ_ERANGE : MIXQ_OK;
+        const long long total6 = static_cast<long long>(rows16) * (K >> 5);
+        const dim3 g6(static_cast<unsigned>((total6 + QT - 1) / QT));
+        if (unpack) hipLaunchKernelGGL(repack_f6_kernel<true>, g6, dim3(QT), 0, mixq_stream(stream), static_cast<const uint8_t*>(src),
+                                       static_cast<uint8_t*>(dst), R, K, rows16);
+        else        hipLaunchKernelGGL(repack_f6_kernel<false>, g6, dim3(QT), 0, mixq_stream(stream), static_cast<const uint8_t*>(src),
+                                       static_cast<uint8_t*>(dst), R, K, rows16);
+        return mixq_launch_status();
     }
     const long long total = static_cast<long long>(rows16) * (KB >> 4);
     const dim3 g(static_cast<unsigned>((total + QT - 1) / QT));

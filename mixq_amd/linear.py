@@ -22,7 +22,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import mixlib as _hip_mixlib
-from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, MIXQ_ERANGE
+from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128
 
 # The kernel backend.  Always the HIP module in the product; tests that exercise the host-side state machine on a
 # machine without a GPU swap in an oracle-backed stand-in (tests/backend_oracle.py) via `set_backend`.
@@ -39,11 +39,10 @@ def set_backend(mod):
 # Packed layout new layers keep their weights in (and ask their activations in): MIXQ_FMT_F16X64 feeds the
 # weights-in-registers GEMM of gemm_wreg.hip, MIXQ_FMT_P16X64 the LDS-staged one of gemm.hip (include/mixq_hip.h).
 PACK_FMT = FMT_F16X64
-# ... and 4-bit layers: MIXQ_FMT_F6X128 - both operands as FP6 E2M3 codes, the W4A4 GEMM on the FP6 matrix pipe (gfx950 has no int4
-# MFMA; every integer of [-7, 7] is an E2M3 value and the fp32 accumulator is exact, so the result is the int4 contraction bit for
+# ... and 4-bit layers: MIXQ_FMT_F6X128 - both operands as FP6 E3M2 codes, the W4A4 GEMM on the FP6 matrix pipe (gfx950 has no int4
+# MFMA; every integer of [-8, 8] is an E3M2 value and the fp32 accumulator is exact, so the result is the int4 contraction bit for
 # bit at 1.6x the int8 MFMA rate: 22.9 vs 27.6 us at 512 x 4096 -> 11008, 24.9 vs 32.3 us at 11008 -> 4096).  FMT_P16X64 selects the
-# int8-expansion kernel instead (nibbles, half the weight bytes of the FP6 image: the better trade for weight-stream-bound decode);
-# a layer whose weights hold the nibble -8 (no E2M3 value; symmetric 4-bit quantisation never produces it) falls back to it.
+# int8-expansion kernel instead (nibbles, two thirds of the FP6 image's weight bytes: the better trade for weight-stream-bound decode).
 PACK_FMT4 = FMT_F6X128
 # After a layer's outlier search has frozen, keep ONLY the packed weight image in HBM (the plain [N,K] `q_weight` is
 # re-created on demand for state_dict / attribute reads).  False keeps both copies (2x the reference's weight memory).
@@ -354,12 +353,7 @@ class MixLinear_GEMM(nn.Module):
         fmt = PACK_FMT if self.bit == 8 else PACK_FMT4
         key = (id(qw), qw.data_ptr(), qw._version, fmt)
         if self._wpk is None or self._wpk_key != key:
-            try:
-                self._wpk = _backend.PackOperand(qw, fmt)
-            except RuntimeError as e:
-                if fmt != FMT_F6X128 or getattr(e, "code", None) != MIXQ_ERANGE:
-                    raise
-                self._wpk = _backend.PackOperand(qw, FMT_P16X64)         # a -8 among the nibbles: the int8-expansion kernel serves it
+            self._wpk = _backend.PackOperand(qw, fmt)
             self._wpk_key = key
         return self._wpk
 
@@ -454,6 +448,13 @@ class MixLinear_GEMM(nn.Module):
                                         act=act, addend=addend, n_out_dev=n_dev, **extra)
         return _backend.FusedLinear(qx, w, cache.x_scale, self.scale_col, None, None, 0, self.bias, M, self.out_features,
                                     self.in_features, bit=self.bit, act=act, addend=addend, **extra)
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle of a frozen layer: the kept argument block of the one-call forward is a ctypes structure full of device
+        pointers - neither copyable nor meaningful in the copy, which builds its own on its first frozen forward."""
+        state = dict(self.__dict__)
+        state["_plan"], state["_plan_key"] = None, None
+        return state
 
     # ---- frozen steady state: the whole forward behind ONE foreign call (include/mixq_hip.h: mixq_linear_forward) ------
     def _frozen_key(self, cache, inputs, M):
@@ -634,8 +635,8 @@ def _unpack_host_f6(packed, R):
     global _F6_NIBBLE
     if _F6_NIBBLE is None:
         lut = torch.zeros(64, dtype=torch.uint8)
-        for v, code in enumerate((0x00, 0x08, 0x10, 0x14, 0x18, 0x1a, 0x1c, 0x1e)):
-            lut[code] = v
+        for v, code in enumerate((0x00, 0x0c, 0x10, 0x12, 0x14, 0x15, 0x16, 0x17, 0x18)):      # E3M2 codes of 0 .. 8
+            lut[code] = v & 0xF
             lut[code | 0x20] = (16 - v) & 0xF
         _F6_NIBBLE = lut
     rows16, B = packed.shape

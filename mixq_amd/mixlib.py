@@ -578,7 +578,7 @@ def PackOperand(q, fmt=FMT_P16X64):
     if q.dim() != 2 or not q.is_contiguous() or q.element_size() != 1:
         raise RuntimeError("PackOperand: expected a contiguous 2-D int8/uint8 tensor")
     R, KB = q.shape
-    # (F6X128: KB = K / 2 bytes of nibbles per row in, 3 K / 4 bytes of FP6 codes per row out; raises when the operand holds a -8)
+    # (F6X128: KB = K / 2 bytes of nibbles per row in, 3 K / 4 bytes of FP6 codes per row out)
     out = torch.empty((packed_rows(R), KB * 3 // 2 if fmt == FMT_F6X128 else KB), dtype=q.dtype, device=q.device)
     _capi.call("mixq_pack_operand", q.data_ptr(), out.data_ptr(), R, KB, fmt, _stream())
     return set_fmt(out, fmt)

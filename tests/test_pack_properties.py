@@ -64,11 +64,93 @@ def f16x64_unpack(buf, R, KB):
     return out
 
 
+F6_MAG = (0x00, 0x0C, 0x10, 0x12, 0x14, 0x15, 0x16, 0x17, 0x18)      # E3M2 codes of 0..8 (sign bit 0x20): 1 2 (1.5 x 2) 4 (1.25 x 4) (1.5 x 4) (1.75 x 4) 8
+
+
+def f6_value(code):
+    """The value an FP6 E3M2 code denotes (OCP MX: 1 sign, 3 exponent bits of bias 3, 2 mantissa bits; no infinities, no NaNs)."""
+    s, e, m = code >> 5, (code >> 2) & 7, code & 3
+    v = (m / 4.0) * 2.0 ** -2 if e == 0 else (1 + m / 4.0) * 2.0 ** (e - 3)
+    return -v if s else v
+
+
+def f6x128_reference(v):
+    """MIXQ_FMT_F6X128 of include/mixq_hip.h restated byte by byte: v int8 [R, K] with values of [-8, 7] -> the image, [K/128][rows16/16]
+    blocks of 1536 bytes; lane l = 16 (k % 128 // 32) + row % 16 owns elements 32 (l >> 4) .. + 31 as a little-endian stream of 6-bit
+    codes, its first 16 bytes at block + 16 l, the last 8 at block + 1024 + 8 l; rows >= R hold the code of 0."""
+    R, K = v.shape
+    rows16 = (R + 15) // 16 * 16
+    out = np.zeros((K // 128) * (rows16 // 16) * 1536, dtype=np.uint8)
+    for row in range(R):
+        for kb in range(K // 128):
+            base = (kb * (rows16 // 16) + row // 16) * 1536
+            for g in range(4):
+                lane = g * 16 + row % 16
+                bits = 0
+                for e in range(32):
+                    x = int(v[row, kb * 128 + g * 32 + e])
+                    bits |= ((0x20 if x < 0 else 0) | F6_MAG[abs(x)]) << (6 * e)
+                b = np.frombuffer(bits.to_bytes(24, "little"), dtype=np.uint8)
+                out[base + lane * 16: base + lane * 16 + 16] = b[:16]
+                out[base + 1024 + lane * 8: base + 1024 + lane * 8 + 8] = b[16:]
+    return out
+
+
+def f6x128_unpack(buf, R, K):
+    """Inverse of f6x128_reference through the VALUES the codes denote (so a code that is no integer would show)."""
+    rows16 = (R + 15) // 16 * 16
+    out = np.zeros((R, K), dtype=np.int8)
+    for row in range(R):
+        for kb in range(K // 128):
+            base = (kb * (rows16 // 16) + row // 16) * 1536
+            for g in range(4):
+                lane = g * 16 + row % 16
+                b = bytes(buf[base + lane * 16: base + lane * 16 + 16]) + bytes(buf[base + 1024 + lane * 8: base + 1024 + lane * 8 + 8])
+                bits = int.from_bytes(b, "little")
+                for e in range(32):
+                    val = f6_value((bits >> (6 * e)) & 63)
+                    assert val == int(val)
+                    out[row, kb * 128 + g * 32 + e] = int(val)
+    return out
+
+
+def test_every_int4_value_is_an_e3m2_value_and_products_stay_exact():
+    """The premise of the FP6 carrier: [-8, 8] embeds exactly into E3M2 - the reference's 4-bit weights are
+    clamp(round(w / scale), -8, 7), linear.py:139 - while E2M3 stops at 7.5, and a K-long sum of products stays below 2^24 (exact in the
+    fp32 accumulator) for every K the models use."""
+    vals = {f6_value(c) for c in range(64)}
+    for x in range(-8, 9):
+        assert float(x) in vals and f6_value((0x20 if x < 0 else 0) | F6_MAG[abs(x)]) == x
+    assert max(vals) == 28.0
+    e2m3 = {(m / 8.0 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 1)) for e in range(4) for m in range(8)}
+    assert 8.0 not in e2m3 and max(e2m3) == 7.5
+    assert 8 * 7 * 28672 < 2 ** 24 and 8 * 7 * 262144 < 2 ** 24          # |weight| <= 8, |activation| <= 7 (symmetric, qmax = 7)
+
+
+@settings(max_examples=15, deadline=None)
+@given(st.integers(1, 40), st.integers(1, 3), st.integers(0, 2 ** 31 - 1))
+def test_f6x128_layout_is_a_bijection_and_host_unpack_inverts_it(rows, kblocks, seed):
+    import torch
+    from mixq_amd.linear import _unpack_host
+    rng = np.random.default_rng(seed)
+    v = rng.integers(-8, 8, (rows, 128 * kblocks), dtype=np.int8)
+    buf = f6x128_reference(v)
+    assert np.array_equal(f6x128_unpack(buf, rows, 128 * kblocks), v)
+    rows16 = (rows + 15) // 16 * 16
+    back = _unpack_host(torch.from_numpy(buf.reshape(rows16, 96 * kblocks)), rows, 3).numpy()
+    assert np.array_equal(back, O.pack_i4(v))
+    # the 16-byte pieces of a block are read with ds_read_b128 at 16 l and the 8-byte pieces with ds_read_b64 at 1024 + 8 l: consecutive
+    # lanes, consecutive addresses - no two lanes of a service group share a bank (MI355X_MICROARCH.md, LDS)
+    assert len({(16 * l) // 16 % 16 for l in range(16)}) == 16 and len({(1024 + 8 * l) // 8 % 32 for l in range(32)}) == 32
+
+
 def packed_reference(q, fmt):
     return {1: p16x64_reference, 2: f16x64_reference}[fmt](q)
 
 
 def packed_unpack(buf, R, KB, fmt):
+    if fmt == 3:                                             # F6X128: KB = K / 2 nibble bytes per row of the plain matrix
+        return O.pack_i4(f6x128_unpack(buf, R, KB * 2))
     return {1: p16x64_unpack, 2: f16x64_unpack}[fmt](buf, R, KB)
 
 

@@ -18,6 +18,7 @@ ap.add_argument("--rounds", type=int, default=30)
 ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--nout", type=int, default=41)
 ap.add_argument("--bit", type=int, default=8)
+ap.add_argument("--f6", action="store_true", help="bit 4 with both operands as FP6 codes (MIXQ_FMT_F6X128): the FP6-pipe form of the wr kernels")
 ap.add_argument("--gms", default="0", help="comma list of M-tile group sizes of the weights-in-registers kernels' tile order (0 = automatic)")
 args = ap.parse_args()
 dev = "cuda"
@@ -36,8 +37,8 @@ if args.bit == 4:
     qx, qw = qx.view(torch.uint8), qw.view(torch.uint8)
 sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
 sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
-xp = mixlib.PackOperand(qx, 1)
-wp = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 2)}
+xp = mixlib.PackOperand(qx, 3 if args.f6 else 1)
+wp = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 3 if args.f6 else 2)}
 xo = wo = None
 if args.nout:
     pad = (args.nout + 15) // 16 * 16
@@ -56,7 +57,8 @@ with torch.cuda.stream(side):
         assert lib.mixq_gemm_set_krot(gm << 16) == 0
         if gm:
             nm = f"{nm}_gm{gm}"
-        run = lambda: mixlib.FusedLinear(xp, w, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
+        xa = xp if (nm.startswith("wr") or not args.f6) else mixlib.PackOperand(qx, 1)     # (the LDS-staged kernels take nibbles in P16X64)
+        run = lambda xa=xa, w=w: mixlib.FusedLinear(xa, w, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
         for _ in range(3):
             run()
         torch.cuda.synchronize()

@@ -19,8 +19,8 @@ g = torch.Generator().manual_seed(0)
 fails = 0
 
 
-def nibbles(R, K):
-    v = torch.randint(-7, 8, (R, K), generator=g, dtype=torch.int8)
+def nibbles(R, K, lo=-8):
+    v = torch.randint(lo, 8, (R, K), generator=g, dtype=torch.int8)
     u = (v & 0xF).to(torch.uint8)
     return v, (u[:, 0::2] | (u[:, 1::2] << 4)).contiguous()
 
@@ -33,13 +33,6 @@ for R, K in [(16, 128), (37, 256), (500, 4096)]:
     ok = torch.equal(back.cpu(), p)
     print(f"pack/unpack {R}x{K}: image {tuple(img.shape)} {'ok' if ok else 'MISMATCH'}")
     fails += not ok
-bad = torch.full((16, 64), 0x88, dtype=torch.uint8, device=dev)
-try:
-    mixlib.PackOperand(bad, FMT_F6X128)
-    print("pack of -8 nibbles: NOT refused"); fails += 1
-except Exception as e:  # noqa: BLE001
-    print("pack of -8 nibbles refused:", type(e).__name__, str(e)[:80])
-
 # 2. quantiser
 for M, K, n in [(512, 4096, 41), (37, 256, 0), (100, 11008 // 128 * 128, 17)]:
     x = torch.randn(M, K, generator=g).half()
@@ -60,7 +53,7 @@ shapes = [(512, 11008, 4096, 41), (512, 4096, 4096, 0), (500, 4100, 1024, 19), (
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in s.split("x")) for s in sys.argv[1].split(",")]
 for M, N, K, n_out in shapes:
-    _, qx = nibbles(M, K)
+    _, qx = nibbles(M, K, -7)
     _, qw = nibbles(N, K)
     qx, qw = qx.to(dev), qw.to(dev)
     sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)

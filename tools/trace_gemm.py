@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nout", type=int, default=0, help="outlier columns (the fp16 MFMA tail of the epilogue)")
+    ap.add_argument("--f6", action="store_true", help="bit 4 with both operands as FP6 codes (MIXQ_FMT_F6X128): the FP6-pipe form of the wr kernels")
     args = ap.parse_args()
     dev = "cuda"
     lib = _capi.load()
@@ -33,8 +34,10 @@ def main():
         qw = torch.randint(-127, 128, (N, KB), generator=g, dtype=torch.int8).to(dev)
         sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
         sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
-        qxp = mixlib.PackOperand(qx, 1)
-        qw_by_fmt = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 2)}
+        if args.bit == 4:
+            qx, qw = qx.view(torch.uint8), qw.view(torch.uint8)
+        qxp = mixlib.PackOperand(qx, 3 if args.f6 else 1)
+        qw_by_fmt = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 3 if args.f6 else 2)}
         out = torch.empty(M, N, dtype=torch.float16, device=dev)
         xo = wo = None
         if args.nout:

@@ -1,8 +1,9 @@
-// Micro-benchmark for carrying W4A4 on the FP6 matrix pipe of gfx950 (v_mfma_scale_f32_16x16x128_f8f6f4, FP6 E2M3 operands, unit
-// block scales): every integer of [-7, 7] is an E2M3 value (0 1 2 3 4 5 6 7 = 0.0 1.0 2.0 3.0 4.0 5.0 6.0 7.0: 1.25 x 4 = 5, 1.75 x 4 = 7),
-// products are integers <= 49 and the fp32 accumulator is exact below 2^24, so the int4 x int4 -> int32 contraction should come out
-// BIT-EXACT at twice the int8 MFMA rate.  Two questions, answered on the hardware:
-//   (1) exactness: random and worst-case ([-7,7] everywhere, all +7) operands over K up to 262144 against an integer reference;
+// Micro-benchmark for carrying W4A4 on the FP6 matrix pipe of gfx950 (v_mfma_scale_f32_16x16x128_f8f6f4, FP6 E3M2 operands, unit
+// block scales): every integer of [-8, 8] is an E3M2 value (1 2 3 4 5 6 7 8 = 1, 2, 1.5 x 2, 4, 1.25 x 4, 1.5 x 4, 1.75 x 4, 8; E2M3
+// stops at 7.5 and the reference's 4-bit weights reach -8), products are integers <= 64 and the fp32 accumulator is exact below
+// 2^24, so the int4 x int4 -> int32 contraction should come out BIT-EXACT at up to twice the int8 MFMA rate.  Answered on the hardware:
+//   (1) exactness: random ([-8,7] x [-7,7]) and worst-case (all -8 x 7, alternating signs) operands over K up to 262144 against an
+//       integer reference;
 //   (2) rate: cycles per MFMA per SIMD next to v_mfma_i32_16x16x64_i8.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_fp6.hip -o tools/ubench_fp6
 #include <hip/hip_runtime.h>
@@ -15,10 +16,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// E2M3 code of an integer in [-7, 7]: sign | 2-bit exponent (bias 1) | 3-bit mantissa
+// E3M2 code of an integer in [-8, 8]: sign | 3-bit exponent (bias 3) | 2-bit mantissa
 __host__ __device__ inline uint32_t fp6_code(int v)
 {
-    const uint32_t mag[8] = {0x00, 0x08, 0x10, 0x14, 0x18, 0x1a, 0x1c, 0x1e};
+    const uint32_t mag[9] = {0x00, 0x0c, 0x10, 0x12, 0x14, 0x15, 0x16, 0x17, 0x18};
     return (v < 0 ? 0x20u : 0u) | mag[v < 0 ? -v : v];
 }
 
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(64) void exact_kernel(const int8_t* a, const int8_t
         i32x8 va, vb;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { va[i] = static_cast<int>(pa[i]); vb[i] = static_cast<int>(pb[i]); }
-        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, vb, acc, 2, 2, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, vb, acc, 3, 3, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
     }
     // C/D: col = lane & 15 (B row), row = 4 (lane >> 4) + i (A row)
 #pragma unroll
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void rate_kernel(int iters, float* out, unsign
             } else if constexpr (MODE == 3) {
                 i32x6 a6 = {a[0], a[1], a[2], a[3], a[4], a[5]}, b6 = {b[0], b[1], b[2], b[3], b[4], b[5]};
                 const int sc = 0x7f7f7f7f;
-#define M6(D) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(D) : "v"(a6), "v"(b6), "v"(sc))
+#define M6(D) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:3 blgp:3" : "+v"(D) : "v"(a6), "v"(b6), "v"(sc))
                 M6(d0); M6(d1); M6(d2); M6(d3);
 #undef M6
             } else if constexpr (MODE == 4) {
@@ -133,10 +134,10 @@ int main()
             int8_t* ha = (int8_t*)malloc(n); int8_t* hb = (int8_t*)malloc(n);
             uint32_t s = 12345u + K + mode;
             for (size_t i = 0; i < n; ++i) {
-                s = s * 1664525u + 1013904223u; const int va = (int)((s >> 8) % 15) - 7;
-                s = s * 1664525u + 1013904223u; const int vb = (int)((s >> 8) % 15) - 7;
-                ha[i] = mode == 0 ? va : (mode == 1 ? 7 : ((i & 1) ? 7 : -7));
-                hb[i] = mode == 0 ? vb : (mode == 1 ? 7 : ((i % 3) ? 7 : -7));
+                s = s * 1664525u + 1013904223u; const int va = (int)((s >> 8) % 16) - 8;   // weights: [-8, 7]
+                s = s * 1664525u + 1013904223u; const int vb = (int)((s >> 8) % 15) - 7;   // activations: [-7, 7]
+                ha[i] = mode == 0 ? va : (mode == 1 ? -8 : ((i & 1) ? 7 : -8));
+                hb[i] = mode == 0 ? vb : (mode == 1 ? -7 : ((i % 3) ? 7 : -7));
             }
             int8_t *da, *db; int *dout, *dn;
             CHECK(hipMalloc(&da, n)); CHECK(hipMalloc(&db, n)); CHECK(hipMalloc(&dout, 1024)); CHECK(hipMalloc(&dn, 4));
@@ -163,7 +164,7 @@ int main()
     rate<1>("v_mfma_i32_16x16x64_i8", out, cyc);
     rate<0>("v_mfma_scale_f32_16x16x128 fp6 x fp6", out, cyc);
     rate<2>("v_mfma_scale_f32_32x32x64 fp6 x fp6", out, cyc);
-    rate<3>("16x16x128 fp6 x fp6, asm in place", out, cyc);
+    rate<3>("16x16x128 fp6 (E3M2) x fp6, asm in place", out, cyc);
     rate<4>("16x16x128 fp4 x fp4, asm in place", out, cyc);
     printf(total_bad ? "FP6 carrier NOT exact\n" : "FP6 carrier exact on every case\n");
     return total_bad ? 1 : 0;
