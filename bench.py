@@ -451,11 +451,11 @@ def main(argv=None):
         traffic, traffic_src = hbm_traffic_from_profile()
         shape_note = "Llama-2-7b up_proj shape" if (K, N) == (4096, 11008) else f"{K}->{N}"
         out = {
-            "metric": f"effective int8 TFLOPS, W{bit}A{bit}O16 MixQ Linear forward (quantise + {'int8' if bit == 8 or fmt != 3 else 'FP6-pipe'} MFMA GEMM + fused dequant/outlier "
+            "metric": f"effective int8 TFLOPS, W{bit}A{bit}O16 MixQ Linear forward (quantise + {'int8' if bit == 8 or fmt != 4 else 'FP6-pipe'} MFMA GEMM + fused dequant/outlier "
                       f"epilogue), batch {M}, {K}->{N}",
             "value": round(value, 2), "unit": "TFLOPS", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "int8" if bit == 8 else ("int4 (carried exactly as FP6 E3M2 codes on the FP6 matrix pipe: CDNA4 has no int4 MFMA)" if fmt == 3
+            "dtype": "int8" if bit == 8 else ("int4 (carried exactly as FP6 E3M2 codes on the FP6 matrix pipe: CDNA4 has no int4 MFMA)" if fmt == 4
                                               else "int4 (expanded to int8 in registers: CDNA4 has no int4 MFMA)"), "data": "synthetic",
             "config": {"workload": f"MixLinear_GEMM W{bit}A{bit}O16 forward, {shape_note}", "M": M, "K": K, "N": N,
                        "outlier_columns": n_ind, "outlier_predict": "frozen after 2 warm-up forwards", "sigma": SIGMA,
@@ -463,7 +463,7 @@ def main(argv=None):
                        "parallelism": f"batch-shard x{world} ({'independent replicas' if args.scaling == 'weak' else 'rows of one batch split'}, "
                                       f"no data-path collective)",
                        "launch": "eager" if args.no_graph else f"one hipGraph of {steps} steps",
-                       "operand_format": {"activations": {0: "plain", 1: "P16x64", 3: "F6x128 (int4 as FP6 E3M2 codes)"}[fmt],
+                       "operand_format": {"activations": {0: "plain", 1: "P16x64", 4: "R6x128 (int4 as FP6 E3M2 codes, row-contiguous)"}[fmt],
                                "weights": {0: "plain", 1: "P16x64", 2: "F16x64", 3: "F6x128 (int4 as FP6 E3M2 codes)"}[mixlib.fmt_of(layer._wpk)]},
                        "weight_bytes_resident": int(layer._wpk.numel() + (0 if layer._buffers['q_weight'] is None else layer._buffers['q_weight'].numel()))},
             "timing": {"clock": "HIP events on the launch stream around the K steps", "host_wall_ms_per_step": round(max_host * 1e3 / steps, 5),
@@ -476,11 +476,11 @@ def main(argv=None):
             "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
             "max_abs_err_vs_dequant_linear": round(max_abs_err, 6),
             # (W4A4 on the FP6 pipe is priced against the FP6 dense peak, 2x the int8 one: MI355X_MICROARCH.md "Peak FP6/FP4 MFMA ~10 PF dense")
-            "roofline": {"bound": "mfma", "kernel": ("FP6-pipe MFMA GEMM (int4 as E3M2 codes)" if fmt == 3 else "int8 MFMA GEMM") + " + fused epilogue (" +
+            "roofline": {"bound": "mfma", "kernel": ("FP6-pipe MFMA GEMM (int4 as E3M2 codes)" if fmt == 4 else "int8 MFMA GEMM") + " + fused epilogue (" +
                                                     _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(rows, N, K, bit, mixlib.fmt_of(layer._wpk))] + ")",
                          "rank": 0,
-                         "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS * (2 if fmt == 3 else 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_INT8_TOPS * (2 if fmt == 3 else 1)), 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS * (2 if fmt == 4 else 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_INT8_TOPS * (2 if fmt == 4 else 1)), 4), "traffic": traffic, "traffic_source": traffic_src,
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": flops_step,
                          "algorithmic_bytes_per_launch": (rows * K + N * K) * bit // 8 + 2 * rows * N},
             "device": info,

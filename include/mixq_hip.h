@@ -75,11 +75,18 @@ extern "C" {
  *                   mixq_pack_operand / mixq_unpack_operand (fmt = MIXQ_FMT_F6X128) convert from / to the plain nibble-packed
  *                   [R, K/2] matrix (KB = K/2 in their signature). */
 #define MIXQ_FMT_F6X128 3
+/* MIXQ_FMT_R6X128 : the ACTIVATION side of the same GEMM: the same blocks and the same 24-byte lane fragments, but in the block's first
+ *                   KiB a row's four 16-byte pieces stay together - row r at 64 r, fragment g at + 16 g - because a quantise kernel owns
+ *                   ONE row: two thirds of what it writes are 64-byte runs here, against 16-byte pieces at a 256-byte stride in fragment
+ *                   order.  (The 8-byte pieces stay at 1024 + 8 l: the b64 fragment reads of the GEMM want them lane-linear in LDS, and
+ *                   its LDS-DMA copies whole KiBs.)  The DMA permutes the 16-byte pieces inside a row's run into the bank swizzle of a
+ *                   P16X64 block (the source address of a DMA lane is free). */
+#define MIXQ_FMT_R6X128 4
 /* `layout` bits of the GEMM entry points */
 #define MIXQ_X_PACKED 1      /* q_x is MIXQ_FMT_P16X64 */
 #define MIXQ_W_PACKED 2      /* q_w is MIXQ_FMT_P16X64 */
 #define MIXQ_W_F16X64 8      /* q_w is MIXQ_FMT_F16X64 (requires MIXQ_X_PACKED) */
-#define MIXQ_XW_F6X128 16    /* mixq_gemm_i4_fused only: q_x AND q_w are MIXQ_FMT_F6X128 (no other layout bit) */
+#define MIXQ_XW_F6X128 16    /* mixq_gemm_i4_fused only: q_x is MIXQ_FMT_R6X128 and q_w MIXQ_FMT_F6X128 (no other layout bit) */
 
 typedef void* mixq_stream_t; /* hipStream_t */
 

@@ -29,7 +29,8 @@ ACT_SILU_MUL = 2
 FMT_PLAIN = 0
 FMT_P16X64 = 1
 FMT_F16X64 = 2
-FMT_F6X128 = 3          # int4 as FP6 codes, fragment order: both operands of the W4A4 GEMM on the FP6 matrix pipe
+FMT_F6X128 = 3          # int4 as FP6 codes, fragment order: the weights of the W4A4 GEMM on the FP6 matrix pipe
+FMT_R6X128 = 4          # ... and its activations: the same fragments, a row's 96 bytes of a block kept together
 X_PACKED = 1
 W_PACKED = 2
 W_F16X64 = 8

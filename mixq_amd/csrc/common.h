@@ -119,9 +119,13 @@ __device__ __forceinline__ size_t packed_offset(int fmt, int row, int kb, int ro
 // ---- MIXQ_FMT_F6X128 (include/mixq_hip.h): int4 values as FP6 E3M2 codes ------------------------------------------------------
 // code of a two's-complement nibble (-8 .. 7): sign bit 0x20, then the magnitude's code (3-bit exponent of bias 3, 2-bit mantissa):
 // 0 1 2 3 4 5 6 7 8 = 0x00 0x0c 0x10 0x12 0x14 0x15 0x16 0x17 0x18
+__device__ __forceinline__ uint32_t f6_code_of_int(int q) {                 // q in [-8, 8]
+    const uint32_t mag = static_cast<uint32_t>(q < 0 ? -q : q);
+    const uint32_t c = mag >= 4u ? mag + 16u : (0x12100C00u >> (mag * 8u)) & 0xffu;     // 4 .. 8: exponent 5 / 6, mantissa = the low bits
+    return c | (q < 0 ? 0x20u : 0u);
+}
 __device__ __forceinline__ uint32_t f6_code_of_nibble(uint32_t nib) {
-    const uint32_t neg = nib & 8u, mag = neg ? 16u - nib : nib;
-    return (neg << 2) | (static_cast<uint32_t>(0x18bdab494180ull >> (mag * 5)) & 0x1fu);
+    return f6_code_of_int(static_cast<int>(nib << 28) >> 28);
 }
 __device__ __forceinline__ uint32_t f6_nibble_of_code(uint32_t code) {      // inverse (codes that are no integer of [-8, 8] map to 0)
     const uint32_t c = code & 0x1fu;
@@ -132,18 +136,49 @@ __device__ __forceinline__ uint32_t f6_nibble_of_code(uint32_t code) {      // i
 __device__ __forceinline__ size_t f6_block_offset(int row, int k, int rows16) {
     return (static_cast<size_t>(k >> 7) * (rows16 >> 4) + (row >> 4)) * 1536;
 }
-__device__ __forceinline__ int f6_lane(int row, int k) { return (((k & 127) >> 5) << 4) | (row & 15); }
-// eight consecutive codes (elements 8 c8 .. 8 c8 + 7 of a lane's 32, c8 = 0..3) = 48 bits at byte 6 c8 of the lane's 24-byte fragment,
-// which lives at blk + 16 lane (bytes 0..15) and blk + 1024 + 8 lane (bytes 16..23)
-__device__ __forceinline__ void f6_store8(uint8_t* blk, int lane, int c8, const uint32_t (&code)[8]) {
+__device__ __forceinline__ int f6_group(int k) { return (k & 127) >> 5; }
+// where the two pieces of lane fragment (row, g = 32-element group of the block) live inside its block, by format:
+//   F6X128 (fragment order): 16 bytes at 16 lane, 8 bytes at 1024 + 8 lane, lane = 16 g + row % 16
+//   R6X128 (row runs):       16 bytes at 64 r + 16 g (a row's four pieces: one 64-byte run), 8 bytes at 1024 + 8 lane as above, r = row % 16
+__device__ __forceinline__ void f6_pieces(int fmt, uint8_t* blk, int row, int g, uint8_t*& A, uint8_t*& B) {
+    const int r = row & 15;
+    if (fmt == MIXQ_FMT_R6X128) { A = blk + r * 64 + g * 16; B = blk + 1024 + (g * 16 + r) * 8; }
+    else                        { A = blk + (g * 16 + r) * 16; B = blk + 1024 + (g * 16 + r) * 8; }
+}
+// eight consecutive codes (elements 8 c8 .. 8 c8 + 7 of a fragment's 32, c8 = 0..3) = 48 bits at byte 6 c8 of the 24-byte fragment
+__device__ __forceinline__ void f6_store8(int fmt, uint8_t* blk, int row, int g, int c8, const uint32_t (&code)[8]) {
     const uint32_t lo = code[0] | (code[1] << 6) | (code[2] << 12) | (code[3] << 18) | (code[4] << 24) | (code[5] << 30);
     const uint32_t hi = (code[5] >> 2) | (code[6] << 4) | (code[7] << 10);                   // 16 bits
-    uint8_t* A = blk + lane * 16;
-    uint8_t* B = blk + 1024 + lane * 8;
+    uint8_t *A, *B;
+    f6_pieces(fmt, blk, row, g, A, B);
     if (c8 == 0)      { *reinterpret_cast<uint32_t*>(A) = lo;      *reinterpret_cast<uint16_t*>(A + 4) = static_cast<uint16_t>(hi); }
     else if (c8 == 1) { *reinterpret_cast<uint16_t*>(A + 6) = static_cast<uint16_t>(lo); *reinterpret_cast<uint32_t*>(A + 8) = (lo >> 16) | (hi << 16); }
     else if (c8 == 2) { *reinterpret_cast<uint32_t*>(A + 12) = lo; *reinterpret_cast<uint16_t*>(B) = static_cast<uint16_t>(hi); }
     else              { *reinterpret_cast<uint16_t*>(B + 2) = static_cast<uint16_t>(lo); *reinterpret_cast<uint32_t*>(B + 4) = (lo >> 16) | (hi << 16); }
+}
+// sixteen consecutive codes (elements 16 h .. 16 h + 15 of a lane's 32, h = 0 / 1) = 96 bits (w0 w1 w2) at byte 12 h of the fragment: one
+// 12-byte store, or 4 + 8 bytes across the two pieces - what the quantisers write (two adjacent 8-element chunks at a time)
+__device__ __forceinline__ void f6_store_words(int fmt, uint8_t* blk, int row, int g, int h, uint32_t w0, uint32_t w1, uint32_t w2) {
+    uint8_t *A, *B;
+    f6_pieces(fmt, blk, row, g, A, B);
+    if (h == 0) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+        *reinterpret_cast<u32x3*>(A) = u32x3{w0, w1, w2};
+    } else {
+        *reinterpret_cast<uint32_t*>(A + 12) = w0;
+        *reinterpret_cast<uint2*>(B) = make_uint2(w1, w2);
+    }
+}
+// eight codes as 48 bits (lo: 32, hi: 16)
+__device__ __forceinline__ void f6_pack8(const uint32_t* c, uint32_t& lo, uint32_t& hi) {
+    lo = c[0] | (c[1] << 6) | (c[2] << 12) | (c[3] << 18) | (c[4] << 24) | (c[5] << 30);
+    hi = (c[5] >> 2) | (c[6] << 4) | (c[7] << 10);
+}
+__device__ __forceinline__ void f6_store16(int fmt, uint8_t* blk, int row, int g, int h, const uint32_t (&c)[16]) {
+    uint32_t lo0, hi0, lo1, hi1;
+    f6_pack8(c, lo0, hi0);
+    f6_pack8(c + 8, lo1, hi1);
+    f6_store_words(fmt, blk, row, g, h, lo0, hi0 | (lo1 << 16), (lo1 >> 16) | (hi1 << 16));
 }
 __device__ __forceinline__ int wave_id_uniform() {
     return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);

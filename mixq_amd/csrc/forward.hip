@@ -14,10 +14,10 @@ extern "C" int mixq_linear_forward(const mixq_linear_args* a, mixq_stream_t stre
         case MIXQ_FMT_PLAIN:  layout = 0; break;
         case MIXQ_FMT_P16X64: layout = MIXQ_W_PACKED; break;
         case MIXQ_FMT_F16X64: layout = MIXQ_W_F16X64; break;
-        case MIXQ_FMT_F6X128: layout = MIXQ_XW_F6X128; break;       // W4A4 on the FP6 matrix pipe: both operands as FP6 codes
+        case MIXQ_FMT_F6X128: layout = MIXQ_XW_F6X128; break;       // W4A4 on the FP6 matrix pipe: both operands as FP6 codes (activations: R6X128)
         default: return MIXQ_EINVAL;
     }
-    if ((a->wfmt == MIXQ_FMT_F6X128) != (a->qfmt == MIXQ_FMT_F6X128)) return MIXQ_EINVAL;
+    if ((a->wfmt == MIXQ_FMT_F6X128) != (a->qfmt == MIXQ_FMT_R6X128)) return MIXQ_EINVAL;    // FP6 weights go with row-contiguous FP6 activations
     if (a->wfmt == MIXQ_FMT_F6X128) { if (a->bit != 4) return MIXQ_EINVAL; }
     else if (a->qfmt == MIXQ_FMT_P16X64) layout |= MIXQ_X_PACKED;
     else if (a->qfmt != MIXQ_FMT_PLAIN) return MIXQ_EINVAL;         // (fragment-order activations are a producer-side experiment only)

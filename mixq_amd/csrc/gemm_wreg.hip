@@ -166,10 +166,17 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const int p = lw + i * LOADERS;
-            if constexpr (F6) {                            // 1 KiB pieces of a stage of 1.5 KiB blocks: a piece may straddle two blocks
+            if constexpr (F6) {
+                // 1 KiB pieces of a stage of 1.5 KiB blocks (a piece may straddle two blocks).  In the activation image
+                // (MIXQ_FMT_R6X128) a row's four 16-byte pieces form one 64-byte run - what a quantise kernel writes well - at 64 r of
+                // the block's first KiB; the LDS image holds them like a P16X64 block, piece g of row r at position g ^ (-(r >> 2) & 3)
+                // (conflict-free b128 fragment reads): four consecutive DMA lanes fetch one row's run, permuted.  The block's last
+                // 512 bytes (the 8-byte pieces, lane-linear) are copied as they are.  Every DMA instruction moves one contiguous KiB.
                 const int o = p * 1024 + lane * 16, blk = o / BLK, within = o - blk * BLK;
                 int rb = (m0 >> 4) + blk; rb = rb < a.xblocks ? rb : a.xblocks - 1;
-                src[i] = a.qx + static_cast<size_t>(rb) * BLK + within;
+                int off = within;
+                if (within < 1024) { const int sl = within >> 4, r = sl >> 2; off = r * 64 + 16 * ((sl & 3) ^ ((0 - (r >> 2)) & 3)); }
+                src[i] = a.qx + static_cast<size_t>(rb) * BLK + off;
             } else {
                 int rb = (m0 >> 4) + p; rb = rb < a.xblocks ? rb : a.xblocks - 1;  // blocks past M: loaded, computed, dropped
                 src[i] = a.qx + static_cast<size_t>(rb) * 1024 + lane * 16;
@@ -291,6 +298,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if (cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
         };
         const int lane16 = lane * 16, lane8 = lane * 8;
+        const int xoff8 = 1024 + lane8;                                          // F6: the fragment's 8-byte piece in the LDS image (see the loader)
         // activation fragment (row lm, k-chunk lq) inside a P16X64 block: conflict-free by the layout's swizzle (common.h)
         const int xoff = lm * 64 + ((lq ^ ((0 - (lm >> 2)) & 3)) << 4);
         // Weight register ring: NSLOT = D + 1 slots.  k-step kt is consumed from slot kt % NSLOT while the loads of k-step kt + D
@@ -421,8 +429,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (F6 && (ABL == 2 || ABL == 3)) {
                 // (ablation: no LDS reads)
             } else if constexpr (F6) {
-                const i32x4 p4 = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * BLK + lane16);
-                const i32x2 p2 = *reinterpret_cast<const i32x2*>(lds + slot * STAGE_BYTES + j * BLK + 1024 + lane8);
+                const i32x4 p4 = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * BLK + xoff);
+                const i32x2 p2 = *reinterpret_cast<const i32x2*>(lds + slot * STAGE_BYTES + j * BLK + xoff8);
                 xf6[j % XR] = i32x6{p4[0], p4[1], p4[2], p4[3], p2[0], p2[1]};
             } else
             if constexpr (ABL != 2 && ABL != 3)

@@ -139,6 +139,35 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
         if (flag && s > thr_scale) atomicOr(flag, 1);
     }
     char* qb = static_cast<char*>(q);
+    if constexpr (BIT == 4) {
+        if (fmt == MIXQ_FMT_F6X128 || fmt == MIXQ_FMT_R6X128) {
+            // FP6 codes leave in PAIRS of adjacent chunks (12 bytes: whole dwords).  The chunk -> thread map stays as it is - the order
+            // of the sum of squares depends on it - so the odd chunk's 48 bits travel to its even neighbour's lane.
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + i * NT;
+                const bool in = c < nchunk;                          // (K % 128 == 0: both chunks of a pair are in, or neither)
+                uint32_t lo = 0, hi = 0;
+                if (in) {
+                    const uint32_t d[4] = {keep[i].x, keep[i].y, keep[i].z, keep[i].w};
+                    uint32_t code[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        code[2 * e]     = f6_code_of_int(quant_exact<4>(h2f(static_cast<uint16_t>(d[e] & 0xffffu)), s, rs));
+                        code[2 * e + 1] = f6_code_of_int(quant_exact<4>(h2f(static_cast<uint16_t>(d[e] >> 16)), s, rs));
+                    }
+                    f6_pack8(code, lo, hi);
+                }
+                const uint32_t plo = __shfl_xor(lo, 1), phi = __shfl_xor(hi, 1);
+                if (in && !(c & 1)) {
+                    const int k = c * 8;
+                    f6_store_words(fmt, reinterpret_cast<uint8_t*>(qb) + f6_block_offset(row, k, rows16), row, f6_group(k), (k & 31) >> 4,
+                                   lo, hi | (plo << 16), (plo >> 16) | (phi << 16));
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + i * NT;
@@ -156,12 +185,6 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
                 o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
                 const size_t off = fmt ? packed_offset(fmt, row, c * 8, rows16) : static_cast<size_t>(row) * K + c * 8;
                 *reinterpret_cast<uint2*>(qb + off) = o;
-            } else if (fmt == MIXQ_FMT_F6X128) {                   // FP6 codes in fragment order (include/mixq_hip.h)
-                uint32_t code[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) code[e] = f6_code_of_nibble(static_cast<uint32_t>(qv[e]) & 0xfu);
-                const int k = c * 8;
-                f6_store8(reinterpret_cast<uint8_t*>(qb) + f6_block_offset(row, k, rows16), f6_lane(row, k), (k & 31) >> 3, code);
             } else {
                 uint32_t o = 0;
 #pragma unroll
@@ -213,7 +236,7 @@ extern "C" int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weigh
 {
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !weight || !out || !x_scale || !q))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !(qfmt == MIXQ_FMT_F6X128 && bit == 4)) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !((qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) && bit == 4)) return MIXQ_EINVAL;
     if (n > 0 && (!ind || !x_out || ldxo < n)) return MIXQ_EINVAL;
     if ((K & 7) || (ldx & 7) || (ldout & 7) || ldx < K || ldout < K || (bit == 4 && (K & 15))) return MIXQ_ESHAPE;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;

@@ -44,6 +44,16 @@ __device__ __forceinline__ float amax_finish(uint32_t acc) {
     return h2f(static_cast<uint16_t>(lo > hi ? lo : hi));
 }
 
+// FP6 codes of a chunk's 8 quantised values (MIXQ_FMT_F6X128)
+__device__ __forceinline__ void quant_codes8(const uint4& v, float s, float rs, uint32_t* code) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        code[2 * i]     = f6_code_of_int(quant_exact<4>(h2f(static_cast<uint16_t>(w[i] & 0xffffu)), s, rs));
+        code[2 * i + 1] = f6_code_of_int(quant_exact<4>(h2f(static_cast<uint16_t>(w[i] >> 16)), s, rs));
+    }
+}
+
 // q: plain -> row base pointer, packed (fmt != 0) -> matrix base pointer
 template <int BIT>
 __device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, void* q, int chunk, int row, int rows16, int fmt) {
@@ -60,12 +70,12 @@ __device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, 
         o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
         if (fmt) *reinterpret_cast<uint2*>(static_cast<char*>(q) + packed_offset(fmt, row, chunk * 8, rows16)) = o;
         else     reinterpret_cast<uint2*>(q)[chunk] = o;
-    } else if (fmt == MIXQ_FMT_F6X128) {   // FP6 codes in fragment order (include/mixq_hip.h): chunk = elements 8 chunk .. + 7 of the row
+    } else if (fmt == MIXQ_FMT_F6X128 || fmt == MIXQ_FMT_R6X128) {   // FP6 codes (include/mixq_hip.h): chunk = elements 8 chunk .. + 7 of the row
         uint32_t code[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) code[i] = f6_code_of_nibble(static_cast<uint32_t>(qv[i]) & 0xfu);
+        for (int i = 0; i < 8; ++i) code[i] = f6_code_of_int(qv[i]);
         const int k = chunk * 8;
-        f6_store8(static_cast<uint8_t*>(q) + f6_block_offset(row, k, rows16), f6_lane(row, k), (k & 31) >> 3, code);
+        f6_store8(fmt, static_cast<uint8_t*>(q) + f6_block_offset(row, k, rows16), row, f6_group(k), (k & 31) >> 3, code);
     } else {   // nibble pack: low nibble = even column (linear.py:14-18)
         uint32_t o = 0;
 #pragma unroll
@@ -199,10 +209,15 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     const int nchunk = K >> 3;
     const uint4* xv = reinterpret_cast<const uint4*>(xr);
 
+    // Chunk i of this thread: t + i TPR (consecutive threads, consecutive 16 bytes) - except for the FP6 output format, where a thread
+    // owns PAIRS of adjacent chunks (2 (t + (i / 2) TPR) + i % 2; NCH even): 16 codes are 12 bytes, one or two whole-dword stores,
+    // while the 6 bytes of a single chunk would be a dword and a halfword store at a 6-byte stride.
+    const bool pairs = BIT == 4 && NCH >= 2 && (fmt == MIXQ_FMT_F6X128 || fmt == MIXQ_FMT_R6X128);
+    auto chunk = [&](int i) { return pairs ? 2 * (t + (i >> 1) * TPR) + (i & 1) : t + i * TPR; };
     uint4 keep[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int c = t + i * TPR;
+        const int c = chunk(i);
         keep[i] = (valid && c < nchunk) ? xv[c] : make_uint4(0, 0, 0, 0);
     }
     int n = n_cap;
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     uint32_t amax_acc = 0u;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int c = t + i * TPR;
+        const int c = chunk(i);
         if (c < nchunk) {
             const uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
             amax_acc = amax8_masked(keep[i], m8, amax_acc);
@@ -259,10 +274,33 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         if (flag && s > thr_scale) atomicOr(flag, 1);
     }
     void* qrow = fmt ? q : static_cast<void*>(static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1)));
+    if constexpr (BIT == 4 && NCH >= 2) {
+        if (pairs) {                                               // (K % 128 == 0: a pair is inside the row or entirely outside)
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = t + i * TPR;
-        if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
+            for (int i = 0; i < NCH; i += 2) {
+                const int c = chunk(i);
+                if (c < nchunk) {
+                    uint32_t code[16];
+                    quant_codes8(keep[i], s, rs, code);
+                    quant_codes8(keep[i + 1], s, rs, code + 8);
+                    const int k = c * 8;
+                    if (dbg & 16) {                                  // timing probe (tools build): the same bytes to a row-contiguous place
+                        uint32_t lo0, hi0, lo1, hi1;
+                        f6_pack8(code, lo0, hi0); f6_pack8(code + 8, lo1, hi1);
+                        typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+                        *reinterpret_cast<u32x3*>(static_cast<uint8_t*>(q) + static_cast<size_t>(row) * (K * 3 / 4) + (c >> 1) * 12) = u32x3{lo0, hi0 | (lo1 << 16), (lo1 >> 16) | (hi1 << 16)};
+                    } else
+                    f6_store16(fmt, static_cast<uint8_t*>(q) + f6_block_offset(row, k, rows16), row, f6_group(k), (k & 31) >> 4, code);
+                }
+            }
+        }
+    }
+    if (!pairs) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = t + i * TPR;
+            if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
+        }
     }
     if (have_out) {
 #pragma unroll
@@ -467,7 +505,7 @@ __global__ __launch_bounds__(QT) void repack_kernel(const uint8_t* __restrict__ 
 
 // The same for MIXQ_FMT_F6X128: one thread per lane fragment (row, 32-element group): 16 bytes of nibbles <-> 24 bytes of FP6 codes.
 template <bool UNPACK>
-__global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R, int K, int rows16)
+__global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R, int K, int rows16, int fmt)
 {
     const long long t = static_cast<long long>(blockIdx.x) * QT + threadIdx.x;
     const long long total = static_cast<long long>(rows16) * (K >> 5);
@@ -480,8 +518,10 @@ __global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict
     const size_t plain = static_cast<size_t>(row) * (K >> 1) + (k0 >> 1);
     if constexpr (UNPACK) {
         if (row >= R) return;
-        const uint4 a = *reinterpret_cast<const uint4*>(src + blk + lane * 16);
-        const uint2 c = *reinterpret_cast<const uint2*>(src + blk + 1024 + lane * 8);
+        uint8_t *pa, *pb;
+        f6_pieces(fmt, const_cast<uint8_t*>(src) + blk, row, lane >> 4, pa, pb);
+        const uint4 a = *reinterpret_cast<const uint4*>(pa);
+        const uint2 c = *reinterpret_cast<const uint2*>(pb);
         const uint32_t w[6] = {a.x, a.y, a.z, a.w, c.x, c.y};
         uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -504,8 +544,10 @@ __global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict
             w[wi] |= code << sh;
             if (sh > 26) w[wi + 1] |= code >> (32 - sh);
         }
-        *reinterpret_cast<uint4*>(dst + blk + lane * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint2*>(dst + blk + 1024 + lane * 8) = make_uint2(w[4], w[5]);
+        uint8_t *pa, *pb;
+        f6_pieces(fmt, dst + blk, row, lane >> 4, pa, pb);
+        *reinterpret_cast<uint4*>(pa) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint2*>(pb) = make_uint2(w[4], w[5]);
     }
 }
 
@@ -528,7 +570,7 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g((M + RPB - 1) / RPB), b(TPR * RPB);
 #define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt, g_quant_dbg)
-    if      (nchunk <= 1 * TPR)  MIXQ_QLAUNCH2(1);
+    if      (nchunk <= 1 * TPR && qfmt != MIXQ_FMT_F6X128 && qfmt != MIXQ_FMT_R6X128)  MIXQ_QLAUNCH2(1);      // (the FP6 formats are written in chunk pairs)
     else if (nchunk <= 2 * TPR)  MIXQ_QLAUNCH2(2);
     else if (nchunk <= 4 * TPR)  MIXQ_QLAUNCH2(4);
     else if (nchunk <= 8 * TPR)  MIXQ_QLAUNCH2(8);
@@ -550,6 +592,8 @@ int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int
         // (no LDS reduction, no barrier) loses: its 64 elements per lane make the quantise arithmetic, not memory, the critical
         // path.  256 threads per row it is; the gain over round 1 is the gather from global memory instead of an LDS row copy.
         cfg = nchunk >= 512 ? 8 : 6;                     // (512 threads per row from K = 4096 up: 5.3 vs 5.7 us)
+        // FP6 codes leave in chunk pairs (2 chunks per thread at least); two rows per workgroup: 7.06 vs 7.9 us at K = 4096, 12.2 vs 12.9 at 11008
+        if (qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) cfg = nchunk <= 256 ? 5 : (nchunk <= 512 ? 7 : 9);
     }
     int rc = -100;
 #define MIXQ_Q2(TPR, RPB) rc = launch_quant_rows2<BIT, TPR, RPB>(x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, qfmt, st)
@@ -619,7 +663,7 @@ extern "C" int mixq_selftest_quant_exact(unsigned long long* mismatches_dev, int
 extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q, int M, int K, int ldx, int bit, int qfmt,
                                    mixq_stream_t stream)
 {
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !(qfmt == MIXQ_FMT_F6X128 && bit == 4)) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !((qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) && bit == 4)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || (M > 0 && (!x || !x_scale || !q))) return MIXQ_EINVAL;   // empty inputs may carry null pointers
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
@@ -634,7 +678,7 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
                                 uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt,
                                 mixq_stream_t stream)
 {
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !(qfmt == MIXQ_FMT_F6X128 && bit == 4)) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !((qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) && bit == 4)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !x_scale || !q))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
@@ -653,7 +697,7 @@ extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, con
                                      const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K,
                                      int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream)
 {
-    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !(qfmt == MIXQ_FMT_F6X128 && bit == 4)) return MIXQ_EINVAL;
+    if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !((qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) && bit == 4)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !x_scale || !q || !row_amax))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
@@ -726,18 +770,18 @@ extern "C" int mixq_dequant_weight_cols(const void* w, const uint16_t* scale_col
 static int repack_common(const void* src, void* dst, int R, int KB, int fmt, bool unpack, mixq_stream_t stream)
 {
     if (!src || !dst || R < 0 || KB <= 0) return MIXQ_EINVAL;
-    if (fmt != MIXQ_FMT_P16X64 && fmt != MIXQ_FMT_F16X64 && fmt != MIXQ_FMT_F6X128) return MIXQ_EINVAL;
+    if (fmt != MIXQ_FMT_P16X64 && fmt != MIXQ_FMT_F16X64 && fmt != MIXQ_FMT_F6X128 && fmt != MIXQ_FMT_R6X128) return MIXQ_EINVAL;
     if (KB % 64) return MIXQ_ESHAPE;
     if (R == 0) return MIXQ_OK;
     const int rows16 = (R + 15) & ~15;
-    if (fmt == MIXQ_FMT_F6X128) {                          // KB = K / 2 bytes of nibbles per row of the plain side
+    if (fmt == MIXQ_FMT_F6X128 || fmt == MIXQ_FMT_R6X128) {  // KB = K / 2 bytes of nibbles per row of the plain side
         const int K = KB * 2;
         const long long total6 = static_cast<long long>(rows16) * (K >> 5);
         const dim3 g6(static_cast<unsigned>((total6 + QT - 1) / QT));
         if (unpack) hipLaunchKernelGGL(repack_f6_kernel<true>, g6, dim3(QT), 0, mixq_stream(stream), static_cast<const uint8_t*>(src),
-                                       static_cast<uint8_t*>(dst), R, K, rows16);
+                                       static_cast<uint8_t*>(dst), R, K, rows16, fmt);
         else        hipLaunchKernelGGL(repack_f6_kernel<false>, g6, dim3(QT), 0, mixq_stream(stream), static_cast<const uint8_t*>(src),
-                                       static_cast<uint8_t*>(dst), R, K, rows16);
+                                       static_cast<uint8_t*>(dst), R, K, rows16, fmt);
         return mixq_launch_status();
     }
     const long long total = static_cast<long long>(rows16) * (KB >> 4);

@@ -22,7 +22,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import mixlib as _hip_mixlib
-from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128
+from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, FMT_R6X128
 
 # The kernel backend.  Always the HIP module in the product; tests that exercise the host-side state machine on a
 # machine without a GPU swap in an oracle-backed stand-in (tests/backend_oracle.py) via `set_backend`.
@@ -337,8 +337,8 @@ class MixLinear_GEMM(nn.Module):
         wpk = self._packed_weight()
         if wpk is None:
             return FMT_PLAIN
-        # fragment-order int8 weights go with P16X64 activations; the FP6 form takes both operands in F6X128
-        return FMT_F6X128 if _fmt_of(wpk) == FMT_F6X128 else FMT_P16X64
+        # fragment-order int8 weights go with P16X64 activations; FP6-coded weights with FP6-coded, row-contiguous activations
+        return FMT_R6X128 if _fmt_of(wpk) == FMT_F6X128 else FMT_P16X64
 
     def _packed_weight(self):
         """q_weight in the tile-major layout the GEMM streams fastest (include/mixq_hip.h); rebuilt when the buffer is

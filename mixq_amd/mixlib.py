@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import _capi
-from ._capi import (ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, X_PACKED, W_PACKED, W_F16X64,
+from ._capi import (ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, FMT_R6X128, X_PACKED, W_PACKED, W_F16X64,
                     XW_F6X128)
 
 
@@ -67,9 +67,9 @@ def fmt_of(t):
 
 
 def _layout_bits(x_fmt, w_fmt):
-    if x_fmt == FMT_F6X128 or w_fmt == FMT_F6X128:
-        if x_fmt != w_fmt:
-            raise RuntimeError("mixq_amd.mixlib: the FP6 form of the W4A4 GEMM takes BOTH operands in F6X128")
+    if x_fmt in (FMT_F6X128, FMT_R6X128) or w_fmt in (FMT_F6X128, FMT_R6X128):
+        if x_fmt != FMT_R6X128 or w_fmt != FMT_F6X128:
+            raise RuntimeError("mixq_amd.mixlib: the FP6 form of the W4A4 GEMM takes activations in R6X128 and weights in F6X128")
         return XW_F6X128
     if x_fmt == FMT_F16X64:
         raise RuntimeError("mixq_amd.mixlib: F16X64 is a weight format; the GEMMs take activations plain or in P16X64")
@@ -579,7 +579,7 @@ def PackOperand(q, fmt=FMT_P16X64):
         raise RuntimeError("PackOperand: expected a contiguous 2-D int8/uint8 tensor")
     R, KB = q.shape
     # (F6X128: KB = K / 2 bytes of nibbles per row in, 3 K / 4 bytes of FP6 codes per row out)
-    out = torch.empty((packed_rows(R), KB * 3 // 2 if fmt == FMT_F6X128 else KB), dtype=q.dtype, device=q.device)
+    out = torch.empty((packed_rows(R), KB * 3 // 2 if fmt in (FMT_F6X128, FMT_R6X128) else KB), dtype=q.dtype, device=q.device)
     _capi.call("mixq_pack_operand", q.data_ptr(), out.data_ptr(), R, KB, fmt, _stream())
     return set_fmt(out, fmt)
 
@@ -592,9 +592,9 @@ def UnpackOperand(packed, R, fmt=None):
     """Inverse of PackOperand: the plain [R,KB] matrix of a packed image."""
     _dev_check(packed)
     fmt = fmt_of(packed) if fmt is None else fmt
-    if fmt not in (FMT_P16X64, FMT_F16X64, FMT_F6X128):
+    if fmt not in (FMT_P16X64, FMT_F16X64, FMT_F6X128, FMT_R6X128):
         raise RuntimeError("UnpackOperand: the tensor carries no packed-format tag; pass fmt")
-    KB = packed.shape[1] * 2 // 3 if fmt == FMT_F6X128 else packed.shape[1]
+    KB = packed.shape[1] * 2 // 3 if fmt in (FMT_F6X128, FMT_R6X128) else packed.shape[1]
     out = torch.empty((R, KB), dtype=packed.dtype, device=packed.device)
     _capi.call("mixq_unpack_operand", packed.data_ptr(), out.data_ptr(), R, KB, fmt, _stream())
     return out
@@ -602,9 +602,9 @@ def UnpackOperand(packed, R, fmt=None):
 
 def _q_row_bytes(K, bit, fmt):
     """Bytes per row of a quantised activation buffer: K int8, K / 2 nibbles, or 3 K / 4 FP6 codes."""
-    if fmt == FMT_F6X128:
+    if fmt in (FMT_F6X128, FMT_R6X128):
         if bit != 4:
-            raise RuntimeError("mixq_amd.mixlib: F6X128 is an int4 format")
+            raise RuntimeError("mixq_amd.mixlib: F6X128 / R6X128 are int4 formats")
         return K * 3 // 4
     return K if bit == 8 else K // 2
 

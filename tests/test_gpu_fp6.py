@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 
 from mixq_amd import MixLibCache, MixLinear_GEMM, _capi, mixlib  # noqa: E402
 from mixq_amd import linear as L  # noqa: E402
-from mixq_amd._capi import FMT_F6X128, FMT_P16X64, FMT_PLAIN  # noqa: E402
+from mixq_amd._capi import FMT_F6X128, FMT_R6X128, FMT_P16X64, FMT_PLAIN  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from test_gpu_parity import _fused_case, make_x, n, t, ulp_tol  # noqa: E402
-from test_pack_properties import f6x128_reference, f6x128_unpack  # noqa: E402
+from test_pack_properties import f6x128_reference, f6x128_unpack, r6x128_reference, r6x128_to_fragment_order  # noqa: E402
 
 DEV = "cuda"
 F6_TILINGS = ["wr128x192_s16_d4_l2", "wr128x128_s16_d4_l2", "wr64x128_s16_d4_l2", "wr64x192_s16_d4_l2", "wr64x256_s16_d4_l2"]
@@ -49,6 +49,11 @@ def test_pack_matches_the_format_byte_for_byte_and_unpack_inverts_it(R, K):
     assert np.array_equal(f6x128_unpack(n(img).reshape(-1), R, K), v)
     # the host-side inverse the state_dict of a layer moved to the CPU uses
     assert np.array_equal(L._unpack_host(img.cpu(), R, FMT_F6X128).numpy(), p)
+    # the activation side's row-contiguous form
+    img_r = mixlib.PackOperand(t(p), FMT_R6X128)
+    assert mixlib.fmt_of(img_r) == FMT_R6X128 and img_r.shape == img.shape
+    assert np.array_equal(n(img_r).reshape(-1), r6x128_reference(v))
+    assert np.array_equal(n(mixlib.UnpackOperand(img_r, R)), p)
 
 
 def test_entry_points_validate_the_format():
@@ -60,7 +65,7 @@ def test_entry_points_validate_the_format():
                                   out.data_ptr(), 64, 16, 64, 128, 0, _capi.XW_F6X128, None) == _capi.MIXQ_EINVAL   # an int4 layout
     xs = torch.zeros(16, dtype=torch.float16, device=DEV)
     x = torch.zeros(16, 128, dtype=torch.float16, device=DEV)
-    assert lib.mixq_quant_fused(x.data_ptr(), None, 0, None, xs.data_ptr(), out.data_ptr(), None, None, 16, 128, 128, 0, 8, 6.0, FMT_F6X128,
+    assert lib.mixq_quant_fused(x.data_ptr(), None, 0, None, xs.data_ptr(), out.data_ptr(), None, None, 16, 128, 128, 0, 8, 6.0, FMT_R6X128,
                                 None) == _capi.MIXQ_EINVAL                                                          # an int4 format
 
 
@@ -75,28 +80,38 @@ def test_quantisers_emit_the_format_directly(M, K, ncols):
     xs = [torch.zeros(M, dtype=torch.float16, device=DEV) for _ in range(2)]
     xa, xb = t(x.copy()), t(x.copy())
     q_plain, xo1 = mixlib.QuantFused(xa, ind, xs[0], 4, 6.0, fmt=FMT_PLAIN)
-    q_f6, xo2 = mixlib.QuantFused(xb, ind, xs[1], 4, 6.0, fmt=FMT_F6X128)
-    assert mixlib.fmt_of(q_f6) == FMT_F6X128 and q_f6.shape[1] == K * 3 // 4
-    assert torch.equal(mixlib.UnpackOperand(q_f6, M), q_plain) and torch.equal(xs[0], xs[1]) and torch.equal(xa, xb)
-    assert ncols == 0 or torch.equal(xo1, xo2)
-    # ... the oracle's quantisation of the zeroed rows, code for code
     xz = x.copy()
     if ncols:
         O.extract_outliers_zero(xz, ind_np)
     q_or, s_or = O.find_row_scale(xz, 4)
-    assert np.array_equal(f6x128_unpack(n(q_f6).reshape(-1), M, K), O.unpack_i4_all(q_or))
-    assert np.array_equal(n(xs[1]).view(np.uint16), s_or.view(np.uint16).reshape(-1))
-    q_frs = mixlib.FindRowScalePacked(t(xz), xs[0], M, K, bit=4, fmt=FMT_F6X128)
+    for fmt in (FMT_R6X128, FMT_F6X128):                 # (the GEMM takes the first; the second is the weight format, supported for symmetry)
+        xb = t(x.copy())
+        xs[1].zero_()
+        q_f6, xo2 = mixlib.QuantFused(xb, ind, xs[1], 4, 6.0, fmt=fmt)
+        assert mixlib.fmt_of(q_f6) == fmt and q_f6.shape[1] == K * 3 // 4
+        assert torch.equal(mixlib.UnpackOperand(q_f6, M), q_plain) and torch.equal(xs[0], xs[1]) and torch.equal(xa, xb)
+        assert ncols == 0 or torch.equal(xo1, xo2)
+        # ... the oracle's quantisation of the zeroed rows, code for code
+        img = n(q_f6).reshape(-1)
+        assert np.array_equal(f6x128_unpack(img if fmt == FMT_F6X128 else r6x128_to_fragment_order(img, M, K), M, K), O.unpack_i4_all(q_or))
+        assert np.array_equal(n(xs[1]).view(np.uint16), s_or.view(np.uint16).reshape(-1))
+        for cfg in (0, 4, 5, 6, 7, 8, 9):                # every launch geometry writes the same bytes (pairs of chunks per thread, or single chunks)
+            assert _capi.load().mixq_quant_set_config(cfg) == 0
+            q2, _ = mixlib.QuantFused(t(x.copy()), ind, xs[1], 4, 6.0, fmt=fmt)
+            _capi.load().mixq_quant_set_config(-1)
+            assert torch.equal(mixlib.UnpackOperand(q2, M), q_plain), cfg
+    q_frs = mixlib.FindRowScalePacked(t(xz), xs[0], M, K, bit=4, fmt=FMT_R6X128)
     assert torch.equal(mixlib.UnpackOperand(q_frs, M), t(q_or))
     # fused RMSNorm + quantise
     w = t((rng.standard_normal(K) * 0.1 + 1).astype(np.float16))
     outs = []
-    for fmt in (FMT_PLAIN, FMT_F6X128):
+    for fmt in (FMT_PLAIN, FMT_R6X128, FMT_F6X128):
         out = torch.empty(M, K, dtype=torch.float16, device=DEV)
         q, xo = mixlib.RMSNormQuantFused(t(x.copy()), w, out, 1e-5, ind, xs[0], 4, sigma=6.0, fmt=fmt)
         outs.append((out, q if fmt == FMT_PLAIN else mixlib.UnpackOperand(q, M), xo, xs[0].clone()))
-    for a, b in zip(outs[0], outs[1]):
-        assert (a is None and b is None) or torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert (a is None and b is None) or torch.equal(a, b)
 
 
 CASES = [
@@ -127,7 +142,7 @@ def test_fp6_gemm_vs_oracle_and_bit_identical_to_the_int8_expansion(M, N, K, n_o
     run = lambda qx, qw: mixlib.FusedLinear(qx, qw, sx, t(c["sw"]), xo, wo, n_out, b, M, N, K, **args)
     lib, names = _capi.load(), _capi.gemm_config_names()
     y8 = run(mixlib.PackOperand(t(c["qx"]), FMT_P16X64), mixlib.PackOperand(t(c["qw"]), FMT_P16X64))
-    x6, w6 = mixlib.PackOperand(t(c["qx"]), FMT_F6X128), mixlib.PackOperand(t(c["qw"]), FMT_F6X128)
+    x6, w6 = mixlib.PackOperand(t(c["qx"]), FMT_R6X128), mixlib.PackOperand(t(c["qw"]), FMT_F6X128)
     try:
         for cfg in [-1] + [names.index(nm) for nm in F6_TILINGS]:
             assert lib.mixq_gemm_set_config(cfg) == 0
@@ -148,6 +163,8 @@ def test_fp6_gemm_vs_oracle_and_bit_identical_to_the_int8_expansion(M, N, K, n_o
         lib.mixq_gemm_set_config(-1)
     with pytest.raises(RuntimeError):
         mixlib.FusedLinear(x6, mixlib.PackOperand(t(c["qw"]), FMT_P16X64), sx, t(c["sw"]), xo, wo, n_out, b, M, N, K, **args)
+    with pytest.raises(RuntimeError):                     # activations in the WEIGHT format: the DMA would gather the wrong bytes
+        mixlib.FusedLinear(mixlib.PackOperand(t(c["qx"]), FMT_F6X128), w6, sx, t(c["sw"]), xo, wo, n_out, b, M, N, K, **args)
 
 
 def test_fp6_gemm_extreme_operands_stay_exact():
@@ -160,7 +177,7 @@ def test_fp6_gemm_extreme_operands_stay_exact():
         want = (qx.astype(np.int64) @ qw.astype(np.int64).T).astype(np.float64)
         sx = torch.ones((M, 1), dtype=torch.float16, device=DEV) * 2.0 ** -12
         sw = torch.ones((1, N), dtype=torch.float16, device=DEV) * 2.0 ** -10
-        y = mixlib.FusedLinear(mixlib.PackOperand(t(O.pack_i4(qx)), FMT_F6X128), mixlib.PackOperand(t(O.pack_i4(qw)), FMT_F6X128), sx, sw, None, None, 0,
+        y = mixlib.FusedLinear(mixlib.PackOperand(t(O.pack_i4(qx)), FMT_R6X128), mixlib.PackOperand(t(O.pack_i4(qw)), FMT_F6X128), sx, sw, None, None, 0,
                                None, M, N, K, bit=4)
         ref = (want * 2.0 ** -22).astype(np.float16)
         assert np.array_equal(n(y).view(np.uint16), ref.view(np.uint16))
@@ -191,7 +208,8 @@ def test_four_bit_layer_runs_on_the_fp6_pipe_and_equals_the_int8_expansion():
             x[:, cols] *= 20
             ys.append(layer(x.to(DEV), None, True).clone())
         assert layer.add_outliers is False and layer._plan is not None
-        assert mixlib.fmt_of(layer._packed_weight()) == fmt and layer.x_fmt() == fmt and mixlib.fmt_of(cache.q_xcache) == fmt
+        xf = FMT_R6X128 if fmt == FMT_F6X128 else fmt
+        assert mixlib.fmt_of(layer._packed_weight()) == fmt and layer.x_fmt() == xf and mixlib.fmt_of(cache.q_xcache) == xf
         outs[fmt] = (ys, layer, cache)
     L.PACK_FMT4 = FMT_F6X128
     for a, b in zip(outs[FMT_F6X128][0], outs[FMT_P16X64][0]):

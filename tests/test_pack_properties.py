@@ -96,6 +96,34 @@ def f6x128_reference(v):
     return out
 
 
+def r6x128_reference(v):
+    """MIXQ_FMT_R6X128 (the activation side): the same blocks and 24-byte fragments; in the block's first KiB a row's four 16-byte pieces
+    form one run (64 r + 16 g); the 8-byte pieces stay lane-linear in its last 512 bytes (1024 + 8 (16 g + r))."""
+    R, K = v.shape
+    rows16 = (R + 15) // 16 * 16
+    frag = f6x128_reference(v).reshape(K // 128, rows16 // 16, 1536)
+    out = np.zeros_like(frag)
+    for r in range(16):
+        for g in range(4):
+            lane = g * 16 + r
+            out[:, :, r * 64 + g * 16: r * 64 + g * 16 + 16] = frag[:, :, lane * 16: lane * 16 + 16]
+            out[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8] = frag[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8]
+    return out.reshape(-1)
+
+
+def r6x128_to_fragment_order(buf, R, K):
+    """An R6X128 image re-ordered into F6X128 (for f6x128_unpack)."""
+    rows16 = (R + 15) // 16 * 16
+    src = np.asarray(buf, dtype=np.uint8).reshape(K // 128, rows16 // 16, 1536)
+    out = np.zeros_like(src)
+    for r in range(16):
+        for g in range(4):
+            lane = g * 16 + r
+            out[:, :, lane * 16: lane * 16 + 16] = src[:, :, r * 64 + g * 16: r * 64 + g * 16 + 16]
+            out[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8] = src[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8]
+    return out.reshape(-1)
+
+
 def f6x128_unpack(buf, R, K):
     """Inverse of f6x128_reference through the VALUES the codes denote (so a code that is no integer would show)."""
     rows16 = (R + 15) // 16 * 16
@@ -139,6 +167,7 @@ def test_f6x128_layout_is_a_bijection_and_host_unpack_inverts_it(rows, kblocks, 
     rows16 = (rows + 15) // 16 * 16
     back = _unpack_host(torch.from_numpy(buf.reshape(rows16, 96 * kblocks)), rows, 3).numpy()
     assert np.array_equal(back, O.pack_i4(v))
+    assert np.array_equal(r6x128_to_fragment_order(r6x128_reference(v), rows, 128 * kblocks), buf)
     # the 16-byte pieces of a block are read with ds_read_b128 at 16 l and the 8-byte pieces with ds_read_b64 at 1024 + 8 l: consecutive
     # lanes, consecutive addresses - no two lanes of a service group share a bank (MI355X_MICROARCH.md, LDS)
     assert len({(16 * l) // 16 % 16 for l in range(16)}) == 16 and len({(1024 + 8 * l) // 8 % 32 for l in range(32)}) == 32
@@ -151,6 +180,8 @@ def packed_reference(q, fmt):
 def packed_unpack(buf, R, KB, fmt):
     if fmt == 3:                                             # F6X128: KB = K / 2 nibble bytes per row of the plain matrix
         return O.pack_i4(f6x128_unpack(buf, R, KB * 2))
+    if fmt == 4:                                             # R6X128: the activation side's row-contiguous form
+        return O.pack_i4(f6x128_unpack(r6x128_to_fragment_order(buf, R, KB * 2), R, KB * 2))
     return {1: p16x64_unpack, 2: f16x64_unpack}[fmt](buf, R, KB)
 
 

@@ -37,7 +37,7 @@ if args.bit == 4:
     qx, qw = qx.view(torch.uint8), qw.view(torch.uint8)
 sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
 sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
-xp = mixlib.PackOperand(qx, 3 if args.f6 else 1)
+xp = mixlib.PackOperand(qx, 4 if args.f6 else 1)
 wp = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 3 if args.f6 else 2)}
 xo = wo = None
 if args.nout:

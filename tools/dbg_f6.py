@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mixq_amd import _capi, mixlib  # noqa: E402
-from mixq_amd._capi import FMT_F6X128, FMT_P16X64, FMT_PLAIN  # noqa: E402
+from mixq_amd._capi import FMT_F6X128, FMT_R6X128, FMT_P16X64, FMT_PLAIN  # noqa: E402
 
 dev = "cuda"
 lib = _capi.load()
@@ -29,8 +29,9 @@ def nibbles(R, K, lo=-8):
 for R, K in [(16, 128), (37, 256), (500, 4096)]:
     v, p = nibbles(R, K)
     img = mixlib.PackOperand(p.to(dev), FMT_F6X128)
+    img2 = mixlib.PackOperand(p.to(dev), FMT_R6X128)
     back = mixlib.UnpackOperand(img, R)
-    ok = torch.equal(back.cpu(), p)
+    ok = torch.equal(back.cpu(), p) and torch.equal(mixlib.UnpackOperand(img2, R).cpu(), p)
     print(f"pack/unpack {R}x{K}: image {tuple(img.shape)} {'ok' if ok else 'MISMATCH'}")
     fails += not ok
 # 2. quantiser
@@ -39,7 +40,7 @@ for M, K, n in [(512, 4096, 41), (37, 256, 0), (100, 11008 // 128 * 128, 17)]:
     ind = torch.randperm(K, generator=g)[:n].to(torch.int32).to(dev) if n else None
     xs1, xs2 = torch.zeros(M, dtype=torch.float16, device=dev), torch.zeros(M, dtype=torch.float16, device=dev)
     q_plain, xo1 = mixlib.QuantFused(x.clone().to(dev), ind, xs1, 4, 6.0, fmt=FMT_PLAIN)
-    q_f6, xo2 = mixlib.QuantFused(x.clone().to(dev), ind, xs2, 4, 6.0, fmt=FMT_F6X128)
+    q_f6, xo2 = mixlib.QuantFused(x.clone().to(dev), ind, xs2, 4, 6.0, fmt=FMT_R6X128)
     back = mixlib.UnpackOperand(q_f6, M)
     ok = torch.equal(back, q_plain) and torch.equal(xs1, xs2) and (n == 0 or torch.equal(xo1, xo2))
     print(f"quantiser {M}x{K} n_out={n}: F6 image {tuple(q_f6.shape)} {'ok' if ok else 'MISMATCH'}")
@@ -65,7 +66,7 @@ for M, N, K, n_out in shapes:
         wo = torch.randn((N, pad), generator=g).half().to(dev)[:, :n_out]
     bias = torch.randn(N, generator=g).half().to(dev)
     xp, wp = mixlib.PackOperand(qx, FMT_P16X64), mixlib.PackOperand(qw, FMT_P16X64)
-    x6, w6 = mixlib.PackOperand(qx, FMT_F6X128), mixlib.PackOperand(qw, FMT_F6X128)
+    x6, w6 = mixlib.PackOperand(qx, FMT_R6X128), mixlib.PackOperand(qw, FMT_F6X128)
     lib.mixq_gemm_set_config(-1)
     want = mixlib.FusedLinear(xp, wp, sx, sw, xo, wo, n_out, bias, M, N, K, bit=4)
     auto = mixlib.FusedLinear(x6, w6, sx, sw, xo, wo, n_out, bias, M, N, K, bit=4)

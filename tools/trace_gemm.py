@@ -36,7 +36,7 @@ def main():
         sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
         if args.bit == 4:
             qx, qw = qx.view(torch.uint8), qw.view(torch.uint8)
-        qxp = mixlib.PackOperand(qx, 3 if args.f6 else 1)
+        qxp = mixlib.PackOperand(qx, 4 if args.f6 else 1)
         qw_by_fmt = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 3 if args.f6 else 2)}
         out = torch.empty(M, N, dtype=torch.float16, device=dev)
         xo = wo = None
