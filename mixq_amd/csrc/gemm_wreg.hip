@@ -528,13 +528,17 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                         __builtin_amdgcn_sched_barrier(0);
                         continue;
                     }
-                    if constexpr (ABL != 31) {
+#ifdef MIXQ_R2_ORDER                                 // (a second product build with round 2's order, for tools/ab_libs.py; never shipped)
+                    constexpr bool NEW_ORDER = false;
+#else
+                    constexpr bool NEW_ORDER = ABL != 31;
+#endif
+                    if constexpr (NEW_ORDER) {
                         // At most ONE memory instruction per MFMA gap: a wave issues in order and a 16-cycle MFMA leaves ~12 cycles in
                         // which one fragment read or one weight load can be issued for free.  The weight load goes behind the group's
                         // FIRST MFMA, the fragment's re-read behind its last use (round 2 put both behind the last).  Measured: -1.6 %
-                        // against the old order compiled into the same (tuning) library, 26.69 vs 26.79 us between two product builds
-                        // (profiles/r03_gemm_ab_issue_timing.txt, r03_ab_order_builds.txt): at the noise floor - co-compiled variants
-                        // perturb each other's code placement (cdna_hip_programming.md 5.4 rule 19) - kept because it is never worse.
+                        // against the old order compiled into the same (tuning) library, -1.8 % / -1.5 % at N = 11008 / 12288 between
+                        // two product builds loaded side by side (profiles/r03_gemm_ab_issue_timing.txt, r03_ab_order_builds.txt).
                         acc[j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][0], xf[j], acc[j][0], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         loads_behind(j);
@@ -1002,23 +1006,27 @@ struct WrConfig {
 #define MIXQ_WR(MBv, WNBv, NS, Dv, LD, ABL, TAG)                                                                        \
     { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, ABL>,                                     \
       gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, ABL>, nullptr, 0 }
-// ... and with the FP6 form: X ring of NS6 stages (12 KiB each at 128 rows), weight ring of 3 k-steps (a k-step is 128 elements)
-#define MIXQ_WR6(MBv, WNBv, NS, Dv, LD, NS6, TAG)                                                                       \
+// ... and with the FP6 form: X ring of NS6 stages (12 KiB each at 128 rows), weight ring of D6 k-steps: 2 for the 128-row tiles (a k-step
+// is 128 elements, twice the time of an int8 one; 3 deep is 2.7 % slower - 22.03 vs 22.68 us at the metric shape), 3 for the 64-row
+// tiles, whose k-steps are half as long (64 x 128 at 11008 -> 4096: 24.7 us with 3 or 4, 28.9 with 2; at 4096 -> 4096 12.6 / 12.9 / 13.5 us with 2 / 3 / 4): 3.  Tried and dropped: assembling the
+// tuples of k-step kt+1 DURING k-step kt into a second tuple set (two ring slots + two sets, the 9 moves spread behind MFMAs instead of
+// sitting in front of the first one): 24.5 vs 22.5 us, and wrong results on the 64-row tiles.
+#define MIXQ_WR6(MBv, WNBv, NS, Dv, LD, NS6, D6, TAG)                                                                   \
     { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 0>,                                       \
       gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, 0>,                \
-      gemm_wreg_kernel<MBv, WNBv, NS6, 3, 2, LD, 0>, NS6 }
+      gemm_wreg_kernel<MBv, WNBv, NS6, D6, 2, LD, 0>, NS6 }
 
 const WrConfig g_wr[] = {
     // name = tile (activation rows x weight rows) _ X ring depth _ weight ring depth _ loader waves
-    MIXQ_WR6(8, 3, 16, 4, 2, 8, "128x192_s16_d4_l2"),  // 0: the metric shape's tile: 232 tiles at 512 x 11008
+    MIXQ_WR6(8, 3, 16, 4, 2, 8, 2, "128x192_s16_d4_l2"),  // 0: the metric shape's tile: 232 tiles at 512 x 11008
     MIXQ_WR(8, 3, 16, 3, 2, 0, "128x192_s16_d3_l2"),   // 1
     MIXQ_WR(8, 3, 8, 4, 1, 0, "128x192_s8_d4_l1"),     // 2: the first form of this kernel (8-deep X ring, one loader)
     MIXQ_WR(8, 3, 12, 4, 2, 0, "128x192_s12_d4_l2"),   // 3
-    MIXQ_WR6(8, 2, 16, 4, 2, 8, "128x128_s16_d4_l2"),  // 4
+    MIXQ_WR6(8, 2, 16, 4, 2, 8, 2, "128x128_s16_d4_l2"),  // 4
     MIXQ_WR(8, 4, 16, 3, 2, 0, "128x256_s16_d3_l2"),   // 5 (int4: weight ring depth 2)
-    MIXQ_WR6(4, 2, 16, 4, 2, 12, "64x128_s16_d4_l2"),  // 6: N = 4096 at M = 512 is exactly 256 such tiles
-    MIXQ_WR6(4, 3, 16, 4, 2, 12, "64x192_s16_d4_l2"),  // 7: N = 6144
-    MIXQ_WR6(4, 4, 16, 4, 2, 12, "64x256_s16_d4_l2"),  // 8
+    MIXQ_WR6(4, 2, 16, 4, 2, 12, 3, "64x128_s16_d4_l2"),  // 6: N = 4096 at M = 512 is exactly 256 such tiles
+    MIXQ_WR6(4, 3, 16, 4, 2, 12, 3, "64x192_s16_d4_l2"),  // 7: N = 6144
+    MIXQ_WR6(4, 4, 16, 4, 2, 12, 3, "64x256_s16_d4_l2"),  // 8
     MIXQ_WR(8, 1, 8, 4, 1, 0, "128x64_s8_d4_l1"),      // 9
     MIXQ_WR(4, 1, 8, 4, 1, 0, "64x64_s8_d4_l1"),       // 10
     MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 11
@@ -1030,12 +1038,15 @@ const WrConfig g_wr[] = {
     // (profiles/r02_decode.txt)
     MIXQ_WR(2, 1, 8, 6, 1, 0, "32x64_s8_d6_l1"),       // 14 (WR_SMALL)
 #ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): only in the tools build (make tuning)
-    { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
-    { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 2, 2>, 8 },
-    { "wr128x192_f6_abl3_mfma", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 2, 3>, 8 },
-    { "wr128x192_f6_s10", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 10, 3, 2, 2, 0>, 10 },         // deeper X ring
-    { "wr128x192_f6_d2", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 0>, 8 },            // shallower weight ring
-    { "wr128x192_f6_l4", 8, 3, 16, 4, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 4, 0>, 8 },            // four loader waves
+    { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
+    { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 2>, 8 },
+    { "wr128x192_f6_abl3_mfma", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 3>, 8 },
+    { "wr128x192_f6_s10", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 10, 2, 2, 2, 0>, 10 },         // deeper X ring
+    { "wr128x192_f6_d3", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 2, 0>, 8 },            // deeper weight ring
+    { "wr64x128_f6_d2", 4, 2, 16, 2, nullptr, nullptr, gemm_wreg_kernel<4, 2, 12, 2, 2, 2, 0>, 12 },           // 64-row tile, shallower / deeper weight rings
+    { "wr64x128_f6_d3", 4, 2, 16, 2, nullptr, nullptr, gemm_wreg_kernel<4, 2, 12, 3, 2, 2, 0>, 12 },
+    { "wr64x128_f6_d5", 4, 2, 16, 2, nullptr, nullptr, gemm_wreg_kernel<4, 2, 12, 5, 2, 2, 0>, 12 },
+    { "wr128x192_f6_l4", 8, 3, 16, 4, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 4, 0>, 8 },            // four loader waves
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic
     MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // cfg 0, MFMA + epilogue only

@@ -1,10 +1,10 @@
 #!/bin/bash
-export MIXQ_TUNING_LIB=1
 mkdir -p gpurun_out
 {
-python tools/dbg_f6.py 512x11008x4096x128,200x328x512x143,512x4096x11008x128
-for shp in 512x11008x4096 512x4096x11008; do
-timeout 300 python tools/ab_gemm.py --shape $shp --bit 4 --f6 --nout 128 --rounds 20 --cfgs wr128x192_s16_d4_l2,wr128x192_f6_abl3_mfma,wr64x128_s16_d4_l2,128x192_w2x2_s5_l4
+timeout 600 python -m pytest tests/test_gpu_fp6.py -m gpu -q -x 2>&1 | tail -4
+export MIXQ_TUNING_LIB=1
+for shp in 512x4096x11008 512x4096x4096; do
+timeout 300 python tools/ab_gemm.py --shape $shp --bit 4 --f6 --nout 128 --rounds 20 --cfgs wr64x128_s16_d4_l2,wr64x128_f6_d2,wr64x128_f6_d3,wr64x128_f6_d5,64x128_w2x2_s5_l4
 done
-} > gpurun_out/r03_f6_ab2.txt 2>&1
-grep -v amdgpu.ids gpurun_out/r03_f6_ab2.txt | tail -40
+} > gpurun_out/r03_f6_ab4.txt 2>&1
+grep -v amdgpu.ids gpurun_out/r03_f6_ab4.txt | tail -40
