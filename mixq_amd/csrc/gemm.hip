@@ -1074,9 +1074,9 @@ extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) 
     if (M <= 0 || N <= 0 || K <= 0 || (bit != 4 && bit != 8)) return MIXQ_EINVAL;
     const int KB = bit == 8 ? K : K / 2;
     const int dec = NUM_CFGS + mixq_sk_num_configs();
+    if (fmt == MIXQ_FMT_F6X128) return bit == 4 ? dec + 1 + mixq_wr_pick(6, M, N, KB) : MIXQ_EINVAL;   // (FP6-coded operands: the weights-in-registers kernels only)
     const bool wide_wr = fmt == MIXQ_FMT_F16X64 && bit == 8 && N >= 8192;                 // as in gemm_fused_common
     if (!wide_wr && fmt != MIXQ_FMT_PLAIN && mixq_skinny_applies(bit, M, N, KB, true, true)) return dec;
-    if (fmt == MIXQ_FMT_F6X128) return bit == 4 ? dec + 1 + mixq_wr_pick(6, M, N, KB) : MIXQ_EINVAL;
     if (fmt == MIXQ_FMT_F16X64) return (bit == 8 && prefill_prefers_lds256(M, N)) ? LDS256 : dec + 1 + mixq_wr_pick(bit, M, N, KB);
     return mixq_gemm_pick_config(M, N, K, bit);
 }

@@ -43,7 +43,8 @@ class FasterTransformerRMSNorm(nn.Module):
             raise NotImplementedError
         cache = self.cache
         # the layout and the outlier bookkeeping (capacity-padded `ind`, device-resident count) are the NEXT layer's
-        fmt = nl.x_fmt() if (hasattr(nl, "x_fmt") and hasattr(_backend, "PackOperand")) else 0
+        rows = x.numel() // x.shape[-1]                      # (4-bit layers take small batches in another layout than large ones)
+        fmt = nl.x_fmt(rows) if (hasattr(nl, "x_fmt") and hasattr(_backend, "PackOperand")) else 0
         n = int(nl.ind.shape[0])
         if n and hasattr(nl, "_ind_dev") and hasattr(_backend, "PackOperand"):
             ind, n_dev = nl._ind_dev()

@@ -44,6 +44,11 @@ PACK_FMT = FMT_F16X64
 # bit at 1.6x the int8 MFMA rate: 22.9 vs 27.6 us at 512 x 4096 -> 11008, 24.9 vs 32.3 us at 11008 -> 4096).  FMT_P16X64 selects the
 # int8-expansion kernel instead (nibbles, two thirds of the FP6 image's weight bytes: the better trade for weight-stream-bound decode).
 PACK_FMT4 = FMT_F6X128
+# Small batches of a 4-bit layer are a weight stream, and nibbles are two thirds of the FP6 image's bytes (M <= 32: 13.8 vs 16.7 us at
+# 4096 -> 11008, 9.3 vs 15.7 at 4096 -> 4096, 14.2 vs 28.0 at 11008 -> 4096; tools/time_w4_small_batch.py).  A layer that meets such a batch
+# keeps a SECOND, nibble image for it (+ 2/3 of the FP6 image: 288 GB of HBM per GPU is not what a 4-bit model runs out of); layers that
+# only ever see large batches never build it.  0 disables.
+SMALL_BATCH_M4 = 32
 # After a layer's outlier search has frozen, keep ONLY the packed weight image in HBM (the plain [N,K] `q_weight` is
 # re-created on demand for state_dict / attribute reads).  False keeps both copies (2x the reference's weight memory).
 COMPACT_WEIGHTS = True
@@ -171,6 +176,8 @@ class MixLinear_GEMM(nn.Module):
         self._wstore = None          # _ColStore behind weight_cache once outliers were appended online
         self._wpk = None             # q_weight re-tiled to PACK_FMT (built once, on the first forward)
         self._wpk_key = None
+        self._wpk_small = None       # 4-bit layers: the nibble image small batches stream (SMALL_BATCH_M4), built when one arrives
+        self._wpk_small_key = None
         self._wo_ready = None        # weight_cache in the GEMM tail's padded layout (built when it is not already)
         self._wo_key = None
         self._ind_buf = None         # `ind` padded to a multiple of 16 entries: the capacity the kernels are given
@@ -308,6 +315,7 @@ class MixLinear_GEMM(nn.Module):
                 else:
                     self._buffers["q_weight"] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self._wpk.device)
                     self._wpk, self._wpk_key = None, None                # re-packed on the next forward
+                    self._wpk_small, self._wpk_small_key = None, None
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def _apply(self, fn, *args, **kwargs):
@@ -322,6 +330,7 @@ class MixLinear_GEMM(nn.Module):
                     _backend.set_fmt(moved, tag)
                 self._wpk = moved
         self._wpk_key = None                                             # (re-packed from q_weight when that buffer still exists)
+        self._wpk_small, self._wpk_small_key = None, None                # (rebuilt when a small batch arrives)
         if isinstance(self.__dict__.get("weight_cache"), Tensor):
             self.weight_cache = fn(self.weight_cache)                    # 8-bit layers keep it as a plain attribute (linear.py:42)
         if isinstance(self.__dict__.get("ind"), Tensor):
@@ -332,17 +341,34 @@ class MixLinear_GEMM(nn.Module):
         self._n_dev, self._n_dev_host = None, -1
         return out
 
-    def x_fmt(self):
-        """Layout this layer wants its quantised activation in (what a fused norm in front of it should emit)."""
-        wpk = self._packed_weight()
+    def x_fmt(self, M=None):
+        """Layout this layer wants its quantised activation in for a batch of M rows (what a fused norm in front of it should emit)."""
+        wpk = self._packed_weight(M)
         if wpk is None:
             return FMT_PLAIN
         # fragment-order int8 weights go with P16X64 activations; FP6-coded weights with FP6-coded, row-contiguous activations
         return FMT_R6X128 if _fmt_of(wpk) == FMT_F6X128 else FMT_P16X64
 
-    def _packed_weight(self):
-        """q_weight in the tile-major layout the GEMM streams fastest (include/mixq_hip.h); rebuilt when the buffer is
+    def _small_batch_image(self, M):
+        return self.bit == 4 and M is not None and 0 < M <= SMALL_BATCH_M4 and PACK_FMT4 == FMT_F6X128 and not self.weight_only
+
+    def _packed_small(self):
+        """The nibble (P16X64) image of a 4-bit layer, for small batches; made from the plain matrix while it exists, from the FP6 image after."""
+        qw = self._buffers.get("q_weight")
+        main = self._packed_weight()
+        if main is None:
+            return None
+        key = (id(main), main._version) if qw is None else (id(qw), qw.data_ptr(), qw._version)
+        if self._wpk_small is None or self._wpk_small_key != key:
+            plain = qw if qw is not None else self._plain_weight()
+            self._wpk_small, self._wpk_small_key = _backend.PackOperand(plain, FMT_P16X64), key
+        return self._wpk_small
+
+    def _packed_weight(self, M=None):
+        """q_weight in the tile-major layout the GEMM streams fastest for a batch of M rows (include/mixq_hip.h); rebuilt when the buffer is
         replaced or rewritten (checkpoint load)."""
+        if self._small_batch_image(M):
+            return self._packed_small()
         qw = self._buffers.get("q_weight")
         if qw is None:
             return self._wpk                                             # compacted: the packed image is all there is
@@ -432,10 +458,10 @@ class MixLinear_GEMM(nn.Module):
                 n_dev, n_cap = self._n_dev, cap
             else:
                 n_dev, n_cap = None, n
-        wpk = self._packed_weight()
+        wpk = self._packed_weight(M)
         qx = cache.q_xcache
         w = wpk if wpk is not None else self.q_weight
-        want = self.x_fmt()
+        want = self.x_fmt(M)
         if _fmt_of(qx) != want and hasattr(_backend, "PackOperand"):
             # the producer of q_xcache (e.g. the reference's own fused norm through the mixlib shim) used another layout
             if _fmt_of(qx) != FMT_PLAIN:
@@ -469,7 +495,7 @@ class MixLinear_GEMM(nn.Module):
         if wc is None:
             wc = b.get("weight_cache")
         qw = b.get("q_weight")
-        return (M, inputs.stride(0), id(cache), id(cache.x_scale), id(ind), ind._version, id(d.get("_wpk")), id(qw),
+        return (M, inputs.stride(0), id(cache), id(cache.x_scale), id(ind), ind._version, id(d.get("_wpk")), id(d.get("_wpk_small")), id(qw),
                 -1 if qw is None else qw._version, id(wc), -1 if wc is None else wc._version, id(b.get("bias", d.get("bias"))),
                 id(b.get("scale_col")), PACK_FMT)
 
@@ -477,7 +503,7 @@ class MixLinear_GEMM(nn.Module):
         if not hasattr(_backend, "ForwardPlan") or M == 0 or inputs.dtype != torch.float16 or inputs.stride(1) != 1 \
                 or inputs.stride(0) % 8 or not inputs.is_cuda:
             return None
-        wpk = self._packed_weight()
+        wpk = self._packed_weight(M)
         if wpk is None:
             return None                                      # K % 64: plain operands, the two-call route serves them
         n = int(self.ind.shape[0])
@@ -493,7 +519,7 @@ class MixLinear_GEMM(nn.Module):
                 return None
             wo = _wide(wo, _pad16(n))
         return _backend.ForwardPlan(M, self.out_features, self.in_features, self.bit, self._sigma_f, inputs.stride(0), ind_buf, n, n_dev,
-                                    cache.x_scale, wpk, self.scale_col, wo, self.bias, self.x_fmt())
+                                    cache.x_scale, wpk, self.scale_col, wo, self.bias, self.x_fmt(M))
 
     # ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -542,7 +568,7 @@ class MixLinear_GEMM(nn.Module):
             if self.add_outliers:
                 flag = cache.flag
                 flag.zero_()
-            fmt = self.x_fmt()
+            fmt = self.x_fmt(M)
             ind_buf, n_dev = self._ind_dev()
             if hasattr(_backend, "PackOperand"):
                 cache.q_xcache, xo = _backend.QuantFused(inputs, ind_buf, cache.x_scale, self.bit, self._sigma_f, flag=flag,
@@ -566,7 +592,7 @@ class MixLinear_GEMM(nn.Module):
                 ind = self.FindOutliers(inputs)
                 cache.new_ind = ind
                 self._append_outliers(cache, inputs, ind)
-                fmt = self.x_fmt()
+                fmt = self.x_fmt(M)
                 if fmt != FMT_PLAIN:
                     cache.q_xcache = _backend.FindRowScalePacked(inputs, cache.x_scale, M, self.in_features, self.bit, fmt=fmt)
                 else:

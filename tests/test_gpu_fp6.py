@@ -268,3 +268,29 @@ def test_mlp_block_w4a4_shares_the_fp6_activation():
     L.PACK_FMT4 = FMT_F6X128
     for a, b in zip(res[FMT_F6X128], res[FMT_P16X64]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_small_batches_of_a_four_bit_layer_stream_a_nibble_image():
+    """M <= SMALL_BATCH_M4: a weight stream - the layer serves it from a second, nibble image (built when the first small batch arrives,
+    also after the plain matrix was dropped) with P16X64 activations; larger batches keep the FP6 pair.  Same bits either way."""
+    K, N, ncols = 1024, 320, 10
+    outs = {}
+    for fmt in (FMT_F6X128, FMT_P16X64):
+        L.PACK_FMT4 = fmt
+        layer, cache, cols = _layer(96, K, N, ncols, True)
+        ys = []
+        for call, M in enumerate((96, 96, 96, 16, 96, 1, 32, 33)):
+            x = torch.randn(M, K, generator=torch.Generator().manual_seed(40 + call)).half()
+            x[:, cols] *= 20
+            if fmt == FMT_F6X128 and call == 3:
+                assert layer._wpk_small is None and layer._buffers["q_weight"] is None       # frozen, compacted, no small batch seen yet
+            ys.append(layer(x.to(DEV), None, True).clone())
+            if fmt == FMT_F6X128:
+                small = M <= L.SMALL_BATCH_M4
+                assert mixlib.fmt_of(cache.q_xcache) == (FMT_P16X64 if small else FMT_R6X128), (M, mixlib.fmt_of(cache.q_xcache))
+        if fmt == FMT_F6X128:
+            assert layer._wpk_small is not None and mixlib.fmt_of(layer._wpk_small) == FMT_P16X64 and mixlib.fmt_of(layer._wpk) == FMT_F6X128
+        outs[fmt] = ys
+    L.PACK_FMT4 = FMT_F6X128
+    for a, b in zip(outs[FMT_F6X128], outs[FMT_P16X64]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

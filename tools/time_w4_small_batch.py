@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""4-bit layer forward at small batches: FP6-coded weights (the default) against nibble weights (PACK_FMT4 = FMT_P16X64: skinny / LDS-staged
+kernels); us per forward in a graph of 50 forwards, frozen layer."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mixq_amd import MixLibCache, MixLinear_GEMM, _capi
+from mixq_amd import linear as L
+from mixq_amd._capi import FMT_F6X128, FMT_P16X64
+dev = "cuda"
+names = _capi.gemm_config_names()
+for (K, N) in [(4096, 11008), (4096, 4096), (11008, 4096)]:
+    for M in (1, 16, 32, 64, 128, 256):
+        row = []
+        for fmt in (FMT_F6X128, FMT_P16X64):
+            L.PACK_FMT4 = fmt
+            torch.manual_seed(0)
+            cache = MixLibCache(M, bit=4, device=dev)
+            ls = torch.ones(K); ls[torch.randperm(K)[:128]] = 20.0
+            layer = MixLinear_GEMM.from_linear(torch.nn.Linear(K, N, bias=False).half(), 4, cache=cache, layer_scales=ls, dev=dev)
+            x = torch.randn(8, M, K).half().to(dev)
+            for i in range(3):
+                layer(x[i].clone(), None, True)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for i in range(50):
+                        layer(x[i % 8], None, True)
+                torch.cuda.synchronize()
+                g.replay(); torch.cuda.synchronize()
+                t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize()
+                us = (time.perf_counter() - t0) * 1e6 / 50
+            cfg = names[_capi.load().mixq_gemm_pick_config_fmt(M, N, K, 4, fmt)]
+            row.append(f"{'fp6' if fmt == FMT_F6X128 else 'nibble'} {us:6.1f} us ({cfg})")
+        print(f"{K:6d}->{N:6d} M={M:4d}: " + "   ".join(row), flush=True)
+L.PACK_FMT4 = FMT_F6X128
