@@ -448,7 +448,8 @@ def main(argv=None):
 
     if rank == 0:
         fmt = layer.x_fmt()
-        traffic, traffic_src = hbm_traffic_from_profile()
+        # (the committed PMC passes profiled the metric configuration: any other shape / bit width / per-rank batch carries no traffic figure)
+        traffic, traffic_src = hbm_traffic_from_profile() if (bit == 8 and (rows, K, N) == (512, 4096, 11008)) else (None, None)
         shape_note = "Llama-2-7b up_proj shape" if (K, N) == (4096, 11008) else f"{K}->{N}"
         out = {
             "metric": f"effective int8 TFLOPS, W{bit}A{bit}O16 MixQ Linear forward (quantise + {'int8' if bit == 8 or fmt != 4 else 'FP6-pipe'} MFMA GEMM + fused dequant/outlier "

@@ -32,7 +32,8 @@ for (K, N) in [(4096, 11008), (4096, 4096), (11008, 4096)]:
                 g.replay(); torch.cuda.synchronize()
                 t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize()
                 us = (time.perf_counter() - t0) * 1e6 / 50
-            cfg = names[_capi.load().mixq_gemm_pick_config_fmt(M, N, K, 4, fmt)]
+            used = getattr(layer._packed_weight(M), "_mixq_fmt", 0)                   # (the FP6 layer serves small batches from its nibble image)
+            cfg = names[_capi.load().mixq_gemm_pick_config_fmt(M, N, K, 4, used)] + (" on its nibble image" if used != fmt else "")
             row.append(f"{'fp6' if fmt == FMT_F6X128 else 'nibble'} {us:6.1f} us ({cfg})")
         print(f"{K:6d}->{N:6d} M={M:4d}: " + "   ".join(row), flush=True)
 L.PACK_FMT4 = FMT_F6X128
