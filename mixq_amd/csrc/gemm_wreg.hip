@@ -88,7 +88,14 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // v_mfma_i32_16x16x64_i8 - gfx950 has no int4 MFMA, and the nibble form (Q = 1) pays the int8 rate plus the expansion.
     // Operand blocks are 16 rows x 128 elements = 1.5 KiB in fragment order (MIXQ_FMT_F6X128, include/mixq_hip.h): a lane's 24 bytes
     // are a 16-byte piece at block + 16 lane and an 8-byte piece at block + 1024 + 8 lane.
-    constexpr bool I4 = Q == 1, F6 = Q == 2;
+    // Q = 3 (F6R): the same with the weight ring held AS the 6-register operand tuples.  One load cannot fill a 192-bit tuple, so each
+    // fragment's dwordx4 + dwordx2 are two outputs of one asm statement that are concatenated into the tuple right there - a pure
+    // renaming IF the register coalescer assigns the outputs to the tuple's sub-registers (it does: no v_mov in the loop, checked on the
+    // ISA by tools/check_wreg_asm.py and by the bit-exact tests - a copy at that point would read registers whose loads are in flight).
+    // That removes the 9 v_mov_b64 + wait states in front of each k-step's first MFMA of the Q = 2 form.  Loads are unconditional
+    // (requests past the end of K wrap around to the first k-steps: valid addresses, never consumed, drained behind the loop), so
+    // every wait is a compile-time count.
+    constexpr bool I4 = Q == 1, F6 = Q >= 2, F6R = Q == 3;
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
     constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
@@ -109,6 +116,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int TAILX = NSTAGE * STAGE_BYTES;          // LDS offset of those blocks: behind the ring, [TQ][MB] x 1 KiB
     static_assert(MB % ISSUERS == 0 && (STAGE_BYTES / 1024) % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
     static_assert(!F6 || (!SELF && (ABL == 0 || ABL == 1 || ABL == 2 || ABL == 3)), "the FP6 form exists for the shipped loop (and its feed ablations) only");
+    static_assert(!F6R || ABL == 0, "the tuple-ring form has no ablations");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
     static_assert(!SELF || (LOOK == D + 1 && !I4 && ABL == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
     static_assert(NSTAGE * STAGE_BYTES + TQ * MB * 1024 <= 160 * 1024, "X ring + tail blocks must fit the 160 KiB of LDS");
@@ -294,8 +302,20 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         const size_t wks = static_cast<size_t>(a.wblocks) * BLK;
         int wk = rot;                                    // k-step the next weight loads read
         size_t woff = static_cast<size_t>(rot) * wks;
-        auto wadvance = [&](int cond) MIXQ_INL {                    // once per requested k-step (cond: wave-uniform 0 / 1)
-            if (cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
+        i32x6 wr6[F6R ? D + 1 : 1][F6R ? WNB : 1];                               // F6R: the weight ring as operand tuples (D + 1 slots, as wq below)
+        auto wadvance = [&](int cond) MIXQ_INL {                    // once per requested k-step (cond: wave-uniform 0 / 1; F6R requests always)
+            if (F6R || cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
+        };
+        auto wload6 = [&](auto d_c, int i) MIXQ_INL {               // F6R: fragment i of the k-step at woff -> tuple i of ring slot d
+            constexpr int d = decltype(d_c)::value;
+            if constexpr (F6R) {
+                const uint8_t* src = wb[i] + woff;
+                const int l16 = lane * 16, l8 = lane * 8;
+                i32x4 lo; i32x2 hi;
+                asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:1024"
+                             : "=v"(lo), "=v"(hi) : "v"(l16), "v"(l8), "s"(src) : "memory");
+                wr6[d][i] = i32x6{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
+            }
         };
         const int lane16 = lane * 16, lane8 = lane * 8;
         const int xoff8 = 1024 + lane8;                                          // F6: the fragment's 8-byte piece in the LDS image (see the loader)
@@ -344,7 +364,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // meaningful after wwait() for that slot.
         auto wload1 = [&](auto d_c, int i, int cond) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
-            if constexpr (ABL != 1 && ABL != 3) {
+            if constexpr (F6R) { (void)cond; wload6(d_c, i); }
+            else if constexpr (ABL != 1 && ABL != 3) {
                 const int cs = __builtin_amdgcn_readfirstlane(cond);             // provably wave-uniform for the "s" constraint
                 const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];                     // (named outside the statement: implicit capture does not look into asm operands)
@@ -361,7 +382,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         };
         auto wload1_always = [&](auto d_c, int i) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
-            if constexpr (ABL != 1 && ABL != 3) {
+            if constexpr (F6R) wload6(d_c, i);
+            else if constexpr (ABL != 1 && ABL != 3) {
                 const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];
                 const int l16 = lane16;
@@ -378,6 +400,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // as read-write operands makes every MFMA that uses them depend on this statement
         auto wwait = [&](auto d_c, auto cnt_c) MIXQ_INL {
             constexpr int d = decltype(d_c)::value, CNT = decltype(cnt_c)::value;
+            if constexpr (F6R) {
+#if defined(__HIP_DEVICE_COMPILE__)                  // (192-bit "v" operands: device pass only)
+                if constexpr (WNB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr6[d][0]) : "i"(CNT));
+                if constexpr (WNB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wr6[d][0]), "+v"(wr6[d][1]) : "i"(CNT));
+                if constexpr (WNB == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wr6[d][0]), "+v"(wr6[d][1]), "+v"(wr6[d][2]) : "i"(CNT));
+                if constexpr (WNB == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wr6[d][0]), "+v"(wr6[d][1]), "+v"(wr6[d][2]), "+v"(wr6[d][3]) : "i"(CNT));
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            } else
             if constexpr (ABL != 1 && ABL != 3) {
                 if constexpr (WNB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wq[d][0]) : "i"(CNT));
                 if constexpr (WNB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wq[d][0]), "+v"(wq[d][1]) : "i"(CNT));
@@ -393,7 +424,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // the same with a run-time count (tail of the k loop): CNT in {0, WNB, 2 WNB, ...}, selected inside ONE statement
         auto wwait_rt = [&](auto d_c, int younger) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
-            if constexpr (ABL != 1 && ABL != 3) {
+            if constexpr (F6R) { (void)younger; wwait(d_c, std::integral_constant<int, WL * (D - 1)>{}); }   // (every k-step requests: the count is fixed)
+            else if constexpr (ABL != 1 && ABL != 3) {
                 const int sel = __builtin_amdgcn_readfirstlane(younger >= D - 1 ? D - 1 : younger);   // k-steps requested after this one, capped at the ring depth
 #define MIXQ_WR_W1(n, l) "s_cmp_lt_u32 %[sel], " #n "\n\ts_cbranch_scc1 " #l "f\n\t"
 #define MIXQ_WR_W2(l, c) #l ":\n\ts_waitcnt vmcnt(%[" #c "])\n\ts_branch 199f\n"
@@ -462,7 +494,29 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     if (pos == j) { if constexpr (FULL) wload1_always(LC{}, i); else wload1(LC{}, i, issue); }
                 }
             };
-            if constexpr (F6) {
+            if constexpr (F6R) {
+                const int unit = 0x7f7f7f7f;                                       // E8M0 block scales of 2^0
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MIXQ_F6_MMA(ACC, W, X) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:3 blgp:3" \
+                                            : "+v"(ACC) : "v"(W), "v"(X), "v"(unit))
+#else
+#define MIXQ_F6_MMA(ACC, W, X) (void)unit
+#endif
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    MIXQ_F6_MMA(acc[j][0], wr6[C][0], xf6[j % XR]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    loads_behind(j);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 1; i < WNB; ++i) MIXQ_F6_MMA(acc[j][i], wr6[C][i], xf6[j % XR]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + XR < MB) xread(rslot == 0 ? NSTAGE - 1 : rslot - 1, j + XR);
+                    else if (refill) xread(rslot, j + XR - MB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef MIXQ_F6_MMA
+            } else if constexpr (F6) {
                 // Same order as the int8 loop: weight load behind the group's first MFMA, the fragment's re-read behind its last.
                 // The MFMA is inline asm: the compiler's form of the scaled MFMA is not tied (vdst != srcC, accumulators rotating through
                 // VGPRs), which runs at 32 cycles instead of 19.5 (tools/ubench_fp6.hip) and doubles the accumulator footprint.  In asm
@@ -717,6 +771,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             auto tail_one = [&](auto c_c) MIXQ_INL { if (k0 + decltype(c_c)::value < nk) one(c_c, std::false_type{}); };
             wr_static_for<0, NSLOT>(tail_one);
         }
+        if constexpr (F6R) wr_wait_vmcnt<0>();                                   // the wrapped-around requests of the last k-steps: nothing may land in a register the epilogue re-uses
         if constexpr (F6) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // asm MFMA -> accumulator reads: wait states the compiler cannot count
         stamp(2);
         }
@@ -1006,7 +1061,8 @@ struct WrConfig {
 #define MIXQ_WR(MBv, WNBv, NS, Dv, LD, ABL, TAG)                                                                        \
     { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, ABL>,                                     \
       gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, ABL>, nullptr, 0 }
-// ... and with the FP6 form: X ring of NS6 stages (12 KiB each at 128 rows), weight ring of D6 k-steps: 2 for the 128-row tiles (a k-step
+// ... and with the FP6 form (Q = 3: the weight ring held as operand tuples; 20.9 vs 22.1 us at the metric shape against Q = 2, which
+// assembles the tuples in front of each k-step's first MFMA and stays as a tuning config): X ring of NS6 stages (12 KiB each at 128 rows), weight ring of D6 k-steps: 2 for the 128-row tiles (a k-step
 // is 128 elements, twice the time of an int8 one; 3 deep is 2.7 % slower - 22.03 vs 22.68 us at the metric shape), 3 for the 64-row
 // tiles, whose k-steps are half as long (64 x 128 at 11008 -> 4096: 24.7 us with 3 or 4, 28.9 with 2; at 4096 -> 4096 12.6 / 12.9 / 13.5 us with 2 / 3 / 4): 3.  Tried and dropped: assembling the
 // tuples of k-step kt+1 DURING k-step kt into a second tuple set (two ring slots + two sets, the 9 moves spread behind MFMAs instead of
@@ -1014,7 +1070,7 @@ struct WrConfig {
 #define MIXQ_WR6(MBv, WNBv, NS, Dv, LD, NS6, D6, TAG)                                                                   \
     { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 0>,                                       \
       gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, 0>,                \
-      gemm_wreg_kernel<MBv, WNBv, NS6, D6, 2, LD, 0>, NS6 }
+      gemm_wreg_kernel<MBv, WNBv, NS6, D6, 3, LD, 0>, NS6 }
 
 const WrConfig g_wr[] = {
     // name = tile (activation rows x weight rows) _ X ring depth _ weight ring depth _ loader waves
@@ -1041,11 +1097,11 @@ const WrConfig g_wr[] = {
     { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
     { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 2>, 8 },
     { "wr128x192_f6_abl3_mfma", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 3>, 8 },
-    { "wr128x192_f6_s10", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 10, 2, 2, 2, 0>, 10 },         // deeper X ring
-    { "wr128x192_f6_d3", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 2, 2, 0>, 8 },            // deeper weight ring
-    { "wr64x128_f6_d2", 4, 2, 16, 2, nullptr, nullptr, gemm_wreg_kernel<4, 2, 12, 2, 2, 2, 0>, 12 },           // 64-row tile, shallower / deeper weight rings
-    { "wr64x128_f6_d3", 4, 2, 16, 2, nullptr, nullptr, gemm_wreg_kernel<4, 2, 12, 3, 2, 2, 0>, 12 },
-    { "wr64x128_f6_d5", 4, 2, 16, 2, nullptr, nullptr, gemm_wreg_kernel<4, 2, 12, 5, 2, 2, 0>, 12 },
+    { "wr128x192_f6_s10", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 10, 2, 2, 2, 0>, 10 },         // deeper X ring (Q = 2)
+    { "wr128x192_f6mov_d2", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 0>, 8 },         // Q = 2: tuples assembled by v_mov in front of each k-step (the first FP6 form)
+    { "wr64x128_f6mov_d3", 4, 2, 16, 2, nullptr, nullptr, gemm_wreg_kernel<4, 2, 12, 3, 2, 2, 0>, 12 },
+    { "wr128x192_f6r_d3", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 3, 2, 0>, 8 },           // Q = 3 ring variants
+    { "wr128x192_f6r_s10", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 10, 2, 3, 2, 0>, 10 },
     { "wr128x192_f6_l4", 8, 3, 16, 4, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 4, 0>, 8 },            // four loader waves
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic

@@ -9,7 +9,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (source file, kernel name, how to read the template arguments out of the mangled name)
 TARGETS = [
-    ("gemm_wreg.hip", "gemm_wreg_kernel", r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)", "MB={0} WNB={1} NSTAGE={2} D={3} I4={4} L={5} ABL={6}", 6),
+    ("gemm_wreg.hip", "gemm_wreg_kernel", r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)", "MB={0} WNB={1} NSTAGE={2} D={3} Q={4} L={5} ABL={6}", 6),
     ("gemm_w8a16.hip", "gemm_w8a16_kernel", r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)", "w8a16 MB={0} WNB={1} NSTAGE={2} D={3} L={4} ABL={5}", 5),
 ]
 
@@ -44,7 +44,7 @@ def check(fname, kname, tag_re, tag_fmt, abl_idx):
             t = ln.strip()
             if t.startswith(";;#ASMSTART"): in_asm = True
             elif t.startswith(";;#ASMEND"): in_asm = False
-            elif in_asm and t.startswith("global_load_dwordx4"):
+            elif in_asm and t.startswith(("global_load_dwordx4", "global_load_dwordx2")):   # (dwordx2: the 8-byte pieces of the FP6 form's fragments)
                 loaded |= regs(t.split()[1].rstrip(","))
         # the k loop and its tail: from the first hand-placed wait to the last one
         first = last = None
@@ -53,7 +53,7 @@ def check(fname, kname, tag_re, tag_fmt, abl_idx):
             t = ln.strip()
             if t.startswith(";;#ASMSTART"): in_asm = True
             elif t.startswith(";;#ASMEND"): in_asm = False
-            elif in_asm and t.startswith("global_load_dwordx4"): seen_load = True
+            elif in_asm and t.startswith(("global_load_dwordx4", "global_load_dwordx2")): seen_load = True
             elif in_asm and t.startswith("s_waitcnt vmcnt") and seen_load:       # (the loader wave's own waits come before any ring load)
                 if first is None: first = i            # (the prologue gives every slot a defined value BEFORE its first load: harmless copies)
                 if any("sched_barrier" in x for x in lines[i:i + 4]): last = i    # a ring wait (the trace drain at the very end is not)

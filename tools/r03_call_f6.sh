@@ -17,7 +17,7 @@ n=_capi.gemm_config_names()
 print(','.join(str(i) for i,x in enumerate(n) if x in ('wr128x192_s16_d4_l2','wr128x192_f6_abl3_mfma')))")
 python tools/trace_gemm.py --shapes 512x11008x4096 --cfgs $C --bit 4 --f6 --nout 128 > gpurun_out/r03w4_trace.txt 2>&1
 for shp in 512x11008x4096 512x4096x11008; do
-python tools/ab_gemm.py --shape $shp --bit 4 --f6 --nout 128 --rounds 20 --cfgs wr128x192_s16_d4_l2,wr128x192_f6_abl1_noW,wr128x192_f6_abl2_noX,wr128x192_f6_abl3_mfma,wr128x192_f6_s10,wr128x192_f6_d3,wr128x192_f6_l4,wr64x128_s16_d4_l2,128x192_w2x2_s5_l4
+python tools/ab_gemm.py --shape $shp --bit 4 --f6 --nout 128 --rounds 20 --cfgs wr128x192_s16_d4_l2,wr128x192_f6_abl1_noW,wr128x192_f6_abl2_noX,wr128x192_f6_abl3_mfma,wr128x192_f6mov_d2,wr128x192_f6r_d3,wr128x192_f6r_s10,wr128x192_f6_l4,wr64x128_s16_d4_l2,128x192_w2x2_s5_l4
 done > gpurun_out/r03w4_ab.txt 2>&1
 python tools/time_quant4.py > gpurun_out/r03w4_quant.txt 2>&1
 head -6 gpurun_out/r03w4_kt.txt; cat gpurun_out/r03w4_bench.json | head -c 600; echo; grep -A4 "cfg2" gpurun_out/r03w4_configs.txt
