@@ -295,7 +295,24 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
             }
         }
     }
-    if (!pairs) {
+    // ONE chunk per thread (NCH = 1) and an FP6 format: the odd chunk's 48 bits travel to its even neighbour's lane, which stores the pair
+    // (12 bytes, whole dwords) - half the per-thread quantise arithmetic of the two-chunks-per-thread form above
+    const bool xchg = BIT == 4 && NCH == 1 && (fmt == MIXQ_FMT_F6X128 || fmt == MIXQ_FMT_R6X128);
+    if constexpr (BIT == 4 && NCH == 1) {
+        if (xchg) {
+            const int c = t;
+            const bool in = c < nchunk;                                // (K % 128 == 0: both chunks of a pair are in, or neither)
+            uint32_t lo = 0, hi = 0;
+            if (in) { uint32_t code[8]; quant_codes8(keep[0], s, rs, code); f6_pack8(code, lo, hi); }
+            const uint32_t plo = __shfl_xor(lo, 1), phi = __shfl_xor(hi, 1);
+            if (in && !(c & 1)) {
+                const int k = c * 8;
+                f6_store_words(fmt, static_cast<uint8_t*>(q) + f6_block_offset(row, k, rows16), row, f6_group(k), (k & 31) >> 4,
+                               lo, hi | (plo << 16), (plo >> 16) | (phi << 16));
+            }
+        }
+    }
+    if (!pairs && !xchg) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = t + i * TPR;
@@ -570,7 +587,7 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g((M + RPB - 1) / RPB), b(TPR * RPB);
 #define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt, g_quant_dbg)
-    if      (nchunk <= 1 * TPR && qfmt != MIXQ_FMT_F6X128 && qfmt != MIXQ_FMT_R6X128)  MIXQ_QLAUNCH2(1);      // (the FP6 formats are written in chunk pairs)
+    if      (nchunk <= 1 * TPR)  MIXQ_QLAUNCH2(1);
     else if (nchunk <= 2 * TPR)  MIXQ_QLAUNCH2(2);
     else if (nchunk <= 4 * TPR)  MIXQ_QLAUNCH2(4);
     else if (nchunk <= 8 * TPR)  MIXQ_QLAUNCH2(8);
