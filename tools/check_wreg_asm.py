@@ -24,7 +24,10 @@ def regs(tok):
 
 def main():
     bad = 0
+    only = set(sys.argv[1:])                                  # optional: source file names to restrict the check to
     for fname, kname, tag_re, tag_fmt, abl_idx in TARGETS:
+        if only and fname not in only:
+            continue
         bad += check(fname, kname, tag_re, tag_fmt, abl_idx)
     return 1 if bad else 0
 
