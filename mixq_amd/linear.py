@@ -187,6 +187,7 @@ class MixLinear_GEMM(nn.Module):
         self._silu_calls = 0
         self._plan = None            # argument block of the one-call forward of the frozen layer (mixq_linear_forward)
         self._plan_key = None
+        self._plans = {}             # ... the last few of them by key: a server alternates prefill and decode batch sizes
         self._cmask = None           # bit-per-input-column mask of `ind` (int32 words) for a producer's row-maximum side output
         self._cmask_key = None
         self._amax_buf = None        # int32 [M]: this layer's row maxima as left by the GEMM that produced its input
@@ -316,6 +317,7 @@ class MixLinear_GEMM(nn.Module):
                     self._buffers["q_weight"] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self._wpk.device)
                     self._wpk, self._wpk_key = None, None                # re-packed on the next forward
                     self._wpk_small, self._wpk_small_key = None, None
+                    self._plan, self._plan_key, self._plans = None, None, {}     # (kept plans pin the old images)
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def _apply(self, fn, *args, **kwargs):
@@ -331,6 +333,7 @@ class MixLinear_GEMM(nn.Module):
                 self._wpk = moved
         self._wpk_key = None                                             # (re-packed from q_weight when that buffer still exists)
         self._wpk_small, self._wpk_small_key = None, None                # (rebuilt when a small batch arrives)
+        self._plan, self._plan_key, self._plans = None, None, {}         # (kept plans pin the old device's tensors)
         if isinstance(self.__dict__.get("weight_cache"), Tensor):
             self.weight_cache = fn(self.weight_cache)                    # 8-bit layers keep it as a plain attribute (linear.py:42)
         if isinstance(self.__dict__.get("ind"), Tensor):
@@ -479,7 +482,7 @@ class MixLinear_GEMM(nn.Module):
         """copy.deepcopy / pickle of a frozen layer: the kept argument block of the one-call forward is a ctypes structure full of device
         pointers - neither copyable nor meaningful in the copy, which builds its own on its first frozen forward."""
         state = dict(self.__dict__)
-        state["_plan"], state["_plan_key"] = None, None
+        state["_plan"], state["_plan_key"], state["_plans"] = None, None, {}
         return state
 
     # ---- frozen steady state: the whole forward behind ONE foreign call (include/mixq_hip.h: mixq_linear_forward) ------
@@ -533,11 +536,17 @@ class MixLinear_GEMM(nn.Module):
             # prediction frozen: extract + quantise + GEMM enqueued by one C call on a kept argument block; bit-identical to the
             # route below (tests/test_gpu_round3.py::test_one_call_forward_is_bit_identical)
             key = self._frozen_key(cache, inputs, M)
+            if self._plan_key != key and key in self._plans:
+                self._plan, self._plan_key = self._plans[key], key       # (a batch size seen before, nothing else changed)
             if self._plan_key != key:
                 self._plan = self._build_plan(cache, inputs, M)
                 if COMPACT_WEIGHTS and self._plan is not None:
                     self.compact_weights_()                  # (e.g. after a load_state_dict into a frozen layer re-created q_weight)
                 self._plan_key = self._frozen_key(cache, inputs, M)
+                if self._plan is not None:
+                    if len(self._plans) >= 4:
+                        self._plans.pop(next(iter(self._plans)))         # (oldest entry; stale keys - another weight image, new outliers - just age out)
+                    self._plans[self._plan_key] = self._plan
             plan = self._plan
             if plan is not None:
                 tag = getattr(x, "_mixq_row_amax", None)     # left by the GEMM that produced x (forward_without_preconditionFusedSilu)

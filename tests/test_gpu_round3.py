@@ -421,3 +421,27 @@ def test_row_maximum_hand_over_is_dropped_when_the_activation_was_edited():
     y3 = down(g3, None, True)
     assert not down._amax_dirty and int(down._amax_buf.abs().sum()) == 0
     assert (y3.float() - y.float()).abs().max() < 0.05                              # (fused product: one rounding fewer than g *= u)
+
+
+def test_one_call_plans_are_kept_per_batch_size():
+    """A server alternates prefill and decode batches: the frozen layer keeps the argument block of each of the last few batch sizes
+    instead of rebuilding it on every switch, and results stay those of the two-call route."""
+    layer, cache, cols = frozen_layer(96, 1024, 320, 8, 5, True)
+    xs = {M: torch.randn(M, 1024, generator=torch.Generator().manual_seed(M)).half() for M in (96, 16, 40)}
+    want = {}
+    L.ONE_CALL_FORWARD = False
+    for M, x in xs.items():
+        want[M] = layer(x.clone().to(DEV), None, True).clone()
+    L.ONE_CALL_FORWARD = True
+    plans = {}
+    for rnd in range(3):
+        for M, x in xs.items():
+            y = layer(x.clone().to(DEV), None, True)
+            assert torch.equal(y, want[M]), (rnd, M)
+            if rnd == 0:
+                plans[M] = layer._plan
+            else:
+                assert layer._plan is plans[M], "the plan of a batch size seen before was rebuilt"
+    assert len(layer._plans) == 3
+    moved = layer.to(DEV)                                             # a device move drops them (they pin the old tensors)
+    assert moved._plans == {} and moved._plan is None
