@@ -29,11 +29,13 @@ def main():
     for name, s, e in rows:
         agg[name].append(e - s)
     print(f"# {db}")
-    print(f"{'kernel':72s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'total_ms':>10s}")
+    # median_us: the kernel's duration in the steady state (the average also holds the first, clock-unsettled launches after every idle gap)
+    print(f"{'kernel':72s} {'calls':>6s} {'avg_us':>10s} {'median_us':>10s} {'min_us':>10s} {'total_ms':>10s}")
     for name, d in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         if filt and filt not in name:
             continue
-        print(f"{short(name):72s} {len(d):6d} {sum(d) / len(d) / 1e3:10.2f} {min(d) / 1e3:10.2f} {sum(d) / 1e6:10.3f}")
+        med = sorted(d)[len(d) // 2]
+        print(f"{short(name):72s} {len(d):6d} {sum(d) / len(d) / 1e3:10.2f} {med / 1e3:10.2f} {min(d) / 1e3:10.2f} {sum(d) / 1e6:10.3f}")
     try:
         pm = cur.execute("select name, dispatch_id, counter_name, counter_value from pmc_events").fetchall()
     except sqlite3.Error:
