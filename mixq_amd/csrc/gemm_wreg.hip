@@ -96,6 +96,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // (requests past the end of K wrap around to the first k-steps: valid addresses, never consumed, drained behind the loop), so
     // every wait is a compile-time count.
     constexpr bool I4 = Q == 1, F6 = Q >= 2, F6R = Q == 3;
+    // WRAP: every k-step requests weights unconditionally - past the end of K the requests wrap around to the first k-steps (valid
+    // addresses, never consumed, drained behind the loop) - so the last D + NSLOT k-steps need no conditional loads and no run-time wait
+    // tables.  The tuple-ring FP6 form and the int8 form of the shipped loop: -0.8 ... -3.2 % over the BASELINE shapes between two product
+    // builds (-1.3 % at the metric shape; profiles/r03_ab_wrap_tail.txt; -DMIXQ_NO_WRAP_TAIL builds the other one).
+#ifdef MIXQ_NO_WRAP_TAIL
+    constexpr bool WRAP = F6R || ABL == 41;
+#else
+    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && ABL == 0 && LOADERS != 0);
+#endif
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
     constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
@@ -304,7 +313,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         size_t woff = static_cast<size_t>(rot) * wks;
         i32x6 wr6[F6R ? D + 1 : 1][F6R ? WNB : 1];                               // F6R: the weight ring as operand tuples (D + 1 slots, as wq below)
         auto wadvance = [&](int cond) MIXQ_INL {                    // once per requested k-step (cond: wave-uniform 0 / 1; F6R requests always)
-            if (F6R || cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
+            if (WRAP || cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
         };
         auto wload6 = [&](auto d_c, int i) MIXQ_INL {               // F6R: fragment i of the k-step at woff -> tuple i of ring slot d
             constexpr int d = decltype(d_c)::value;
@@ -365,6 +374,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         auto wload1 = [&](auto d_c, int i, int cond) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
             if constexpr (F6R) { (void)cond; wload6(d_c, i); }
+            else if constexpr (WRAP) {                     // (int8 form with unconditional, wrapping requests: compile-time waits in the tail)
+                const uint8_t* src = wb[i] + woff;
+                i32x4& dst = wq[d][i];
+                const int l16 = lane16;
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(l16), "s"(src) : "memory");
+            }
             else if constexpr (ABL != 1 && ABL != 3) {
                 const int cs = __builtin_amdgcn_readfirstlane(cond);             // provably wave-uniform for the "s" constraint
                 const uint8_t* src = wb[i] + woff;
@@ -424,7 +439,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // the same with a run-time count (tail of the k loop): CNT in {0, WNB, 2 WNB, ...}, selected inside ONE statement
         auto wwait_rt = [&](auto d_c, int younger) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
-            if constexpr (F6R) { (void)younger; wwait(d_c, std::integral_constant<int, WL * (D - 1)>{}); }   // (every k-step requests: the count is fixed)
+            if constexpr (WRAP) { (void)younger; wwait(d_c, std::integral_constant<int, WL * (D - 1)>{}); }   // (every k-step requests: the count is fixed)
             else if constexpr (ABL != 1 && ABL != 3) {
                 const int sel = __builtin_amdgcn_readfirstlane(younger >= D - 1 ? D - 1 : younger);   // k-steps requested after this one, capped at the ring depth
 #define MIXQ_WR_W1(n, l) "s_cmp_lt_u32 %[sel], " #n "\n\ts_cbranch_scc1 " #l "f\n\t"
@@ -771,7 +786,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             auto tail_one = [&](auto c_c) MIXQ_INL { if (k0 + decltype(c_c)::value < nk) one(c_c, std::false_type{}); };
             wr_static_for<0, NSLOT>(tail_one);
         }
-        if constexpr (F6R) wr_wait_vmcnt<0>();                                   // the wrapped-around requests of the last k-steps: nothing may land in a register the epilogue re-uses
+        // The wrapped-around requests of the last k-steps are never consumed: to the compiler their destination registers are dead the
+        // moment they are issued - free for anything - while the loads are still in flight.  The drain therefore NAMES every ring slot
+        // (read-write operands of the wait statements): the ring stays allocated until nothing can land in it any more.
+        if constexpr (WRAP) wr_static_for<0, NSLOT>([&](auto d_c) MIXQ_INL { wwait(d_c, std::integral_constant<int, 0>{}); });
         if constexpr (F6) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // asm MFMA -> accumulator reads: wait states the compiler cannot count
         stamp(2);
         }
@@ -1116,6 +1134,7 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 23, "128x192_p23_wlate_paced"),
     MIXQ_WR(8, 3, 16, 4, 2, 24, "128x192_p24_paced2"),
     MIXQ_WR(8, 3, 16, 4, 2, 28, "128x192_p28_prio"),
+    MIXQ_WR(8, 3, 16, 4, 2, 41, "128x192_p41_wrapload"),
     MIXQ_WR(8, 3, 16, 4, 2, 31, "128x192_p31_r2order"),   // round 2's order: re-read and weight load in the same gap
     MIXQ_WR(8, 3, 16, 4, 2, 30, "128x192_p30_earlyreread"),
     MIXQ_WR(8, 3, 16, 5, 2, 0, "128x192_s16_d5_l2"),
