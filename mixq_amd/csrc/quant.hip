@@ -284,12 +284,14 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
                     quant_codes8(keep[i], s, rs, code);
                     quant_codes8(keep[i + 1], s, rs, code + 8);
                     const int k = c * 8;
+#ifdef MIXQ_TUNING
                     if (dbg & 16) {                                  // timing probe (tools build): the same bytes to a row-contiguous place
                         uint32_t lo0, hi0, lo1, hi1;
                         f6_pack8(code, lo0, hi0); f6_pack8(code + 8, lo1, hi1);
                         typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
                         *reinterpret_cast<u32x3*>(static_cast<uint8_t*>(q) + static_cast<size_t>(row) * (K * 3 / 4) + (c >> 1) * 12) = u32x3{lo0, hi0 | (lo1 << 16), (lo1 >> 16) | (hi1 << 16)};
                     } else
+#endif
                     f6_store16(fmt, static_cast<uint8_t*>(q) + f6_block_offset(row, k, rows16), row, f6_group(k), (k & 31) >> 4, code);
                 }
             }
