@@ -445,3 +445,11 @@ def test_one_call_plans_are_kept_per_batch_size():
     assert len(layer._plans) == 3
     moved = layer.to(DEV)                                             # a device move drops them (they pin the old tensors)
     assert moved._plans == {} and moved._plan is None
+
+
+def test_every_wreg_tiling_survives_interleaved_graph_replays():
+    """tools/stress_wreg.py: every weights-in-registers tiling (int8 with the wrapped tail, FP6 tuple ring) inside graphs that interleave
+    seven shapes, each replay compared bit for bit with the LDS-staged kernels' result: the hazards of a hand-counted register ring
+    (a register re-used or copied while its load is in flight) are timing dependent, single launches on quiet buffers can miss them."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_wreg.py"), "7", "6"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "TOTAL MISMATCHES 0" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
