@@ -944,6 +944,7 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
             a.w_packed = 1; a.w_f16 = 1;
             return launch_gemm(a, bit == 8 ? 0 : 1, mixq_stream(stream), g_forced >= 0 ? g_forced : LDS256);
         }
+        else if (bit == 8 && !row_amax && mixq_wr_ksplit_pays(M, N, KB)) c = mixq_wr_ksplit_config();   // long K, few tiles: two workgroups per tile
         else c = mixq_wr_pick(bit, M, N, KB);
         return mixq_wr_launch(c, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                               ldy, M, N, KB, act, g_trace, mixq_stream(stream), row_amax, amax_mask);
@@ -1077,7 +1078,8 @@ extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) 
     if (fmt == MIXQ_FMT_F6X128) return bit == 4 ? dec + 1 + mixq_wr_pick(6, M, N, KB) : MIXQ_EINVAL;   // (FP6-coded operands: the weights-in-registers kernels only)
     const bool wide_wr = fmt == MIXQ_FMT_F16X64 && bit == 8 && N >= 8192;                 // as in gemm_fused_common
     if (!wide_wr && fmt != MIXQ_FMT_PLAIN && mixq_skinny_applies(bit, M, N, KB, true, true)) return dec;
-    if (fmt == MIXQ_FMT_F16X64) return (bit == 8 && prefill_prefers_lds256(M, N)) ? LDS256 : dec + 1 + mixq_wr_pick(bit, M, N, KB);
+    if (fmt == MIXQ_FMT_F16X64) return (bit == 8 && prefill_prefers_lds256(M, N)) ? LDS256
+                                     : dec + 1 + ((bit == 8 && mixq_wr_ksplit_pays(M, N, KB)) ? mixq_wr_ksplit_config() : mixq_wr_pick(bit, M, N, KB));
     return mixq_gemm_pick_config(M, N, K, bit);
 }
 

@@ -12,3 +12,7 @@ int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
                    hipStream_t st);
+
+// the registered workspace of the current device (mixq_gemm_set_workspace): flags region of `*flag_bytes` bytes first (zero between launches),
+// slots behind it.  False when none is registered.  Also used by the pairwise split-K form of gemm_wreg.hip.
+bool mixq_ws_get(void** ws, size_t* bytes, size_t* flag_bytes);

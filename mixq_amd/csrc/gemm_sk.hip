@@ -469,6 +469,13 @@ bool mixq_sk_usable(int c) {
     return d->num_cu > 0 && mixq_sk_workspace_need(c, d->num_cu) <= d->bytes;
 }
 
+bool mixq_ws_get(void** ws, size_t* bytes, size_t* flag_bytes) {
+    SkDev* d = sk_dev();
+    if (!d || !d->ws) return false;
+    *ws = d->ws; *bytes = d->bytes; *flag_bytes = SK_FLAG_BYTES;
+    return true;
+}
+
 int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,

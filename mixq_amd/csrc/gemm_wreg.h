@@ -12,3 +12,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
                    unsigned long long* trace, hipStream_t st, uint32_t* row_amax = nullptr, const uint32_t* amax_mask = nullptr);
+// pairwise split-K form (two workgroups per 128 x 128 tile, half of K each, int32 hand-off through the registered workspace)
+int mixq_wr_ksplit_config();                 // its configuration index
+int mixq_wr_ksplit_ok(int M, int N, int KB); // MIXQ_OK when it can run this problem on the current device (workspace, residency), else the reason
+bool mixq_wr_ksplit_pays(int M, int N, int KB);   // ... and the tile model says it is the faster choice

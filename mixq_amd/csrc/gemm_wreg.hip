@@ -26,6 +26,7 @@
 // them, /root/reference/mixquant/modules/linear.py:244-285, :330-373.
 #include "common.h"
 #include "gemm_wreg.h"
+#include "gemm_sk.h"
 #include <stdio.h>
 #include <string.h>
 #include <type_traits>
@@ -50,6 +51,9 @@ struct WrArgs {
     // amax_mask is clear of |fp16 bits of y[m,n]| (atomic max of bit patterns: order-independent, exact); amax_mask: bit n of a uint32 array
     uint32_t* row_amax;
     const uint32_t* amax_mask;
+    // pairwise split-K (ABL = 50): one int32 slot of BM x BN per tile and one flag word per tile (zero between launches)
+    uint8_t* ks_slots;
+    unsigned int* ks_flags;
 };
 
 constexpr int WR_CW = 4;
@@ -133,11 +137,20 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (ABL == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
 
+    // KS (ABL = 50): pairwise split-K.  Long-K layers with few output tiles (11008 -> 4096 at 512 tokens: 128 tiles of 128 x 128, half the
+    // CUs idle, or 256 tiles of 64 x 128 at a third fewer MACs per operand byte) run TWO workgroups per tile, each over half of K: the
+    // second publishes its int32 accumulators (register order, write-through 16-byte stores) into the tile's workspace slot and raises the
+    // tile's flag, the first adds them to its own and runs the epilogue.  Integer sums: exact in any order, the result is bit-identical.
+    // The hand-off costs 2.9 us between partners on one XCD (tools/ubench_handoff.hip) - the tile map below puts the halves of a tile next
+    // to each other in an XCD's run.  Both halves must be resident at once: the host launches this form only when 2 x tiles <= CUs.
+    constexpr bool KS = ABL == 50;
     const int ntiles = a.tiles_m * a.tiles_n;
-    int tile;
+    int tile, kz = 0;
     {
-        const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, x = b & 7, s = b >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;          // XCD-aware, bijective for any ntiles
+        const int nu = KS ? 2 * ntiles : ntiles;
+        const int b = blockIdx.x, q = nu >> 3, r = nu & 7, x = b & 7, s = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;          // XCD-aware, bijective for any count
+        if constexpr (KS) { kz = tile & 1; tile >>= 1; }
     }
     // Tile order inside an XCD's contiguous run of tiles: groups of gm M tiles, M fastest inside a group, then N, then the next group.
     // With gm = tiles_m (few M tiles, e.g. the 4 of a 512-token batch) that is "M fastest": the CUs of an XCD share a handful of
@@ -154,7 +167,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
-    const int nk = a.KB >> 6;
+    const int nk_all = a.KB >> 6;
+    const int kbeg = KS ? (kz ? nk_all >> 1 : 0) : 0;                            // this workgroup's k-steps: [kbeg, kbeg + nk)
+    const int nk = KS ? (kz ? nk_all - (nk_all >> 1) : nk_all >> 1) : nk_all;
     // Integer accumulation is exact in any order, so a tile may walk K from any starting k-step and wrap around.  Tiles of one
     // weight panel (same tn) start together - they share the panel's bytes in their XCD's L2 - while neighbouring panels start
     // krot k-steps apart, so the CUs of an XCD are not all asking the L2 for the same activation slab at the same moment.
@@ -201,6 +216,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             dsto[i] = p * 1024;
         }
         const size_t xks = static_cast<size_t>(a.xblocks) * BLK;
+        if constexpr (KS) {                              // (this workgroup's half of K starts at k-step kbeg)
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) src[i] += static_cast<size_t>(kbeg) * xks;
+        }
         int xk = rot;                                    // k-step the next stage reads
         size_t xoff = static_cast<size_t>(rot) * xks;
         auto stage = [&](int slot) MIXQ_INL {
@@ -309,6 +328,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             wb[i] = a.qw + static_cast<size_t>(rb) * BLK;
         }
         const size_t wks = static_cast<size_t>(a.wblocks) * BLK;
+        if constexpr (KS) {
+#pragma unroll
+            for (int i = 0; i < WNB; ++i) wb[i] += static_cast<size_t>(kbeg) * wks;
+        }
         int wk = rot;                                    // k-step the next weight loads read
         size_t woff = static_cast<size_t>(rot) * wks;
         i32x6 wr6[F6R ? D + 1 : 1][F6R ? WNB : 1];                               // F6R: the weight ring as operand tuples (D + 1 slots, as wq below)
@@ -791,6 +814,36 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // (read-write operands of the wait statements): the ring stays allocated until nothing can land in it any more.
         if constexpr (WRAP) wr_static_for<0, NSLOT>([&](auto d_c) MIXQ_INL { wwait(d_c, std::integral_constant<int, 0>{}); });
         if constexpr (F6) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // asm MFMA -> accumulator reads: wait states the compiler cannot count
+        if constexpr (KS) {
+            // ---- pairwise split-K hand-off (see KS above): slot = [wave][MB x WNB fragments][64 lanes x 16 bytes], register order ------
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.ks_slots + static_cast<size_t>(tile) * (BM * BN * 4), 0, BM * BN * 4, 0x00020000);
+            const int base = wave * (MB * WNB * 1024) + lane * 16;
+            if (kz) {
+#pragma unroll
+                for (int j = 0; j < MB; ++j)
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) {
+                        const u32x4 v = {static_cast<uint32_t>(acc[j][i][0]), static_cast<uint32_t>(acc[j][i][1]), static_cast<uint32_t>(acc[j][i][2]), static_cast<uint32_t>(acc[j][i][3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (j * WNB + i) * 1024, 0, 16 /* sc1: write-through */);
+                    }
+                wr_wait_vmcnt<0>();                                               // every storing wave drains its own stores
+                __builtin_amdgcn_s_barrier();                                    // (the epilogue's two barriers: the loader waves arrive here as well)
+                if (tid == 0) __hip_atomic_store(a.ks_flags + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_barrier();
+                return;
+            }
+            if (lane == 0) while (__hip_atomic_load(a.ks_flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                u32x4 v[WNB];
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (j * WNB + i) * 1024, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int i = 0; i < WNB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][i][r] += static_cast<int>(v[i][r]);
+            }
+        }
         stamp(2);
         }
     }
@@ -851,6 +904,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         if (ksteps > 0) tail_load_w(0, 0);
         if (TD > 1 && ksteps > 1) tail_load_w(TD - 1, 1);
         __builtin_amdgcn_s_barrier();                                            // every wave is done reading the ring; X_out blocks landed
+        if constexpr (KS) { if (tid == 0) __hip_atomic_store(a.ks_flags + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (every wave has passed its poll)
         stamp(6);
         if (ksteps > 0) tail_load_x(0, 0);
         if (TD > 1 && ksteps > 1) tail_load_x(TD - 1, 1);
@@ -1111,6 +1165,7 @@ const WrConfig g_wr[] = {
     // k-steps) are slower (13.8, 14.0 us), narrow layers (N = 4096: 64 panels for 256 CUs) stay with gemm_skinny.hip
     // (profiles/r02_decode.txt)
     MIXQ_WR(2, 1, 8, 6, 1, 0, "32x64_s8_d6_l1"),       // 14 (WR_SMALL)
+    MIXQ_WR(8, 2, 16, 4, 2, 50, "128x128_s16_d4_l2_k2"),   // 15 (WR_KSPLIT): two workgroups per tile, half of K each (pairwise split-K)
 #ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): only in the tools build (make tuning)
     { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
     { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 2>, 8 },
@@ -1152,6 +1207,7 @@ const WrConfig g_wr[] = {
 #endif
 };
 constexpr int WR_SMALL = 14;
+constexpr int WR_KSPLIT = 15;
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
 #ifdef MIXQ_TUNING
 int g_wr_krot = 0;
@@ -1210,6 +1266,45 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
     return bi;
 }
 
+int mixq_wr_ksplit_config() { return WR_KSPLIT; }
+// Can the pairwise split-K form (WR_KSPLIT) run (M, N, KB) on the current device?  MIXQ_OK, or why not: both halves of every tile must be
+// resident at once (2 x tiles <= CUs), the workspace registered with mixq_gemm_set_workspace must hold a flag word and an int32 slot per tile.
+int mixq_wr_ksplit_ok(int M, int N, int KB)
+{
+    const WrConfig& g = g_wr[WR_KSPLIT];
+    const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
+    if ((KB >> 6) < 2) return MIXQ_ESHAPE;
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) { (void)hipGetLastError(); return MIXQ_ENODEV; } cus = p.multiProcessorCount; }
+    if (2 * tiles > cus) return MIXQ_ESHAPE;
+    void* ws; size_t bytes, fb;
+    if (!mixq_ws_get(&ws, &bytes, &fb)) return MIXQ_EINVAL;
+    if (static_cast<size_t>(tiles) * 4 > fb || fb + static_cast<size_t>(tiles) * (g.mb * 16) * (g.wnb * 64) * 4 > bytes) return MIXQ_EINVAL;
+    return MIXQ_OK;
+}
+// ... and is it the faster choice?  The model of mixq_wr_pick with the MEASURED cost of a k-step when all 256 CUs run 128 x 128 tiles
+// (0.28 us - not the 0.218 us fitted on 128 such tiles over 256 CUs: the part is power-bound, time follows the MFMA work, not the bytes)
+// plus the hand-off (2.9 us, tools/ubench_handoff.hip).  At the shapes it was built for it does not pay: 32.6 vs 28.8 us at 11008 ->
+// 4096, 38.6 vs 35.8 us at 14336 -> 4096 against 64 x 128 (profiles/r03_splitk_ab.txt).  The form stays selectable by configuration.
+bool mixq_wr_ksplit_pays(int M, int N, int KB)
+{
+    if (M <= 32 || mixq_wr_ksplit_ok(M, N, KB) != MIXQ_OK) return false;
+    const int nk = KB >> 6;
+    const double t_split = (nk - nk / 2) * 0.28 + 5.5 + 2.9;
+    const WrConfig& g = g_wr[mixq_wr_pick(8, M, N, KB)];
+    static const struct { int cfg; float tk, fixed; } cand[] = {
+        {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f}, {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
+    double best = 1e30;
+    for (const auto& c : cand) {
+        const WrConfig& q = g_wr[c.cfg];
+        const int tiles = cdiv(M, q.mb * 16) * cdiv(N, q.wnb * 64);
+        const double t = cdiv(tiles, 256) * (nk * static_cast<double>(c.tk) + c.fixed);
+        if (t < best) best = t;
+    }
+    (void)g;
+    return t_split < 0.97 * best;
+}
+
 // bit: 8, 4 (nibble-packed operands) or 6 (int4 as FP6 codes, MIXQ_FMT_F6X128 operands; KB is K / 2 as for bit 4)
 int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
@@ -1236,10 +1331,19 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     a.trace = trace;
     a.row_amax = row_amax; a.amax_mask = amax_mask;
     void (*k)(const WrArgs) = bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4);
-    if (!k) return MIXQ_EINVAL;                                                  // (the prefill tiles have no nibble form, few tilings an FP6 form)
+    if (!k) return MIXQ_EINVAL;
+    int units = a.tiles_m * a.tiles_n;
+    if (c == WR_KSPLIT) {
+        if (int rc = mixq_wr_ksplit_ok(M, N, KB)) return rc;
+        void* ws; size_t bytes, fb;
+        mixq_ws_get(&ws, &bytes, &fb);
+        a.ks_flags = static_cast<unsigned int*>(ws);
+        a.ks_slots = static_cast<uint8_t*>(ws) + fb;
+        units *= 2;
+    }                                                  // (the prefill tiles have no nibble form, few tilings an FP6 form)
     const size_t ring = bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 4 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
     const size_t shm = ring > stg ? ring : stg;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
-    hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3((WR_CW + g.loaders) * 64), shm, st, a);
+    hipLaunchKernelGGL(k, dim3(units), dim3((WR_CW + g.loaders) * 64), shm, st, a);
     return mixq_launch_status();
 }

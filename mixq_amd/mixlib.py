@@ -584,6 +584,12 @@ def PackOperand(q, fmt=FMT_P16X64):
     return set_fmt(out, fmt)
 
 
+def EnsureWorkspace(device):
+    """Register (once per process and device) the zero-filled workspace the stream-K and pairwise split-K forms of the GEMM hand partial tiles
+    over through (mixq_gemm_set_workspace); without it the library runs its other tilings."""
+    return _capi.ensure_workspace(device)
+
+
 def PackP16x64(q):
     return PackOperand(q, FMT_P16X64)
 

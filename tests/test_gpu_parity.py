@@ -991,7 +991,8 @@ def test_silu_mul_needs_its_multiplier():
 # round 2: the holes VERDICT r01 listed
 # ---------------------------------------------------------------------------------------------------------------
 def _wr_configs():
-    return [i for i, name in enumerate(_capi.gemm_config_names()) if name.startswith("wr") and "abl" not in name and "self" not in name]
+    # (the pairwise split-K form needs a workspace and 2 x tiles <= CUs: it has its own tests in test_gpu_round3.py)
+    return [i for i, name in enumerate(_capi.gemm_config_names()) if name.startswith("wr") and "abl" not in name and "self" not in name and not name.endswith("_k2")]
 
 
 def _tiled_configs():

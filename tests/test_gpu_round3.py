@@ -453,3 +453,67 @@ def test_every_wreg_tiling_survives_interleaved_graph_replays():
     (a register re-used or copied while its load is in flight) are timing dependent, single launches on quiet buffers can miss them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_wreg.py"), "7", "6"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "TOTAL MISMATCHES 0" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("M,N,K,n_out,act,bias", [(512, 4096, 11008, 110, 0, False), (512, 4096, 14336, 143, 0, True), (500, 4000, 2048, 19, 1, True),
+                                                  (130, 200, 128, 0, 0, False), (512, 4096, 4096 + 64, 41, 2, False)])
+def test_pairwise_split_k_is_bit_identical(M, N, K, n_out, act, bias):
+    """Two workgroups per 128 x 128 tile, half of K each, int32 partial handed over through the workspace (gemm_wreg.hip, KS): integer sums are
+    exact in any order, so every output bit equals the one-workgroup-per-tile kernels' - odd k-step counts, ragged M / N, every epilogue term,
+    repeated launches (the flags must come back to zero) and graph replay."""
+    _capi.ensure_workspace(DEV)
+    lib, names = _capi.load(), _capi.gemm_config_names()
+    from test_gpu_parity import _fused_case, t
+    c = _fused_case(M, N, K, 8, seed=M + N + K, n_out=n_out, bias=bias, addend=act == 2, act=act)
+    pad = (n_out + 15) // 16 * 16
+    xo = wo = None
+    if n_out:
+        xo = torch.zeros((M, pad), dtype=torch.float16, device=DEV); xo[:, :n_out] = t(c["xo"]); xo = xo[:, :n_out]
+        wo = torch.zeros((N, pad), dtype=torch.float16, device=DEV); wo[:, :n_out] = t(c["wo"]); wo = wo[:, :n_out]
+    sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV); sx[:, 0] = t(c["sx"])
+    qx, qw = mixlib.PackOperand(t(c["qx"]), 1), mixlib.PackOperand(t(c["qw"]), 2)
+    b = None if c["bias"] is None else t(c["bias"])
+    ad = None if c["addend"] is None else t(c["addend"])
+    sw = t(c["sw"])
+    run = lambda out=None: mixlib.FusedLinear(qx, qw, sx, sw, xo, wo, n_out, b, M, N, K, bit=8, act=act, addend=ad, out=out)
+    try:
+        assert lib.mixq_gemm_set_config(names.index("wr128x128_s16_d4_l2")) == 0
+        want = run().clone()
+        assert lib.mixq_gemm_set_config(names.index("wr128x128_s16_d4_l2_k2")) == 0
+        for rep in range(4):
+            got = run()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (rep, int((got != want).sum()))
+        out = torch.zeros_like(want)
+        g = torch.cuda.CUDAGraph()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(3):
+                    run(out)
+        for _ in range(3):
+            out.zero_(); g.replay(); torch.cuda.synchronize()
+            assert torch.equal(out, want)
+    finally:
+        lib.mixq_gemm_set_config(-1)
+    ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], addend=c["addend"], bias=c["bias"], act=act, bit=8).astype(np.float32)
+    assert (np.abs(n(want).astype(np.float32) - ref) <= ulp_tol(ref)).all()
+
+
+def test_split_k_is_not_chosen_where_it_was_measured_slower_and_refused_when_it_cannot_run():
+    lib, names = _capi.load(), _capi.gemm_config_names()
+    _capi.ensure_workspace(DEV)
+    pick = lambda M, N, K: names[lib.mixq_gemm_pick_config_fmt(M, N, K, 8, 2)]
+    # (profiles/r03_splitk_ab.txt: 32.6 vs 28.8 us at 11008 -> 4096: the automatic choice stays with one workgroup per tile)
+    for shp in [(512, 4096, 11008), (512, 4096, 14336), (512, 11008, 4096), (512, 4096, 4096), (4096, 4096, 11008), (16, 4096, 11008)]:
+        assert "_k2" not in pick(*shp), shp
+    # forced onto a problem whose tiles cannot all be resident twice: refused, not deadlocked
+    qx = mixlib.PackOperand(torch.zeros((2048, 256), dtype=torch.int8, device=DEV), 1)
+    qw = mixlib.PackOperand(torch.zeros((4096, 256), dtype=torch.int8, device=DEV), 2)
+    s1 = torch.ones((2048, 1), dtype=torch.float16, device=DEV); s2 = torch.ones((1, 4096), dtype=torch.float16, device=DEV)
+    try:
+        assert lib.mixq_gemm_set_config(names.index("wr128x128_s16_d4_l2_k2")) == 0
+        with pytest.raises(_capi.MixqError):
+            mixlib.FusedLinear(qx, qw, s1, s2, None, None, 0, None, 2048, 4096, 256, bit=8)
+    finally:
+        lib.mixq_gemm_set_config(-1)

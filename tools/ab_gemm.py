@@ -45,7 +45,7 @@ if args.nout:
     xo = torch.randn((M, pad), device=dev).half()[:, :args.nout]
     wo = torch.randn((N, pad), device=dev).half()[:, :args.nout]
 out = torch.empty((M, N), dtype=torch.float16, device=dev)
-if any(nm.startswith("sk") for nm in args.cfgs.split(",")):
+if any(nm.startswith("sk") or nm.endswith("_k2") for nm in args.cfgs.split(",")):
     _capi.ensure_workspace(dev)                        # stream-K forms hand partial tiles over through a registered workspace
 side = torch.cuda.Stream()
 graphs = []
