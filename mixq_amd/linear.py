@@ -139,6 +139,10 @@ class MixLinear_GEMM(nn.Module):
         self.bit = bit
         if bit not in (4, 8):
             raise ValueError("MixLinear_GEMM: bit must be 4 or 8")
+        # the kernels' shape contract (include/mixq_hip.h): said here, where the layer is built, not by the first forward's MIXQ_ESHAPE
+        if not weight_only and (in_features % (64 if bit == 8 else 128) or out_features % 4):
+            raise ValueError(f"MixLinear_GEMM: W{bit}A{bit} needs in_features % {64 if bit == 8 else 128} == 0 and out_features % 4 == 0 "
+                             f"(got {in_features} -> {out_features})")
 
         if weight_only is False:
             self.register_buffer("scale_col", torch.empty((1, out_features), dtype=torch.float16, device=dev))

@@ -294,3 +294,32 @@ def test_small_batches_of_a_four_bit_layer_stream_a_nibble_image():
     L.PACK_FMT4 = FMT_F6X128
     for a, b in zip(outs[FMT_F6X128], outs[FMT_P16X64]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,K,N,ncols", [(37, 384, 100, 3), (130, 128, 72, 5), (64, 4224, 136, 12), (40, 640, 16, 1), (96, 1152, 1000, 0)])
+def test_four_bit_layer_with_ragged_k_and_n(M, K, N, ncols):
+    """Odd counts of 128-column FP6 blocks, out_features that are not a multiple of 16, batches that are not a multiple of 16: the
+    zero-padded FP6 pair gives the nibble path's bits, warm-up and frozen calls alike."""
+    outs = {}
+    for fmt in (FMT_F6X128, FMT_P16X64):
+        L.PACK_FMT4 = fmt
+        layer, cache, cols = _layer(M, K, N, ncols, True, seed=3)
+        ys = []
+        for call in range(4):
+            x = torch.randn(M, K, generator=torch.Generator().manual_seed(70 + call)).half()
+            x[:, cols] *= 20
+            ys.append(layer(x.to(DEV), None, True).clone())
+        assert mixlib.fmt_of(layer._packed_weight()) == fmt
+        outs[fmt] = (ys, layer)
+    L.PACK_FMT4 = FMT_F6X128
+    for a, b in zip(outs[FMT_F6X128][0], outs[FMT_P16X64][0]):
+        assert a.shape == (M, N) and torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.equal(outs[FMT_F6X128][1].state_dict()["q_weight"], outs[FMT_P16X64][1].state_dict()["q_weight"])
+
+
+def test_unsupported_layer_shapes_are_refused_when_the_layer_is_built():
+    """The kernels' shape contract (K % 128 for 4-bit operands, K % 64 for int8, N % 4: include/mixq_hip.h) is stated by the constructor."""
+    for bit, K, N in [(4, 192, 64), (4, 200, 64), (8, 96, 64), (8, 128, 66)]:
+        with pytest.raises(ValueError, match="in_features"):
+            MixLinear_GEMM(K, N, False, DEV, bit, cache=MixLibCache(16, bit=bit, device=DEV))
+    MixLinear_GEMM(192, 64, False, DEV, 8, cache=MixLibCache(16, bit=8, device=DEV))
