@@ -59,6 +59,9 @@ struct WrArgs {
 constexpr int WR_CW = 4;
 // every lambda of the kernels below is force-inlined: at 256-row tiles their bodies are big enough for the inliner to leave them as
 // functions, and a by-reference capture of the accumulator array behind a real call puts the whole frame in scratch memory
+#ifndef MIXQ_XR
+#define MIXQ_XR 4                                                              // FP6 form: activation tuples held per wave (window)
+#endif
 #define MIXQ_INL __attribute__((always_inline))                              // consumer waves, 1 x 4 along N
 
 template <int N> __device__ __forceinline__ void wr_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -364,7 +367,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // F6: activation fragments as the 6-register operand tuples - a rotating window of XR of a k-step's MB fragments (all MB would
         // not fit next to 6-register weight fragments: 256 registers per wave at 6 waves per CU).  Group j runs on window slot j % XR and
         // requests fragment j + XR behind its last MFMA - of this stage, or of the next one (landed: the k-step's barrier) once j + XR >= MB.
-        constexpr int XR = F6 ? (MB < 4 ? MB : 4) : 1;
+        constexpr int XR = F6 ? (MB < MIXQ_XR ? MB : MIXQ_XR) : 1;
         i32x6 xf6[XR];
         static_assert(!F6 || MB % XR == 0, "window slots must be compile-time");
         i32x4 xc[2];                                     // (probe ABL 30: copies of the last two fragments)
