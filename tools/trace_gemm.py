@@ -17,7 +17,7 @@ from mixq_amd import _capi, mixlib  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="512x11008x4096")
-    ap.add_argument("--cfgs", default="8")
+    ap.add_argument("--cfgs", default="8", help="configuration indices or names, comma-separated")
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nout", type=int, default=0, help="outlier columns (the fp16 MFMA tail of the epilogue)")
@@ -45,7 +45,7 @@ def main():
             xo = torch.randn((M, pad), device=dev).half()[:, :args.nout]
             wo = torch.randn((N, pad), device=dev).half()[:, :args.nout]
         trace = torch.zeros(16 * 4096, dtype=torch.int64, device=dev)
-        for c in [int(v) for v in args.cfgs.split(",")]:
+        for c in [int(v) if v.lstrip("-").isdigit() else names.index(v) for v in args.cfgs.split(",")]:
             assert lib.mixq_gemm_set_config(c) == 0
             qwp = qw_by_fmt[2 if names[c].startswith("wr") else 1]
             run = lambda: mixlib.FusedLinear(qxp, qwp, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
