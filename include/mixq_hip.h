@@ -75,12 +75,12 @@ extern "C" {
  *                   mixq_pack_operand / mixq_unpack_operand (fmt = MIXQ_FMT_F6X128) convert from / to the plain nibble-packed
  *                   [R, K/2] matrix (KB = K/2 in their signature). */
 #define MIXQ_FMT_F6X128 3
-/* MIXQ_FMT_R6X128 : the ACTIVATION side of the same GEMM: the same blocks and the same 24-byte lane fragments, but in the block's first
- *                   KiB a row's four 16-byte pieces stay together - row r at 64 r, fragment g at + 16 g - because a quantise kernel owns
- *                   ONE row: two thirds of what it writes are 64-byte runs here, against 16-byte pieces at a 256-byte stride in fragment
- *                   order.  (The 8-byte pieces stay at 1024 + 8 l: the b64 fragment reads of the GEMM want them lane-linear in LDS, and
- *                   its LDS-DMA copies whole KiBs.)  The DMA permutes the 16-byte pieces inside a row's run into the bank swizzle of a
- *                   P16X64 block (the source address of a DMA lane is free). */
+/* MIXQ_FMT_R6X128 : the ACTIVATION side of the same GEMM: the same blocks and the same 24-byte lane fragments, ROW-MAJOR inside a block: row r
+ *                   (= row % 16) owns the 96 bytes at 96 r - its four 16-byte pieces (fragment g at + 16 g), then its four 8-byte pieces
+ *                   (+ 64 + 8 g) - because a quantise kernel owns ONE row: it writes whole 96-byte runs here, against 16-byte and 8-byte
+ *                   pieces at 256- and 128-byte strides in fragment order.  The GEMM's LDS-DMA copies whole KiBs and swaps the two
+ *                   16-byte units of every aligned 32-byte pair in rows 8 .. 15 on the way (the source address of a DMA lane is free):
+ *                   that image serves its b128 and b64 fragment reads without bank conflicts. */
 #define MIXQ_FMT_R6X128 4
 /* `layout` bits of the GEMM entry points */
 #define MIXQ_X_PACKED 1      /* q_x is MIXQ_FMT_P16X64 */

@@ -139,10 +139,11 @@ __device__ __forceinline__ size_t f6_block_offset(int row, int k, int rows16) {
 __device__ __forceinline__ int f6_group(int k) { return (k & 127) >> 5; }
 // where the two pieces of lane fragment (row, g = 32-element group of the block) live inside its block, by format:
 //   F6X128 (fragment order): 16 bytes at 16 lane, 8 bytes at 1024 + 8 lane, lane = 16 g + row % 16
-//   R6X128 (row runs):       16 bytes at 64 r + 16 g (a row's four pieces: one 64-byte run), 8 bytes at 1024 + 8 lane as above, r = row % 16
+//   R6X128 (row-major):      a row's 96 bytes of the block are ONE run at 96 r: its four 16-byte pieces (16 g), then its four 8-byte pieces
+//                            (64 + 8 g), r = row % 16 - what a quantise kernel, which owns one row, writes as whole cache-line segments
 __device__ __forceinline__ void f6_pieces(int fmt, uint8_t* blk, int row, int g, uint8_t*& A, uint8_t*& B) {
     const int r = row & 15;
-    if (fmt == MIXQ_FMT_R6X128) { A = blk + r * 64 + g * 16; B = blk + 1024 + (g * 16 + r) * 8; }
+    if (fmt == MIXQ_FMT_R6X128) { A = blk + r * 96 + g * 16; B = blk + r * 96 + 64 + g * 8; }
     else                        { A = blk + (g * 16 + r) * 16; B = blk + 1024 + (g * 16 + r) * 8; }
 }
 // eight consecutive codes (elements 8 c8 .. 8 c8 + 7 of a fragment's 32, c8 = 0..3) = 48 bits at byte 6 c8 of the 24-byte fragment

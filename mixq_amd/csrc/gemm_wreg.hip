@@ -202,15 +202,16 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         for (int i = 0; i < LOADS; ++i) {
             const int p = lw + i * LOADERS;
             if constexpr (F6) {
-                // 1 KiB pieces of a stage of 1.5 KiB blocks (a piece may straddle two blocks).  In the activation image
-                // (MIXQ_FMT_R6X128) a row's four 16-byte pieces form one 64-byte run - what a quantise kernel writes well - at 64 r of
-                // the block's first KiB; the LDS image holds them like a P16X64 block, piece g of row r at position g ^ (-(r >> 2) & 3)
-                // (conflict-free b128 fragment reads): four consecutive DMA lanes fetch one row's run, permuted.  The block's last
-                // 512 bytes (the 8-byte pieces, lane-linear) are copied as they are.  Every DMA instruction moves one contiguous KiB.
+                // 1 KiB pieces of a stage of 1.5 KiB blocks (a piece may straddle two blocks).  The activation image (MIXQ_FMT_R6X128) is
+                // row-major inside a block - 96 bytes per row: four 16-byte pieces, then four 8-byte pieces - which is what a quantise
+                // kernel writes well; the LDS image is the same bytes with the two 16-byte units of every aligned 32-byte pair SWAPPED in
+                // rows 8 .. 15: the 16-byte piece g of row r then sits at 96 r + 16 (g ^ (r >> 3)) and the 8-byte piece at
+                // 96 r + 64 + 8 (g ^ 2 (r >> 3)) - conflict-free for the b128 reads of 16 lanes (banks 24 r + 4 (g ^ (r >> 3)): rows r and
+                // r + 8 would collide) and for the b64 reads of 32 lanes.  A DMA lane's source address is free, a 32-byte pair never
+                // straddles a KiB, so every DMA instruction still moves one contiguous KiB.
                 const int o = p * 1024 + lane * 16, blk = o / BLK, within = o - blk * BLK;
                 int rb = (m0 >> 4) + blk; rb = rb < a.xblocks ? rb : a.xblocks - 1;
-                int off = within;
-                if (within < 1024) { const int sl = within >> 4, r = sl >> 2; off = r * 64 + 16 * ((sl & 3) ^ ((0 - (r >> 2)) & 3)); }
+                const int off = within ^ ((within / 96) >= 8 ? 16 : 0);
                 src[i] = a.qx + static_cast<size_t>(rb) * BLK + off;
             } else {
                 int rb = (m0 >> 4) + p; rb = rb < a.xblocks ? rb : a.xblocks - 1;  // blocks past M: loaded, computed, dropped
@@ -353,9 +354,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             }
         };
         const int lane16 = lane * 16, lane8 = lane * 8;
-        const int xoff8 = 1024 + lane8;                                          // F6: the fragment's 8-byte piece in the LDS image (see the loader)
-        // activation fragment (row lm, k-chunk lq) inside a P16X64 block: conflict-free by the layout's swizzle (common.h)
-        const int xoff = lm * 64 + ((lq ^ ((0 - (lm >> 2)) & 3)) << 4);
+        // activation fragment (row lm, k-chunk lq) inside a P16X64 block: conflict-free by the layout's swizzle (common.h);
+        // F6: the fragment's 16-byte and 8-byte pieces in the LDS image of an R6X128 block (see the loader)
+        const int xoff8 = lm * 96 + 64 + ((lq ^ ((lm >> 3) << 1)) << 3);
+        const int xoff = F6 ? lm * 96 + ((lq ^ (lm >> 3)) << 4) : lm * 64 + ((lq ^ ((0 - (lm >> 2)) & 3)) << 4);
         // Weight register ring: NSLOT = D + 1 slots.  k-step kt is consumed from slot kt % NSLOT while the loads of k-step kt + D
         // go into slot (kt + D) % NSLOT - the slot the PREVIOUS k-step freed - so they can be issued anywhere inside the step,
         // one behind every few MFMAs, instead of as a burst at its end (a VMEM issue blocks its wave while the address unit is

@@ -611,8 +611,9 @@ int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int
         // (no LDS reduction, no barrier) loses: its 64 elements per lane make the quantise arithmetic, not memory, the critical
         // path.  256 threads per row it is; the gain over round 1 is the gather from global memory instead of an LDS row copy.
         cfg = nchunk >= 512 ? 8 : 6;                     // (512 threads per row from K = 4096 up: 5.3 vs 5.7 us)
-        // FP6 codes leave in chunk pairs (2 chunks per thread at least); two rows per workgroup: 7.06 vs 7.9 us at K = 4096, 12.2 vs 12.9 at 11008
-        if (qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) cfg = nchunk <= 256 ? 5 : (nchunk <= 512 ? 7 : 9);
+        // FP6 codes leave in chunk pairs (2 chunks per thread at least); two rows per workgroup.  R6X128 (row-major blocks) at K = 4096:
+        // (256,2) 6.31 | (512,1) 6.25 | (512,2) 6.11 us, at 11008 (512,x) 11.2-11.3 | (256,x) 12.2-12.3 (profiles/r03_w4a4_quant_formats.txt)
+        if (qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) cfg = nchunk <= 256 ? 5 : (qfmt == MIXQ_FMT_F6X128 && nchunk <= 512 ? 7 : 9);
     }
     int rc = -100;
 #define MIXQ_Q2(TPR, RPB) rc = launch_quant_rows2<BIT, TPR, RPB>(x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, qfmt, st)

@@ -97,8 +97,8 @@ def f6x128_reference(v):
 
 
 def r6x128_reference(v):
-    """MIXQ_FMT_R6X128 (the activation side): the same blocks and 24-byte fragments; in the block's first KiB a row's four 16-byte pieces
-    form one run (64 r + 16 g); the 8-byte pieces stay lane-linear in its last 512 bytes (1024 + 8 (16 g + r))."""
+    """MIXQ_FMT_R6X128 (the activation side): the same blocks and 24-byte fragments, row-major inside a block: row r's 96 bytes at 96 r -
+    its four 16-byte pieces (16 g), then its four 8-byte pieces (64 + 8 g)."""
     R, K = v.shape
     rows16 = (R + 15) // 16 * 16
     frag = f6x128_reference(v).reshape(K // 128, rows16 // 16, 1536)
@@ -106,8 +106,8 @@ def r6x128_reference(v):
     for r in range(16):
         for g in range(4):
             lane = g * 16 + r
-            out[:, :, r * 64 + g * 16: r * 64 + g * 16 + 16] = frag[:, :, lane * 16: lane * 16 + 16]
-            out[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8] = frag[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8]
+            out[:, :, r * 96 + g * 16: r * 96 + g * 16 + 16] = frag[:, :, lane * 16: lane * 16 + 16]
+            out[:, :, r * 96 + 64 + g * 8: r * 96 + 64 + g * 8 + 8] = frag[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8]
     return out.reshape(-1)
 
 
@@ -119,8 +119,8 @@ def r6x128_to_fragment_order(buf, R, K):
     for r in range(16):
         for g in range(4):
             lane = g * 16 + r
-            out[:, :, lane * 16: lane * 16 + 16] = src[:, :, r * 64 + g * 16: r * 64 + g * 16 + 16]
-            out[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8] = src[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8]
+            out[:, :, lane * 16: lane * 16 + 16] = src[:, :, r * 96 + g * 16: r * 96 + g * 16 + 16]
+            out[:, :, 1024 + lane * 8: 1024 + lane * 8 + 8] = src[:, :, r * 96 + 64 + g * 8: r * 96 + 64 + g * 8 + 8]
     return out.reshape(-1)
 
 
@@ -168,9 +168,24 @@ def test_f6x128_layout_is_a_bijection_and_host_unpack_inverts_it(rows, kblocks, 
     back = _unpack_host(torch.from_numpy(buf.reshape(rows16, 96 * kblocks)), rows, 3).numpy()
     assert np.array_equal(back, O.pack_i4(v))
     assert np.array_equal(r6x128_to_fragment_order(r6x128_reference(v), rows, 128 * kblocks), buf)
-    # the 16-byte pieces of a block are read with ds_read_b128 at 16 l and the 8-byte pieces with ds_read_b64 at 1024 + 8 l: consecutive
-    # lanes, consecutive addresses - no two lanes of a service group share a bank (MI355X_MICROARCH.md, LDS)
-    assert len({(16 * l) // 16 % 16 for l in range(16)}) == 16 and len({(1024 + 8 * l) // 8 % 32 for l in range(32)}) == 32
+    # The GEMM's LDS image of an R6X128 block: the block's bytes with the two 16-byte units of every aligned 32-byte pair swapped in rows
+    # 8 .. 15 (a DMA lane's source address is free).  Lane (r = l & 15, g = l >> 4) reads its 16-byte piece with ds_read_b128 at
+    # 96 r + 16 (g ^ (r >> 3)) and its 8-byte piece with ds_read_b64 at 96 r + 64 + 8 (g ^ 2 (r >> 3)): no two lanes of a service group
+    # (16 lanes of a b128 read, 32 of a b64 read: 256 bytes = all 64 banks once) share a bank (MI355X_MICROARCH.md, LDS)
+    a_of = lambda l: 96 * (l & 15) + 16 * ((l >> 4) ^ ((l & 15) >> 3))
+    b_of = lambda l: 96 * (l & 15) + 64 + 8 * ((l >> 4) ^ (((l & 15) >> 3) << 1))
+    for grp in range(4):
+        banks = [b for l in range(16 * grp, 16 * grp + 16) for b in range(a_of(l) // 4 % 64, a_of(l) // 4 % 64 + 4)]
+        assert len(set(banks)) == 64
+    for grp in range(2):
+        banks = [b for l in range(32 * grp, 32 * grp + 32) for b in range(b_of(l) // 4 % 64, b_of(l) // 4 % 64 + 2)]
+        assert len(set(banks)) == 64
+    # ... and that image is the row-major block under the swap: LDS unit u of row r holds block bytes 96 r + 16 (u ^ (r >> 3))
+    lds_unit_src = lambda pos: pos ^ (16 if pos // 96 >= 8 else 0)
+    for l in range(64):
+        r, g = l & 15, l >> 4
+        assert lds_unit_src(a_of(l)) == 96 * r + 16 * g and lds_unit_src(b_of(l) & ~15) + (b_of(l) & 15) == 96 * r + 64 + 8 * g
+    assert all((pos ^ 16) // 1024 == pos // 1024 for pos in range(0, 3 * 1536, 16))       # a swapped pair never straddles a DMA instruction's KiB
 
 
 def packed_reference(q, fmt):
