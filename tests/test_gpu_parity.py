@@ -847,7 +847,8 @@ def test_randomized_shapes_all_tilings_bit_exact():
     that run several workgroups per CU)."""
     rng = np.random.default_rng(2024)
     names = _capi.gemm_config_names()
-    real = [i for i, nm in enumerate(names) if "abl" not in nm and not nm.startswith("sk") and not nm.startswith("decode")]
+    # (stream-K and pairwise split-K forms need a registered workspace and have their own tests)
+    real = [i for i, nm in enumerate(names) if "abl" not in nm and not nm.startswith("sk") and not nm.startswith("decode") and not nm.endswith("_k2")]
     decode = names.index("decode32")
     lib = _capi.load()
     keep = []
