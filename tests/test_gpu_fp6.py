@@ -323,3 +323,25 @@ def test_unsupported_layer_shapes_are_refused_when_the_layer_is_built():
         with pytest.raises(ValueError, match="in_features"):
             MixLinear_GEMM(K, N, False, DEV, bit, cache=MixLibCache(16, bit=bit, device=DEV))
     MixLinear_GEMM(192, 64, False, DEV, 8, cache=MixLibCache(16, bit=8, device=DEV))
+
+
+@pytest.mark.parametrize("M,N,K,n_out", [(512, 11008, 4096, 128), (512, 12288, 4096, 128), (512, 4096, 4096, 128), (2048, 11008, 4096, 128), (512, 28672, 8192, 128)])
+def test_fp6_gemm_at_the_baseline_shapes_equals_the_nibble_path_bit_for_bit(M, N, K, n_out):
+    """BASELINE config 2's layers (and a prefill batch, and the 70b width) at full size: too big for the oracle in a test, so the property
+    checked is the one the carrier promises - the FP6 pipe returns the int8-expansion path's bits - plus a sampled-rows check against
+    exact integer arithmetic on the host."""
+    rng = np.random.default_rng(M + N + K)
+    vx = rng.integers(-7, 8, (M, K), dtype=np.int8); vw = rng.integers(-8, 8, (N, K), dtype=np.int8)
+    qx, qw = t(O.pack_i4(vx)), t(O.pack_i4(vw))
+    sx = t((rng.random((M, 1)) * 0.01 + 0.001).astype(np.float16)); sw = t((rng.random((1, N)) * 0.01 + 0.001).astype(np.float16))
+    pad = (n_out + 15) // 16 * 16
+    xo = torch.randn((M, pad), device=DEV, dtype=torch.float16)[:, :n_out]; wo = torch.randn((N, pad), device=DEV, dtype=torch.float16)[:, :n_out]
+    bias = torch.randn(N, device=DEV, dtype=torch.float16)
+    want = mixlib.FusedLinear(mixlib.PackOperand(qx, FMT_P16X64), mixlib.PackOperand(qw, FMT_P16X64), sx, sw, xo, wo, n_out, bias, M, N, K, bit=4)
+    got = mixlib.FusedLinear(mixlib.PackOperand(qx, FMT_R6X128), mixlib.PackOperand(qw, FMT_F6X128), sx, sw, xo, wo, n_out, bias, M, N, K, bit=4)
+    assert torch.equal(want, got)
+    rows = rng.choice(M, 6, replace=False)
+    acc = vx[rows].astype(np.int64) @ vw.astype(np.int64).T
+    ref = acc.astype(np.float64) * n(sx)[rows].astype(np.float64) * n(sw).astype(np.float64) \
+        + n(xo)[rows].astype(np.float64) @ n(wo).astype(np.float64).T + n(bias).astype(np.float64)
+    assert (np.abs(n(got)[rows].astype(np.float64) - ref) <= ulp_tol(ref.astype(np.float32))).all()
