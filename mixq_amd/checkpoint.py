@@ -16,11 +16,12 @@ Weight-only (W8A16) layers are the one place where the two sides store DIFFERENT
 dtype: the reference's `q_weight` there is EETQ's CUTLASS-interleaved image (modules/linear.py:102-106), ours the plain
 int8 [K,N] matrix.  `quant_config.json` therefore records `"w8a16_layout"`: "plain" (written by save_quantized) or
 "eetq"; load_quantized converts "eetq" layers with mixq_amd.eetq.unprocess_weights, and save_quantized(...,
-w8a16_layout="eetq") writes the reference's form.  A checkpoint WITHOUT the key is ambiguous - the reference writes none
-(interleaved image), and this library's own round-1 checkpoints wrote none either (plain matrix) - so load_quantized then
-takes the layout from its `w8a16_layout=` argument or, failing that, from the bytes themselves (`detect_w8a16_layout`: the
-interleaved image is offset-binary, q + 128, so read as int8 its values crowd the two ends of the range, whereas quantised
-weights crowd zero) and says so in a warning.  save_quantized also records `"writer": "mixq_amd"`.  (EETQ is un-versioned and
+w8a16_layout="eetq") writes the reference's form.  A checkpoint WITHOUT the key is the reference's own (it writes none: interleaved image) and is
+loaded as "eetq".  The one other keyless writer was this library's round 1 (plain matrix, no `writer` marker yet): the bytes tell
+the two apart decisively (`detect_w8a16_layout`: the interleaved image is offset-binary, q + 128, so read as int8 its values crowd
+the two ends of the range - mean |q| ~ 100 - whereas quantised weights crowd zero - ~ 20-45), so a keyless checkpoint whose
+weight-only layers ALL read as plain is loaded as such with a warning, and one whose layers disagree or sit near the threshold
+raises - a silent mis-vote would load permuted weights.  save_quantized also records `"writer": "mixq_amd"`.  (EETQ is un-versioned and
 absent from the reference tree: the interleave is restated from the FasterTransformer routine it wraps - parity for these
 layers stays UNPINNED, see mixq_amd/eetq.py.)
 
@@ -238,31 +239,48 @@ def load_state_dict_files(load_dir):
     return sd
 
 
+def _w8a16_stat(q_weight):
+    return q_weight.detach().to("cpu").view(torch.int8).to(torch.int16).abs().float().mean().item()
+
+
 def detect_w8a16_layout(q_weight):
     """"eetq" or "plain" from the bytes of a weight-only layer's q_weight (int8 [K,N]).  EETQ's image stores q + 128: viewed as int8
     a typical weight (|q| small) lands next to -128 / 127, so the mean magnitude is ~100; a plain per-column symmetric quantisation
-    has its mass around zero (mean |q| ~ 20-45 for Gaussian-like weights scaled to absmax 127).  Threshold 64."""
-    v = q_weight.detach().to("cpu").view(torch.int8).to(torch.int16).abs().float().mean().item()
-    return "eetq" if v > 64.0 else "plain"
+    has its mass around zero (mean |q| ~ 20-45 for Gaussian-like weights scaled to absmax 127).  Threshold 64; `_W8A16_BAND` is the
+    margin inside which load_quantized refuses to decide."""
+    return "eetq" if _w8a16_stat(q_weight) > 64.0 else "plain"
+
+
+_W8A16_BAND = (52.0, 80.0)
 
 
 def load_quantized(root, load_dir, cache, arch="LlamaForCausalLM", blocks=None, dev=None, strict=True, w8a16_layout=None):
     """`from_quantized` for an already-constructed skeleton (`base.py:161-229`): swap the Linears for empty quantised
     layers per `quant_config.json`, then load the shards.  Returns the quant config.
     `w8a16_layout` ("plain" | "eetq") overrides what quant_config.json says about weight-only layers; when neither says anything the
-    layout is detected from the bytes (module docstring) and reported in a warning."""
+    checkpoint is the reference's ("eetq") unless every weight-only layer's bytes say plain (module docstring)."""
     quant_config = read_quant_config(load_dir)
     prepare_(root, quant_config, cache, arch, blocks, dev)
     sd = load_state_dict_files(load_dir)
     layout = w8a16_layout if w8a16_layout is not None else quant_config.get("w8a16_layout")
     wo_keys = [pre + "q_weight" for pre in _weight_only_prefixes(root) if pre + "q_weight" in sd]
     if layout is None and wo_keys:
-        votes = [detect_w8a16_layout(sd[k]) for k in wo_keys]
-        layout = "eetq" if votes.count("eetq") * 2 > len(votes) else "plain"
-        warnings.warn(f"{load_dir}: quant_config.json has no 'w8a16_layout' key; the {len(wo_keys)} weight-only layer(s) look like the "
-                      f"{'reference (EETQ-interleaved)' if layout == 'eetq' else 'plain [K,N] int8'} form ({votes.count(layout)}/{len(votes)} "
-                      f"by byte statistics) and are loaded as such - pass w8a16_layout= to load_quantized to decide yourself",
-                      RuntimeWarning, stacklevel=2)
+        # No key: what the reference writes (interleaved image) - the default.  The bytes are consulted only to recognise this library's
+        # own round-1 files (plain matrix, written before the `writer` marker existed); anything in between is an error, not a guess.
+        stats = [_w8a16_stat(sd[k]) for k in wo_keys]
+        near = [k for k, v in zip(wo_keys, stats) if _W8A16_BAND[0] <= v <= _W8A16_BAND[1]]
+        votes = ["eetq" if v > 64.0 else "plain" for v in stats]
+        if near or len(set(votes)) > 1:
+            raise RuntimeError(f"{load_dir}: quant_config.json has no 'w8a16_layout' key and the {len(wo_keys)} weight-only layer(s) do not "
+                               f"agree on a layout by their bytes ({votes.count('eetq')} look EETQ-interleaved, {votes.count('plain')} plain, "
+                               f"{len(near)} undecidable, e.g. {(near or wo_keys)[0]}): pass w8a16_layout='eetq' (a reference checkpoint) or "
+                               f"'plain' to load_quantized")
+        layout = votes[0]
+        if layout == "plain":
+            warnings.warn(f"{load_dir}: quant_config.json has no 'w8a16_layout' key; a keyless checkpoint is normally the reference's "
+                          f"(EETQ-interleaved), but all {len(wo_keys)} weight-only layer(s) hold plain [K,N] int8 by their bytes (a "
+                          f"round-1 checkpoint of this library) and are loaded as such - pass w8a16_layout= to decide yourself",
+                          RuntimeWarning, stacklevel=2)
     if layout is None:
         layout = "plain"                                     # no weight-only layers: nothing to convert
     if layout not in ("plain", "eetq"):
