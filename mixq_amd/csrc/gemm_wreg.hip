@@ -46,6 +46,10 @@ struct WrArgs {
     int xblocks, wblocks;                             // 16-row blocks per k-step of each operand
     int krot;                                         // k-step rotation between neighbouring N tiles (0: every tile starts at k = 0)
     int gm;                                           // M tiles per group of the tile order (see the tile map in the kernel)
+    // reciprocals for the tile map's two divisions (q = mulhi(n, m), exact for n d < 2^32, m = floor(2^32 / d) + 1; 0 stands for d = 1):
+    // by gm x tiles_n, by gm, by the last group's size - three run-time divisions (~25 dependent scalar instructions each, through the
+    // float reciprocal) stood in front of every wave's first operand request
+    unsigned int mg_group, mg_gm, mg_last;
     unsigned long long* trace;
     // optional side output for the NEXT layer's quantiser (down_proj behind gate_proj): row_amax[m] = max over the columns n whose bit in
     // amax_mask is clear of |fp16 bits of y[m,n]| (atomic max of bit patterns: order-independent, exact); amax_mask: bit n of a uint32 array
@@ -110,7 +114,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #ifdef MIXQ_NO_WRAP_TAIL
     constexpr bool WRAP = F6R || ABL == 41;
 #else
-    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && ABL == 0 && LOADERS != 0);
+    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && (ABL == 0 || (ABL >= 60 && ABL < 70)) && LOADERS != 0);
 #endif
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
@@ -130,6 +134,16 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // static fp16 columns (linear.py:100, fp_features_num), and k-steps beyond TQ cost every wave a global round trip for the same rows
     constexpr int TQ = SELF ? 0 : (F6 ? 4 : 2);
     constexpr int TAILX = NSTAGE * STAGE_BYTES;          // LDS offset of those blocks: behind the ring, [TQ][MB] x 1 KiB
+    // EPI2 (round 4): the epilogue as a pipeline of ROW PANELS (PJ = 2 blocks = 32 token rows each).  A consumer wave dequantises panel
+    // p+1 between the fp16 tail MFMAs of panel p (the VALU work hides the MFMAs' latency and the other way round; the first form ran
+    // 24 dependent MFMA pairs back to back and stalled in order behind each), converts panel p to fp16 (v_cvt_pk_f16_f32), stages it in
+    // LDS and signals; the LOADER waves - idle since their last DMA - copy staged panels out to Y with 16-byte nt row stores while the
+    // consumers work on the next panel, so only the last panel's stores (shared by all six waves) are exposed behind the arithmetic.
+    // Same operations per element in the same order as the first form (kept for the fat prefill tile, the pairwise split-K form and as
+    // the tuning build's A/B partner, ABL 60): bit-identical (tests/test_gpu_round4.py).
+    constexpr int PJ = MB >= 2 ? 2 : 1, NPAN = MB / PJ, PROWS = PJ * 16;
+    constexpr bool EPI2 = !SELF && ABL != 50 && ABL != 60 && (MB % PJ == 0) &&
+                          (((BM * OPITCH + 15) & ~15) + WR_CW * 4 * BM * 4 <= TAILX);   // (the staged tile and the row-maximum slots stay clear of the tail's X_out blocks)
     static_assert(MB % ISSUERS == 0 && (STAGE_BYTES / 1024) % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
     static_assert(!F6 || (!SELF && (ABL == 0 || ABL == 1 || ABL == 2 || ABL == 3)), "the FP6 form exists for the shipped loop (and its feed ablations) only");
     static_assert(!F6R || ABL == 0, "the tuple-ring form has no ablations");
@@ -139,6 +153,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (ABL == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
+    // Every argument the prologue needs, asked for in the FIRST basic block: the compiler requests a kernel argument where it is first used,
+    // one scalar load per use site with a wait behind each (nine dependent round trips to a cold scalar cache in front of the first
+    // operand request: ~0.3 us of the 1.0 us between entry and the first k-step); named together here they become a few wide loads and ONE wait.
+    asm volatile("" :: "s"(a.qx), "s"(a.qw), "s"(a.sx), "s"(a.sw), "s"(a.M), "s"(a.N), "s"(a.KB), "s"(a.tiles_m), "s"(a.tiles_n),
+                 "s"(a.xblocks), "s"(a.wblocks), "s"(a.krot), "s"(a.gm), "s"(a.n_out_dev), "s"(a.bias), "s"(a.n_out), "s"(a.mg_group), "s"(a.mg_gm),
+                 "s"(a.mg_last), "s"(a.ldy), "s"(a.y));
+    const bool staged = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
 
     // KS (ABL = 50): pairwise split-K.  Long-K layers with few output tiles (11008 -> 4096 at 512 tokens: 128 tiles of 128 x 128, half the
     // CUs idle, or 256 tiles of 64 x 128 at a third fewer MACs per operand byte) run TWO workgroups per tile, each over half of K: the
@@ -162,10 +183,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // x 4 weight panels need 8 MB for the same work.
     int tm, tn;
     {
-        const int per_group = a.gm * a.tiles_n, grp = tile / per_group, first_m = grp * a.gm;
-        const int gsz = a.tiles_m - first_m < a.gm ? a.tiles_m - first_m : a.gm;
+        auto fdiv = [](int n, unsigned int m) MIXQ_INL { return m ? static_cast<int>(__umulhi(static_cast<unsigned int>(n), m)) : n; };
+        const int per_group = a.gm * a.tiles_n, grp = fdiv(tile, a.mg_group), first_m = grp * a.gm;
+        const bool last = a.tiles_m - first_m < a.gm;
+        const int gsz = last ? a.tiles_m - first_m : a.gm;
         const int r = tile - grp * per_group;
-        tn = r / gsz; tm = first_m + (r - tn * gsz);
+        tn = fdiv(r, last ? a.mg_last : a.mg_gm); tm = first_m + (r - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -176,7 +199,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // Integer accumulation is exact in any order, so a tile may walk K from any starting k-step and wrap around.  Tiles of one
     // weight panel (same tn) start together - they share the panel's bytes in their XCD's L2 - while neighbouring panels start
     // krot k-steps apart, so the CUs of an XCD are not all asking the L2 for the same activation slab at the same moment.
-    const int rot = nk > 1 ? (tn * a.krot) % nk : 0;
+    const int rot = (a.krot && nk > 1) ? (tn * a.krot) % nk : 0;                 // (the division only when a rotation was asked for)
     auto stamp = [&](int slot) MIXQ_INL {                         // diagnostics (mixq_gemm_set_trace): tools build only
 #ifdef MIXQ_TUNING
         if (a.trace && tid == 0) {
@@ -188,6 +211,43 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #endif
     };
     stamp(0);
+    // EPI2 copy-out: rows [p PROWS, (p + 1) PROWS) of the staged fp16 tile -> Y, 16 bytes per lane, every LDS read of a lane issued before
+    // its first store (ONE LDS round trip), streaming (nt) stores - Y is written once and not re-read by this kernel.  The first form
+    // spent its "store issue" time on ADDRESSES (a division by the row length, 64-bit multiply-adds and two bounds tests per 16 bytes:
+    // ~20 VALU instructions, some quarter-rate, per store).  Here a thread's chunk geometry - byte offset in Y relative to the panel's
+    // first row, byte offset in the staged tile - is worked out ONCE (copy_setup: the loaders during their idle drain, the consumers
+    // before the barrier) and is the same for every panel; a panel's stores are buffer stores on a descriptor that starts at the panel's
+    // first row and ends behind its last valid one, so rows past M are dropped by the hardware's range check and chunks past N (or past
+    // the panel) carry an offset that is always out of range: no address arithmetic and no test per store.
+    constexpr int CPR = BN / 8;                                                  // 16-byte chunks per tile row
+    constexpr int CPCH = PROWS * CPR;                                            // ... per panel
+    constexpr int IT_L = SELF ? 1 : (CPCH + LOADERS * 64 - 1) / (LOADERS * 64 > 0 ? LOADERS * 64 : 1);   // per loader thread
+    constexpr int IT_A = (CPCH + NT - 1) / NT;                                   // per thread when every wave copies (the last panel)
+    auto copy_setup = [&](int t, auto nthr_c, uint32_t* voff, int* loff) MIXQ_INL {
+        constexpr int NTHR = decltype(nthr_c)::value, IT = (CPCH + NTHR - 1) / NTHR;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int q = t + it * NTHR, r = q / CPR, c = q - r * CPR;
+            const bool ok = q < CPCH && n0 + c * 8 < a.N;
+            voff[it] = ok ? static_cast<uint32_t>(r * a.ldy + n0 + c * 8) * 2u : 0x80000000u;
+            loff[it] = ok ? r * OPITCH + c * 16 : 0;
+        }
+    };
+    auto copy_panel = [&](int p, auto nthr_c, const uint32_t* voff, const int* loff) MIXQ_INL {
+        constexpr int NTHR = decltype(nthr_c)::value, IT = (CPCH + NTHR - 1) / NTHR;
+        int rows = a.M - m0 - p * PROWS;                                         // valid rows from the panel's first one on
+        rows = rows < 0 ? 0 : (rows > PROWS ? PROWS : rows);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.y + static_cast<size_t>(m0 + p * PROWS) * a.ldy, 0, rows * a.ldy * 2, 0x00020000);
+        u32x4 v[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) v[it] = *reinterpret_cast<const u32x4*>(lds + p * PROWS * OPITCH + loff[it]);
+        if (ABL != 7 || a.act == 12345) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs, voff[it], 0, ABL == 8 ? 0 : 2 /* nt */);
+        }
+    };
+    uint32_t voffA[IT_A];                                                        // this thread's chunks when all NT threads copy a panel
+    int loffA[IT_A];
 
     // =================================================================================================================
     // loader wave(s): X stage kt+LOOK issued, stage kt+1 retired, then the k-step's barrier
@@ -301,8 +361,57 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
         }
         wr_wait_vmcnt<0>();                                                      // (nk = 1: no drain iteration waited for the tail blocks)
-        __builtin_amdgcn_s_barrier();                                            // the epilogue's two barriers
-        __builtin_amdgcn_s_barrier();
+        uint32_t voffL[IT_L];
+        int loffL[IT_L];
+        if constexpr (EPI2) {
+            // EPI2, in the shadow of the consumers' last k-step (which has no barrier): (1) the X_out blocks of the tail in LDS are made
+            // safe to multiply as they are - columns >= n_out (the pad of the caller's buffer may hold anything, NaN patterns included) and
+            // whole k-steps that do not exist (never requested: stale LDS bytes) become zeros - so the consumers spend no VALU on masks
+            // (each loader wave fixes the blocks it requested itself: its own vmcnt(0) above covers them); (2) this thread's copy-out geometry.
+            if constexpr (TQ > 0) {
+                int n_out_l = 0;
+                if (a.xo && a.wo) {
+                    n_out_l = a.n_out;
+                    if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out_l = nd < n_out_l ? nd : n_out_l; }
+                }
+#pragma unroll
+                for (int kk = 0; kk < TQ; ++kk) {
+                    if (kk * 32 + 32 > n_out_l) {                               // (wave-uniform: full k-steps are left alone)
+                        const int kb = kk * 32 + (lane >> 4) * 8;
+                        u32x4 keep;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            uint32_t k = 0;
+                            if (kb + 2 * d < n_out_l)     k |= 0x0000ffffu;
+                            if (kb + 2 * d + 1 < n_out_l) k |= 0xffff0000u;
+                            keep[d] = k;
+                        }
+#pragma unroll
+                        for (int i = 0; i < TLOADS; ++i) {
+                            u32x4* blk = reinterpret_cast<u32x4*>(lds + TAILX + (kk * MB + lw + i * LOADERS) * 1024 + lane * 16);
+                            *blk = kk * 32 < n_out_l ? (*blk & keep) : u32x4{0, 0, 0, 0};
+                        }
+                    }
+                }
+            }
+            copy_setup(tid - CW * 64, std::integral_constant<int, LOADERS * 64>{}, voffL, loffL);
+            copy_setup(tid, std::integral_constant<int, NT>{}, voffA, loffA);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the fix-up's ds_writes: s_barrier does not wait for them
+        }
+        __builtin_amdgcn_s_barrier();                                            // the epilogue's first barrier (ring dead, X_out blocks landed)
+        if constexpr (EPI2) {
+            // EPI2: one barrier per row panel; panels 0 .. NPAN-2 are copied out HERE, under the consumers' work on the next panel (the
+            // last one is shared by all waves behind the final barrier).  Outputs that cannot be staged are stored by the consumers.
+            if constexpr (ABL == 62) __builtin_amdgcn_s_setprio(0);              // probe: the copying loaders below the consumers they share SIMDs with
+#pragma unroll
+            for (int p = 0; p + 1 < NPAN; ++p) {
+                __builtin_amdgcn_s_barrier();                                    // panel p staged
+                if (staged && ABL != 61) copy_panel(p, std::integral_constant<int, LOADERS * 64>{}, voffL, loffL);
+            }
+            __builtin_amdgcn_s_barrier();                                        // last panel staged
+        } else {
+            __builtin_amdgcn_s_barrier();
+        }
     }
     }
 
@@ -320,10 +429,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     if (wave < CW) {
         if constexpr (ABL == 28) __builtin_amdgcn_s_setprio(3);                  // probe: the MFMA waves above the loaders
         if (a.n_out_dev) n_out_dev_v = *a.n_out_dev;
+        auto zero_acc = [&]() MIXQ_INL {
 #pragma unroll
-        for (int j = 0; j < MB; ++j)
+            for (int j = 0; j < MB; ++j)
 #pragma unroll
-            for (int i = 0; i < WNB; ++i) acc[j][i] = acc_t{0, 0, 0, 0};
+                for (int i = 0; i < WNB; ++i) acc[j][i] = acc_t{0, 0, 0, 0};
+        };
+        if constexpr (SELF) zero_acc();                                          // (the others: behind their first operand requests)
 
         // weight stream: wave-uniform block bases (scalar registers), one lane offset
         const uint8_t* wb[WNB];
@@ -378,9 +490,17 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         for (int d = 0; d < NSLOT; ++d)
 #pragma unroll
             for (int i = 0; i < WNB; ++i) {
-                wq[d][i] = i32x4{lane, lane, lane, lane};
-                if constexpr (F6) wq2[d][i] = i32x2{lane, lane};
-                if constexpr (ABL != 0) asm volatile("" : "+v"(wq[d][i]));
+                // the ring's registers are read-write operands of the load statements, so they need a definition in front of the first one:
+                // an EMPTY asm output (no instruction; 15 x 4 v_mov in front of the first weight request otherwise).  Ablation builds that
+                // never load them get defined, opaque values.
+                if constexpr (ABL == 0 || ABL == 50 || (ABL >= 60 && ABL < 70)) {
+                    asm volatile("" : "=v"(wq[d][i]));
+                    if constexpr (F6) asm volatile("" : "=v"(wq2[d][i]));
+                } else {
+                    wq[d][i] = i32x4{lane, lane, lane, lane};
+                    if constexpr (F6) wq2[d][i] = i32x2{lane, lane};
+                    asm volatile("" : "+v"(wq[d][i]));
+                }
             }
         if constexpr (ABL != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
 #pragma unroll
@@ -693,7 +813,6 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 if constexpr (PREBIAS) bvp[i] = a.bias ? *reinterpret_cast<const u32x2_u*>(a.bias + (n < a.N ? n : a.N - 4)) : u32x2{0u, 0u};
             }
         };
-        if constexpr (!SELF) load_scales();
         if constexpr (SELF) {
             // ---- self-loading k loop (prefill form) -------------------------------------------------------------------------
             // Every k-step, in this program order: MB MFMA groups; behind group i*MB/LOADS this wave's piece i of X stage kt+LOOK
@@ -780,7 +899,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (ABL == 25 || ABL == 26) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(8); }
             if constexpr (ABL == 27) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(16); }
         };
-        wr_static_for<0, D>(prologue_w);
+        // Request order: the weights of k-step 0 FIRST - they and the loaders' first stage are what the first MFMA waits for - then the
+        // epilogue's scales (round 3 asked for those before anything else: ~30 address instructions and 14 requests in front of the first
+        // weight request), then the ring's other k-steps, then the accumulators are zeroed under all of it.  The counted waits still hold:
+        // vmcnt retires in order and k-step 0's wait leaves WL (D - 1) requests in flight - exactly the k-steps 1 .. D-1 issued behind
+        // the scales - so the scales have landed with k-step 0 and never sit among the requests a later wait counts.
+        prologue_w(std::integral_constant<int, 0>{});
+        load_scales();
+        wr_static_for<1, D>(prologue_w);
+        zero_acc();
         static_assert(D >= 2 && D <= 16 && WL * (D - 1) < 64, "weight ring depth: run-time wait table / vmcnt range");
         __builtin_amdgcn_s_barrier();                                            // B0
         stamp(1);
@@ -857,7 +984,6 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // =================================================================================================================
     // epilogue
     // =================================================================================================================
-    const bool staged = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
     if (wave < CW) {
         int n_out = a.n_out;
         if (a.n_out_dev) n_out = n_out_dev_v < n_out ? n_out_dev_v : n_out;
@@ -873,6 +999,221 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             o[2] = h2f(static_cast<uint16_t>(v.y & 0xffffu)); o[3] = h2f(static_cast<uint16_t>(v.y >> 16));
         };
 
+        if constexpr (EPI2) {
+            // ---- EPI2: row panels, software-pipelined, copied out by the loader waves (see the note at its declaration) ----------------
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            constexpr int NB = PJ * WNB;                                         // 16 x 16 blocks of one panel (per wave)
+            constexpr int TQ1 = TQ > 0 ? TQ : 1;
+            // (the lane's coordinates again, opaque to the compiler: values derived from them at kernel entry - row indices of the scale
+            // loads - would otherwise be kept alive across the k loop for the epilogue's addresses, in scratch memory where registers are short)
+            int lm = lane & 15, lq = lane >> 4;
+            asm volatile("" : "+v"(lm), "+v"(lq));
+            float swv[WNB][4], sxv[MB];
+            // the weight fragments (W_out rows of this wave, 16 x 32 each) of the first TQ tail k-steps - the ones whose X_out blocks went
+            // through LDS - requested before the barrier; k-steps that do not exist and chunks past the padded width are zeros
+            u32x4 wo2[TQ1][WNB];
+            auto wo_load = [&](int kk, u32x4* dst) MIXQ_INL {
+                const int kb = kk * 32 + lq * 8;
+                const bool in = kk < ksteps && kb < kpad;
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) {
+                    int wr = nw0 + i * 16 + lm; wr = wr < a.N ? wr : a.N - 1;
+                    dst[i] = in ? *reinterpret_cast<const u32x4*>(a.wo + static_cast<size_t>(wr) * a.ldwo + kb) : u32x4{0, 0, 0, 0};
+                }
+            };
+            // columns >= n_out of a k-step (the pad may hold anything, NaN patterns included)
+            auto keep_of = [&](int kk) MIXQ_INL {
+                const int kb = kk * 32 + lq * 8;
+                u32x4 k4;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t k = 0;
+                    if (kb + 2 * d < n_out)     k |= 0x0000ffffu;
+                    if (kb + 2 * d + 1 < n_out) k |= 0xffff0000u;
+                    k4[d] = k;
+                }
+                return k4;
+            };
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): see the first form
+#pragma unroll
+            for (int kk = 0; kk < TQ; ++kk) wo_load(kk, wo2[kk]);
+#pragma unroll
+            for (int i = 0; i < WNB; ++i) unpack4(swp[i], swv[i]);
+#pragma unroll
+            for (int j = 0; j < MB; ++j) sxv[j] = h2f(sxh[j]) * PRE;
+            copy_setup(tid, std::integral_constant<int, NT>{}, voffA, loffA);     // (this thread's share of the last panel's copy-out)
+            __builtin_amdgcn_s_barrier();                                        // every wave is done reading the ring; X_out blocks landed and fixed up
+            stamp(6);
+            // columns >= n_out in the WEIGHT fragments (the pad of weight_cache may hold anything); the X_out blocks were cleaned in LDS by the loaders
+#pragma unroll
+            for (int kk = 0; kk < TQ; ++kk) {
+                if (kk * 32 + 32 > n_out) {
+                    const u32x4 kp = keep_of(kk);
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) wo2[kk][i] &= kp;
+                }
+            }
+            uint32_t rmax[MB];                                                   // running max of |fp16 bits| per tile row (two halves packed)
+#pragma unroll
+            for (int j = 0; j < MB; ++j) rmax[j] = 0u;
+            f32x4 fa[MB][WNB];
+            auto deq = [&](int pn, int b) MIXQ_INL {                // block b of panel pn: acc * sx * sw (this order)
+                const int j = pn * PJ + b / WNB, i = b % WNB;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fa[j][i][r] = static_cast<float>(acc[j][i][r]) * sxv[j] * swv[i][r];
+            };
+            auto finish = [&](auto opt_c, int pn) MIXQ_INL {        // optional terms, fp16, staged or stored (the first form's finish_tile per panel)
+                constexpr bool OPT = decltype(opt_c)::value;
+                u32x2 o[WNB][PJ];
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) {
+                    const int nloc = wave * WN + i * 16 + lq * 4, n = n0 + nloc;
+                    const int nc = n < a.N ? n : a.N - 4;
+                    float bv[4];
+                    if (OPT && has_bias) {
+                        if constexpr (PREBIAS) unpack4(bvp[i], bv);
+                        else unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+                    }
+                    uint32_t keep_lo = 0x7fff7fffu, keep_hi = 0x7fff7fffu;        // |.| of the 4 halves; the next layer's outlier columns drop out
+                    if (OPT && has_amax) {
+                        // (columns past N are computed from clamped operands - values that exist nowhere in y - and count for nothing)
+                        const uint32_t mb = n >= a.N ? 0xfu : (a.amax_mask ? (a.amax_mask[nc >> 5] >> (nc & 31)) & 0xfu : 0u);
+                        if (mb & 1u) keep_lo &= 0xffff0000u;
+                        if (mb & 2u) keep_lo &= 0x0000ffffu;
+                        if (mb & 4u) keep_hi &= 0xffff0000u;
+                        if (mb & 8u) keep_hi &= 0x0000ffffu;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < PJ; ++jj) {
+                        const int j = pn * PJ + jj;
+                        const int m = m0 + j * 16 + lm;
+                        f32x4 f = fa[j][i];
+                        float av[4];
+                        if (OPT && has_add) {
+                            unpack4(*reinterpret_cast<const u32x2_u*>(a.addend + static_cast<size_t>(m < a.M ? m : a.M - 1) * a.lda + nc), av);
+                            if (!mul_add) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) f[r] += av[r];
+                            }
+                        }
+                        if (OPT && do_silu) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) f[r] = wr_silu(f[r]);
+                        }
+                        if (OPT && has_bias) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) f[r] += bv[r];
+                        }
+                        if (OPT && mul_add) {                          // (silu(z) + bias) * up: linear.py:372-373, then mlp.py:61
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) f[r] *= av[r];
+                        }
+                        // round-to-nearest-even, two values per v_cvt_pk_f16_f32
+                        o[i][jj].x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{f[0], f[1]}, f16x2));
+                        o[i][jj].y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{f[2], f[3]}, f16x2));
+                        if (OPT && has_amax) {
+                            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                            const us2 mx = __builtin_elementwise_max(__builtin_bit_cast(us2, o[i][jj].x & keep_lo), __builtin_bit_cast(us2, o[i][jj].y & keep_hi));
+                            rmax[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, rmax[j]), mx));
+                        }
+                    }
+                }
+                if (staged) {
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < PJ; ++jj)
+                            *reinterpret_cast<u32x2*>(lds + ((pn * PJ + jj) * 16 + lm) * OPITCH + (wave * WN + i * 16 + lq * 4) * 2) = o[i][jj];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < PJ; ++jj) {
+                            const int m = m0 + (pn * PJ + jj) * 16 + lm, n = n0 + wave * WN + i * 16 + lq * 4;
+                            if (m < a.M && n < a.N) *reinterpret_cast<u32x2_u*>(a.y + static_cast<size_t>(m) * a.ldy + n) = o[i][jj];
+                        }
+                }
+            };
+            const bool opt = has_add || has_bias || do_silu || has_amax;
+            u32x4 xo2[TQ1][PJ];                                                  // X_out fragments of the current panel (from the LDS blocks)
+            auto xo_read = [&](int pn, int kk) MIXQ_INL {
+#pragma unroll
+                for (int jj = 0; jj < PJ; ++jj)
+                    xo2[kk][jj] = *reinterpret_cast<const u32x4*>(lds + TAILX + (kk * MB + pn * PJ + jj) * 1024 + lane * 16);
+            };
+            auto tail_mma = [&](int j, int i, u32x4 w, u32x4 x) MIXQ_INL {
+                fa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), fa[j][i], 0, 0, 0);
+            };
+#pragma unroll
+            for (int kk = 0; kk < TQ; ++kk) xo_read(0, kk);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) deq(0, b);
+            wr_static_for<0, NPAN>([&](auto p_c) MIXQ_INL {
+                constexpr int pn = decltype(p_c)::value;
+                if constexpr (TQ > 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ONE form for every outlier count (as the first form): k-steps that do not exist multiply zeros - under VALU work that is there
+                    // anyway.  Tail k-steps in order (kk-major: NB MFMAs lie between two on one accumulator); block d of the NEXT panel is
+                    // dequantised behind every TQ-th MFMA.  (The empty asm pins the dequantised block HERE: left alone, the compiler sinks the
+                    // multiplications down to their first use - behind the barrier, where nothing overlaps them.)
+#pragma unroll
+                    for (int kk = 0; kk < TQ; ++kk) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const int slot = kk * NB + b;
+                            tail_mma(pn * PJ + b / WNB, b % WNB, wo2[kk][b % WNB], xo2[kk][b / WNB]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (pn + 1 < NPAN && slot % TQ == 0) {
+                                const int d = slot / TQ, j2 = (pn + 1) * PJ + d / WNB, i2 = d % WNB;
+                                deq(pn + 1, d);
+                                asm volatile("" : "+v"(fa[j2][i2]));
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (pn + 1 < NPAN) xo_read(pn + 1, kk);         // (this k-step's fragments are consumed: the next panel's, in flight under what follows)
+                    }
+                } else {
+                    if constexpr (pn + 1 < NPAN) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) deq(pn + 1, b);
+                    }
+                }
+                // more than 32 TQ outlier columns (rare: the search stops adding beyond 128, linear.py:224): the remaining k-steps with both
+                // operands from global memory, one exposed round trip each
+                for (int kk = TQ; kk < ksteps; ++kk) {
+                    u32x4 wt[WNB], xt[PJ];
+                    wo_load(kk, wt);
+                    const int kb = kk * 32 + lq * 8;
+#pragma unroll
+                    for (int jj = 0; jj < PJ; ++jj) {
+                        int xr = m0 + (pn * PJ + jj) * 16 + lm; xr = xr < a.M ? xr : a.M - 1;
+                        xt[jj] = kb < kpad ? *reinterpret_cast<const u32x4*>(a.xo + static_cast<size_t>(xr) * a.ldxo + kb) : u32x4{0, 0, 0, 0};
+                    }
+                    const u32x4 kp = keep_of(kk);
+#pragma unroll
+                    for (int i = 0; i < WNB; ++i) wt[i] &= kp;
+#pragma unroll
+                    for (int jj = 0; jj < PJ; ++jj) xt[jj] &= kp;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) tail_mma(pn * PJ + b / WNB, b % WNB, wt[b % WNB], xt[b / WNB]);
+                }
+                if (opt) finish(std::true_type{}, pn); else finish(std::false_type{}, pn);
+                if constexpr (pn + 1 == NPAN) {
+                    if (has_amax) {                                              // one slot per (wave, lane group, row): no atomics, no initialisation
+#pragma unroll
+                        for (int j = 0; j < MB; ++j) {
+                            const uint32_t lo = rmax[j] & 0xffffu, hi = rmax[j] >> 16;
+                            *reinterpret_cast<uint32_t*>(lds + AMAX_OFF + ((wave * 4 + lq) * BM + j * 16 + lm) * 4) = lo > hi ? lo : hi;
+                        }
+                    }
+                    stamp(7);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // ds_write is asynchronous; s_barrier does not wait for it
+                __builtin_amdgcn_s_barrier();                                    // panel staged: the loaders (the last one: everybody) copy it out
+            });
+            stamp(3);
+        } else {
         // fp16 outlier tail operands: 16 x 32 fragments, lane = row lm, columns kk*32 + lq*8 .. +8.  TD register sets: with two,
         // the operands of tail k-step kk+1 are in flight behind the MFMAs of kk; the fattest tiles only have room for one.
         constexpr int TD = (SELF || MB * WNB * 4 + 2 * (MB + WNB) * 4 + 40 > 256) ? 1 : 2;
@@ -1083,6 +1424,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // ds_write is asynchronous; s_barrier does not wait for it
         __builtin_amdgcn_s_barrier();                                            // staging tile complete
         stamp(3);
+        }
     }
     if (a.row_amax != nullptr && tid < BM) {                                     // (after the barrier above: every wave's slots are written)
         uint32_t v = 0u;
@@ -1093,10 +1435,17 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         }
         if (m0 + tid < a.M) atomicMax(a.row_amax + m0 + tid, v);
     }
-    if (staged) {
+    if constexpr (EPI2) {
+        if constexpr (ABL == 61) {                                               // probe: EPI2's arithmetic with the first form's copy-out (everything at the end, by everybody)
+            if (staged) {
+#pragma unroll
+                for (int p = 0; p < NPAN; ++p) copy_panel(p, std::integral_constant<int, NT>{}, voffA, loffA);
+            }
+        } else
+        if (staged) copy_panel(NPAN - 1, std::integral_constant<int, NT>{}, voffA, loffA);   // (the earlier panels left under the arithmetic)
+    } else if (staged) {
         // all waves (loader included): 16 bytes per lane, 16 / 24 / 32 consecutive lanes cover one row segment of the tile.  Every
         // LDS read of a lane is issued before its first store, so the copy-out costs ONE LDS round trip, not one per 16 bytes.
-        constexpr int CPR = BN / 8;                                              // 16-byte chunks per tile row
         constexpr int ITER = (BM * CPR + NT - 1) / NT;
         u32x4 v[ITER];
 #pragma unroll
@@ -1139,6 +1488,13 @@ struct WrConfig {
 #define MIXQ_WR(MBv, WNBv, NS, Dv, LD, ABL, TAG)                                                                        \
     { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, ABL>,                                     \
       gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, ABL>, nullptr, 0 }
+// ... int8 only: the 128 x 256 tile's nibble form needs 128 accumulators + the ring + the expanded fragments - it never fitted the
+// registers (112 bytes of scratch in round 3, some of it inside the hand-counted region: one allocation change away from spilling a ring
+// register that is still in flight, which is what round 4's epilogue rewrite then triggered - wrong tiles, caught by the GPU suite).
+// 4-bit layers use the FP6 form (tilings below) or, as nibbles, the LDS-staged kernel of gemm.hip; a forced 128 x 256 configuration
+// answers MIXQ_EINVAL for nibble-packed operands.
+#define MIXQ_WR8(MBv, WNBv, NS, Dv, LD, TAG)                                                                            \
+    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 0>, nullptr, nullptr, 0 }
 // ... and with the FP6 form (Q = 3: the weight ring held as operand tuples; 20.9 vs 22.1 us at the metric shape against Q = 2, which
 // assembles the tuples in front of each k-step's first MFMA and stays as a tuning config): X ring of NS6 stages (12 KiB each at 128 rows), weight ring of D6 k-steps: 2 for the 128-row tiles (a k-step
 // is 128 elements, twice the time of an int8 one; 3 deep is 2.7 % slower - 22.03 vs 22.68 us at the metric shape), 3 for the 64-row
@@ -1157,14 +1513,14 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 8, 4, 1, 0, "128x192_s8_d4_l1"),     // 2: the first form of this kernel (8-deep X ring, one loader)
     MIXQ_WR(8, 3, 12, 4, 2, 0, "128x192_s12_d4_l2"),   // 3
     MIXQ_WR6(8, 2, 16, 4, 2, 8, 2, "128x128_s16_d4_l2"),  // 4
-    MIXQ_WR(8, 4, 16, 3, 2, 0, "128x256_s16_d3_l2"),   // 5 (int4: weight ring depth 2)
+    MIXQ_WR8(8, 4, 16, 3, 2, "128x256_s16_d3_l2"),     // 5 (int8 only)
     MIXQ_WR6(4, 2, 16, 4, 2, 12, 3, "64x128_s16_d4_l2"),  // 6: N = 4096 at M = 512 is exactly 256 such tiles
     MIXQ_WR6(4, 3, 16, 4, 2, 12, 3, "64x192_s16_d4_l2"),  // 7: N = 6144
     MIXQ_WR6(4, 4, 16, 4, 2, 12, 3, "64x256_s16_d4_l2"),  // 8
     MIXQ_WR(8, 1, 8, 4, 1, 0, "128x64_s8_d4_l1"),      // 9
     MIXQ_WR(4, 1, 8, 4, 1, 0, "64x64_s8_d4_l1"),       // 10
     MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 11
-    MIXQ_WR(8, 4, 8, 3, 1, 0, "128x256_s8_d3_l1"),     // 12
+    MIXQ_WR8(8, 4, 8, 3, 1, "128x256_s8_d3_l1"),       // 12 (int8 only)
     MIXQ_WR(4, 2, 8, 4, 1, 0, "64x128_s8_d4_l1"),      // 13
     // small batches (M <= 32) of wide layers (N >= 8192): a weight stream, one 64-channel panel per workgroup.  12.4 us against
     // the 17.4 us of gemm_skinny.hip's in-workgroup K split at 32 x 4096 -> 11008 with cold weights; deeper weight rings (10, 14
@@ -1182,6 +1538,9 @@ const WrConfig g_wr[] = {
     { "wr128x192_f6r_d3", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 3, 2, 0>, 8 },           // Q = 3 ring variants
     { "wr128x192_f6r_s10", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 10, 2, 3, 2, 0>, 10 },
     { "wr128x192_f6_l4", 8, 3, 16, 4, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 4, 0>, 8 },            // four loader waves
+    MIXQ_WR(8, 3, 16, 4, 2, 61, "128x192_p61_epi2_copy_at_end"),
+    MIXQ_WR(8, 3, 16, 4, 2, 62, "128x192_p62_epi2_loaders_prio0"),
+    MIXQ_WR(8, 3, 16, 4, 2, 60, "128x192_p60_epi1"),   // cfg 0 with the first form of the epilogue (round 3's): the A/B partner of EPI2
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic
     MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // cfg 0, MFMA + epilogue only
@@ -1265,6 +1624,7 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
     double best = 1e30; int bi = 0;
     for (const auto& c : cand) {
         const WrConfig& g = g_wr[c.cfg];
+        if (bit == 4 && !g.k4) continue;                 // (tilings without a nibble form)
         const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
         const double t = cdiv(tiles, 256) * (nk * static_cast<double>(c.tk) + c.fixed);
         if (t < best * 0.999) { best = t; bi = c.cfg; }
@@ -1333,6 +1693,12 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
         const int forced_gm = g_wr_krot >> 16;                               // (tuning build: mixq_gemm_set_krot(gm << 16 | krot); 0 = automatic)
         a.gm = forced_gm > 0 ? forced_gm : (a.tiles_m <= 8 ? a.tiles_m : 8);
         if (a.gm > a.tiles_m) a.gm = a.tiles_m;
+    }
+    {
+        auto magic = [](int d) { return d <= 1 ? 0u : static_cast<unsigned int>((1ull << 32) / static_cast<unsigned long long>(d)) + 1u; };
+        a.mg_group = magic(a.gm * a.tiles_n); a.mg_gm = magic(a.gm);
+        a.mg_last = magic(a.tiles_m % a.gm ? a.tiles_m % a.gm : a.gm);
+        if (static_cast<long long>(a.tiles_m) * a.tiles_n * (a.gm * static_cast<long long>(a.tiles_n)) >= (1ll << 32)) return MIXQ_ESHAPE;   // (exactness bound of the reciprocals)
     }
     a.trace = trace;
     a.row_amax = row_amax; a.amax_mask = amax_mask;

@@ -1293,8 +1293,8 @@ def test_every_wreg_tiling_full_epilogue_and_int4():
             lib.mixq_gemm_set_config(names.index("128x128_w2x2_s5_l2"))
             y_lds = n(_run_fused(c, 1))
             for cfg in _wr_configs():
-                if bit == 4 and "self" in names[cfg]:
-                    continue                                # the prefill tiles (four fat self-loading waves) have no nibble form
+                if bit == 4 and ("self" in names[cfg] or "128x256" in names[cfg]):
+                    continue                                # the prefill tiles and 128 x 256 (accumulators + ring + expanded nibbles exceed the registers) have no nibble form
                 assert lib.mixq_gemm_set_config(cfg) == 0
                 y = n(_run_fused(c, 2))
                 assert np.isfinite(y).all(), (names[cfg], M, N, K)
@@ -1609,8 +1609,8 @@ def test_wreg_every_k_step_count_every_tiling():
                 assert lib.mixq_gemm_set_config(cfg) == 0
                 y = n(mixlib.FusedLinear(qxp, qwp, sx, sw, None, None, 0, None, M, N, K))
                 assert np.array_equal(bits(y), bits(want16)), (names[cfg], nk, "int8")
-                if "self" in names[cfg]:
-                    continue                                # (no nibble form of the prefill tiles)
+                if "self" in names[cfg] or "128x256" in names[cfg]:
+                    continue                                # (no nibble form of the prefill tiles, nor of 128 x 256: registers)
                 y4 = n(_i4_call(qxp, qwp, sx4, sw4, M, N, K))
                 assert np.array_equal(bits(y4), bits(want4)), (names[cfg], nk, "int4")
     finally:

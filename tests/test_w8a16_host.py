@@ -175,10 +175,13 @@ def test_weight_only_checkpoint_in_the_references_layout(tmp_path):
         assert torch.equal(fresh.fc_out.q_weight, plain)
 
 
-def test_keyless_checkpoints_are_told_apart_by_their_bytes(tmp_path):
-    """a checkpoint without the `w8a16_layout` key is the reference's (interleaved image) OR this library's own round-1
-    output (plain matrix).  load_quantized decides from the bytes, warns, and an explicit argument overrides."""
+def test_keyless_checkpoints_default_to_the_reference_layout(tmp_path):
+    """a checkpoint without the `w8a16_layout` key is what the reference writes (interleaved image) and loads as such,
+    silently.  The bytes are consulted only to recognise this library's own round-1 output (plain matrix): when EVERY weight-only
+    layer reads as plain it is loaded as plain with a warning; layers that disagree, or sit near the threshold, raise instead of
+    guessing (a mis-vote would load permuted weights).  An explicit argument always wins."""
     import json
+    import warnings as w
     import pytest
     from mixq_amd import checkpoint as ck
     from mixq_amd import MixLibCache
@@ -189,15 +192,21 @@ def test_keyless_checkpoints_are_told_apart_by_their_bytes(tmp_path):
             self.fc_out = torch.nn.Linear(128, 64, bias=False)
 
     class Net(torch.nn.Module):
-        def __init__(self):
+        def __init__(self, n=1):
             super().__init__()
-            self.layers = torch.nn.ModuleList([Blk()])
+            self.layers = torch.nn.ModuleList([Blk() for _ in range(n)])
+    def gaussian(n=1):                                                 # trained weights are bell-shaped: the byte statistic is decisive
+        net = Net(n)
+        for b in net.layers:
+            torch.nn.init.normal_(b.fc_out.weight, std=0.02)
+        return net.half()
     torch.manual_seed(0)
-    m = Net().half()
+    m = gaussian()
     cache = MixLibCache(8, device="cpu")
     ck.quantize_(m, 8, cache, arch="GPTJForCausalLM", blocks=m.layers)
     assert m.layers[0].fc_out.weight_only
     plain = m.layers[0].fc_out.q_weight.clone()
+    assert ck._w8a16_stat(plain) < ck._W8A16_BAND[0] and ck._w8a16_stat(eetq.preprocess_weights(plain)) > ck._W8A16_BAND[1]
     assert ck.detect_w8a16_layout(plain) == "plain" and ck.detect_w8a16_layout(eetq.preprocess_weights(plain)) == "eetq"
     for layout in ("plain", "eetq"):
         d = tmp_path / layout
@@ -207,12 +216,36 @@ def test_keyless_checkpoints_are_told_apart_by_their_bytes(tmp_path):
         cfg.pop("w8a16_layout"); cfg.pop("writer")                   # a round-1 checkpoint of ours / a reference checkpoint
         json.dump(cfg, open(d / "quant_config.json", "w"))
         fresh = Net().half()
-        with pytest.warns(RuntimeWarning, match="w8a16_layout"):
-            ck.load_quantized(fresh, str(d), cache, arch="GPTJForCausalLM", blocks=fresh.layers)
+        if layout == "plain":
+            with pytest.warns(RuntimeWarning, match="w8a16_layout"):
+                ck.load_quantized(fresh, str(d), cache, arch="GPTJForCausalLM", blocks=fresh.layers)
+        else:
+            with w.catch_warnings():                                   # the reference's own form: the default, nothing to say
+                w.simplefilter("error")
+                ck.load_quantized(fresh, str(d), cache, arch="GPTJForCausalLM", blocks=fresh.layers)
         assert torch.equal(fresh.layers[0].fc_out.q_weight, plain), layout
         fresh2 = Net().half()                                          # the explicit argument wins, silently
-        import warnings as w
         with w.catch_warnings():
             w.simplefilter("error")
             ck.load_quantized(fresh2, str(d), cache, arch="GPTJForCausalLM", blocks=fresh2.layers, w8a16_layout=layout)
         assert torch.equal(fresh2.layers[0].fc_out.q_weight, plain)
+    # two weight-only layers that disagree (one plain, one interleaved), and one whose bytes sit between the two populations: no guess
+    m2 = gaussian(2)
+    ck.quantize_(m2, 8, cache, arch="GPTJForCausalLM", blocks=m2.layers)
+    d = tmp_path / "mixed"
+    ck.save_quantized(m2, str(d), {"w_bit": 8}, w8a16_layout="plain")
+    cfg = json.load(open(d / "quant_config.json"))
+    cfg.pop("w8a16_layout"); cfg.pop("writer")
+    json.dump(cfg, open(d / "quant_config.json", "w"))
+    sd = ck.load_state_dict_files(str(d))
+    good = dict(sd)
+    sd["layers.1.fc_out.q_weight"] = eetq.preprocess_weights(sd["layers.1.fc_out.q_weight"])
+    torch.save(sd, str(d / "pytorch_model.bin"))
+    with pytest.raises(RuntimeError, match="w8a16_layout"):
+        ck.load_quantized(Net(2).half(), str(d), cache, arch="GPTJForCausalLM", blocks=None)
+    amb = dict(good)                                                   # (uniform bytes - e.g. an untrained nn.Linear - read the same both ways)
+    g = torch.Generator().manual_seed(1)
+    amb["layers.1.fc_out.q_weight"] = torch.randint(-128, 128, good["layers.1.fc_out.q_weight"].shape, generator=g, dtype=torch.int8)   # mean |q| = 64
+    torch.save(amb, str(d / "pytorch_model.bin"))
+    with pytest.raises(RuntimeError, match="w8a16_layout"):
+        ck.load_quantized(Net(2).half(), str(d), cache, arch="GPTJForCausalLM", blocks=None)
