@@ -114,7 +114,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #ifdef MIXQ_NO_WRAP_TAIL
     constexpr bool WRAP = F6R || ABL == 41;
 #else
-    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && (ABL == 0 || (ABL >= 60 && ABL < 70)) && LOADERS != 0);
+    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && (ABL == 0 || ABL == 6 || (ABL >= 60 && ABL < 70)) && LOADERS != 0);
 #endif
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
@@ -137,11 +137,20 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // EPI2 (round 4): the epilogue as a pipeline of ROW PANELS (PJ = 2 blocks = 32 token rows each).  A consumer wave dequantises panel
     // p+1 between the fp16 tail MFMAs of panel p (the VALU work hides the MFMAs' latency and the other way round; the first form ran
     // 24 dependent MFMA pairs back to back and stalled in order behind each), converts panel p to fp16 (v_cvt_pk_f16_f32), stages it in
-    // LDS and signals; the LOADER waves - idle since their last DMA - copy staged panels out to Y with 16-byte nt row stores while the
-    // consumers work on the next panel, so only the last panel's stores (shared by all six waves) are exposed behind the arithmetic.
+    // LDS and raises a flag word in LDS behind its stores (one LDS unit per CU executes a wave's operations in order: whoever reads the flag
+    // set reads the panel complete - no wait, no barrier on the producing side); the LOADER waves - idle since their last DMA - poll the
+    // flags and copy staged panels out to Y with 16-byte nt row stores while the consumers work on the next panels, so only the last
+    // panels' stores (shared by all six waves behind the one closing barrier) are exposed behind the arithmetic.
     // Same operations per element in the same order as the first form (kept for the fat prefill tile, the pairwise split-K form and as
     // the tuning build's A/B partner, ABL 60): bit-identical (tests/test_gpu_round4.py).
     constexpr int PJ = MB >= 2 ? 2 : 1, NPAN = MB / PJ, PROWS = PJ * 16;
+    // panels the loader waves copy out on their own (the rest is shared by all waves behind the final barrier: the path to memory takes
+    // ~30 cycles per KiB stored, about as long as the consumers need to produce it, so two waves cannot drain more than half the tile in time)
+    // (Tried and dropped, profiles/r04_ab_direct_stores.txt: no staging at all - block pairs exchanged between lanes with v_permlane16_swap so
+    // that a lane holds 16 contiguous bytes, stored straight from registers as 64- / 32-byte row segments.  Bit-identical, 28.6 vs 24.6 us:
+    // the memory system chokes on partial-line writes; full 384-byte row segments out of LDS are what it takes.)
+    constexpr int LP = (SELF || NPAN < 3) ? 0 : (ABL == 61 ? 0 : (ABL == 67 ? NPAN - 1 : NPAN - 2));   // (NPAN - 1, probe 67: the consumers end up waiting for the loaders: 24.14 vs 23.94 us)
+    constexpr int FLAG_OFF = TAILX + TQ * MB * 1024;     // LDS: "panel p staged by consumer wave w" words [NPAN][CW], behind the tail's X_out blocks
     constexpr bool EPI2 = !SELF && ABL != 50 && ABL != 60 && (MB % PJ == 0) &&
                           (((BM * OPITCH + 15) & ~15) + WR_CW * 4 * BM * 4 <= TAILX);   // (the staged tile and the row-maximum slots stay clear of the tail's X_out blocks)
     static_assert(MB % ISSUERS == 0 && (STAGE_BYTES / 1024) % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
@@ -149,7 +158,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     static_assert(!F6R || ABL == 0, "the tuple-ring form has no ablations");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
     static_assert(!SELF || (LOOK == D + 1 && !I4 && ABL == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
-    static_assert(NSTAGE * STAGE_BYTES + TQ * MB * 1024 <= 160 * 1024, "X ring + tail blocks must fit the 160 KiB of LDS");
+    static_assert(NSTAGE * STAGE_BYTES + TQ * MB * 1024 + 64 <= 160 * 1024, "X ring + tail blocks + panel flags must fit the 160 KiB of LDS");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (ABL == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
@@ -211,6 +220,14 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #endif
     };
     stamp(0);
+    // second set of stamps (tools/trace_gemm.py --panels): the same buffer 16 x 4096 entries further on; `who`: the thread that stamps
+    auto stamp2 = [&](int slot, int who) MIXQ_INL {
+#ifdef MIXQ_TUNING
+        if (a.trace && tid == who) a.trace[16 * 4096 + blockIdx.x * 16 + slot] = wall_clock64();
+#else
+        (void)slot; (void)who;
+#endif
+    };
     // EPI2 copy-out: rows [p PROWS, (p + 1) PROWS) of the staged fp16 tile -> Y, 16 bytes per lane, every LDS read of a lane issued before
     // its first store (ONE LDS round trip), streaming (nt) stores - Y is written once and not re-read by this kernel.  The first form
     // spent its "store issue" time on ADDRESSES (a division by the row length, 64-bit multiply-adds and two bounds tests per 16 bytes:
@@ -394,21 +411,33 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     }
                 }
             }
+            if (tid - CW * 64 < NPAN * CW) *reinterpret_cast<uint32_t*>(lds + FLAG_OFF + (tid - CW * 64) * 4) = 0u;   // the panels' flags: clear before anybody can raise one
             copy_setup(tid - CW * 64, std::integral_constant<int, LOADERS * 64>{}, voffL, loffL);
             copy_setup(tid, std::integral_constant<int, NT>{}, voffA, loffA);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the fix-up's ds_writes: s_barrier does not wait for them
         }
         __builtin_amdgcn_s_barrier();                                            // the epilogue's first barrier (ring dead, X_out blocks landed)
         if constexpr (EPI2) {
-            // EPI2: one barrier per row panel; panels 0 .. NPAN-2 are copied out HERE, under the consumers' work on the next panel (the
-            // last one is shared by all waves behind the final barrier).  Outputs that cannot be staged are stored by the consumers.
+            // EPI2: panels 0 .. LP-1 are copied out HERE, each as soon as all four consumer waves have raised its flag, under the consumers'
+            // work on the later panels (which are shared by all waves behind the closing barrier).  Outputs that cannot be staged are
+            // stored by the consumers themselves.
             if constexpr (ABL == 62) __builtin_amdgcn_s_setprio(0);              // probe: the copying loaders below the consumers they share SIMDs with
+            stamp2(8, CW * 64);
+            if (staged) {
 #pragma unroll
-            for (int p = 0; p + 1 < NPAN; ++p) {
-                __builtin_amdgcn_s_barrier();                                    // panel p staged
-                if (staged && ABL != 61) copy_panel(p, std::integral_constant<int, LOADERS * 64>{}, voffL, loffL);
+                for (int p = 0; p < LP; ++p) {
+                    for (;;) {
+                        const u32x4 f = *reinterpret_cast<const volatile u32x4*>(lds + FLAG_OFF + p * CW * 4);
+                        if (f[0] & f[1] & f[2] & f[3]) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    asm volatile("" ::: "memory");                               // (the panel's reads stay behind the poll)
+                    stamp2(9 + 2 * p, CW * 64);
+                    copy_panel(p, std::integral_constant<int, LOADERS * 64>{}, voffL, loffL);
+                    stamp2(10 + 2 * p, CW * 64);
+                }
             }
-            __builtin_amdgcn_s_barrier();                                        // last panel staged
+            __builtin_amdgcn_s_barrier();                                        // every panel staged
         } else {
             __builtin_amdgcn_s_barrier();
         }
@@ -493,7 +522,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 // the ring's registers are read-write operands of the load statements, so they need a definition in front of the first one:
                 // an EMPTY asm output (no instruction; 15 x 4 v_mov in front of the first weight request otherwise).  Ablation builds that
                 // never load them get defined, opaque values.
-                if constexpr (ABL == 0 || ABL == 50 || (ABL >= 60 && ABL < 70)) {
+                if constexpr (ABL == 0 || ABL == 6 || ABL == 50 || (ABL >= 60 && ABL < 70)) {
                     asm volatile("" : "=v"(wq[d][i]));
                     if constexpr (F6) asm volatile("" : "=v"(wq2[d][i]));
                 } else {
@@ -1061,79 +1090,74 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             auto deq = [&](int pn, int b) MIXQ_INL {                // block b of panel pn: acc * sx * sw (this order)
                 const int j = pn * PJ + b / WNB, i = b % WNB;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) fa[j][i][r] = static_cast<float>(acc[j][i][r]) * sxv[j] * swv[i][r];
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (ABL == 66) fa[j][i][r] = static_cast<float>(acc[j][i][r]);   // probe: no scaling
+                    else fa[j][i][r] = static_cast<float>(acc[j][i][r]) * sxv[j] * swv[i][r];
+                }
             };
-            auto finish = [&](auto opt_c, int pn) MIXQ_INL {        // optional terms, fp16, staged or stored (the first form's finish_tile per panel)
-                constexpr bool OPT = decltype(opt_c)::value;
-                u32x2 o[WNB][PJ];
+            // optional terms, fp16, staged or stored: the 16-channel block column i of panel pn (PJ blocks) - the first form's finish_tile, cut
+            // into pieces small enough to sit between two MFMAs
+            auto finish_col = [&](auto opt_c, auto st_c, int pn, int i) MIXQ_INL {
+                constexpr bool OPT = decltype(opt_c)::value, ST = decltype(st_c)::value;   // ST: staged through LDS (else: 8-byte stores straight to Y)
+                const int nloc = wave * WN + i * 16 + lq * 4, n = n0 + nloc;
+                const int nc = n < a.N ? n : a.N - 4;
+                float bv[4];
+                if (OPT && has_bias) {
+                    if constexpr (PREBIAS) unpack4(bvp[i], bv);
+                    else unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+                }
+                uint32_t keep_lo = 0x7fff7fffu, keep_hi = 0x7fff7fffu;            // |.| of the 4 halves; the next layer's outlier columns drop out
+                if (OPT && has_amax) {
+                    // (columns past N are computed from clamped operands - values that exist nowhere in y - and count for nothing)
+                    const uint32_t mb = n >= a.N ? 0xfu : (a.amax_mask ? (a.amax_mask[nc >> 5] >> (nc & 31)) & 0xfu : 0u);
+                    if (mb & 1u) keep_lo &= 0xffff0000u;
+                    if (mb & 2u) keep_lo &= 0x0000ffffu;
+                    if (mb & 4u) keep_hi &= 0xffff0000u;
+                    if (mb & 8u) keep_hi &= 0x0000ffffu;
+                }
 #pragma unroll
-                for (int i = 0; i < WNB; ++i) {
-                    const int nloc = wave * WN + i * 16 + lq * 4, n = n0 + nloc;
-                    const int nc = n < a.N ? n : a.N - 4;
-                    float bv[4];
+                for (int jj = 0; jj < PJ; ++jj) {
+                    const int j = pn * PJ + jj;
+                    const int m = m0 + j * 16 + lm;
+                    f32x4 f = fa[j][i];
+                    float av[4];
+                    if (OPT && has_add) {
+                        unpack4(*reinterpret_cast<const u32x2_u*>(a.addend + static_cast<size_t>(m < a.M ? m : a.M - 1) * a.lda + nc), av);
+                        if (!mul_add) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) f[r] += av[r];
+                        }
+                    }
+                    if (OPT && do_silu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] = wr_silu(f[r]);
+                    }
                     if (OPT && has_bias) {
-                        if constexpr (PREBIAS) unpack4(bvp[i], bv);
-                        else unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] += bv[r];
                     }
-                    uint32_t keep_lo = 0x7fff7fffu, keep_hi = 0x7fff7fffu;        // |.| of the 4 halves; the next layer's outlier columns drop out
+                    if (OPT && mul_add) {                              // (silu(z) + bias) * up: linear.py:372-373, then mlp.py:61
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] *= av[r];
+                    }
+                    u32x2 o;                                           // round-to-nearest-even, two values per v_cvt_pk_f16_f32
+                    o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{f[0], f[1]}, f16x2));
+                    o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{f[2], f[3]}, f16x2));
                     if (OPT && has_amax) {
-                        // (columns past N are computed from clamped operands - values that exist nowhere in y - and count for nothing)
-                        const uint32_t mb = n >= a.N ? 0xfu : (a.amax_mask ? (a.amax_mask[nc >> 5] >> (nc & 31)) & 0xfu : 0u);
-                        if (mb & 1u) keep_lo &= 0xffff0000u;
-                        if (mb & 2u) keep_lo &= 0x0000ffffu;
-                        if (mb & 4u) keep_hi &= 0xffff0000u;
-                        if (mb & 8u) keep_hi &= 0x0000ffffu;
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        const us2 mx = __builtin_elementwise_max(__builtin_bit_cast(us2, o.x & keep_lo), __builtin_bit_cast(us2, o.y & keep_hi));
+                        rmax[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, rmax[j]), mx));
                     }
-#pragma unroll
-                    for (int jj = 0; jj < PJ; ++jj) {
-                        const int j = pn * PJ + jj;
-                        const int m = m0 + j * 16 + lm;
-                        f32x4 f = fa[j][i];
-                        float av[4];
-                        if (OPT && has_add) {
-                            unpack4(*reinterpret_cast<const u32x2_u*>(a.addend + static_cast<size_t>(m < a.M ? m : a.M - 1) * a.lda + nc), av);
-                            if (!mul_add) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) f[r] += av[r];
-                            }
-                        }
-                        if (OPT && do_silu) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) f[r] = wr_silu(f[r]);
-                        }
-                        if (OPT && has_bias) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) f[r] += bv[r];
-                        }
-                        if (OPT && mul_add) {                          // (silu(z) + bias) * up: linear.py:372-373, then mlp.py:61
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) f[r] *= av[r];
-                        }
-                        // round-to-nearest-even, two values per v_cvt_pk_f16_f32
-                        o[i][jj].x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{f[0], f[1]}, f16x2));
-                        o[i][jj].y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{f[2], f[3]}, f16x2));
-                        if (OPT && has_amax) {
-                            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                            const us2 mx = __builtin_elementwise_max(__builtin_bit_cast(us2, o[i][jj].x & keep_lo), __builtin_bit_cast(us2, o[i][jj].y & keep_hi));
-                            rmax[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, rmax[j]), mx));
-                        }
-                    }
+                    if constexpr (ABL == 65) { asm volatile("" :: "v"(o)); }      // probe: converted, never staged
+                    else if constexpr (ST) *reinterpret_cast<u32x2*>(lds + (j * 16 + lm) * OPITCH + nloc * 2) = o;
+                    else if (m < a.M && n < a.N) *reinterpret_cast<u32x2_u*>(a.y + static_cast<size_t>(m) * a.ldy + n) = o;
                 }
-                if (staged) {
-#pragma unroll
-                    for (int i = 0; i < WNB; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < PJ; ++jj)
-                            *reinterpret_cast<u32x2*>(lds + ((pn * PJ + jj) * 16 + lm) * OPITCH + (wave * WN + i * 16 + lq * 4) * 2) = o[i][jj];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < WNB; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < PJ; ++jj) {
-                            const int m = m0 + (pn * PJ + jj) * 16 + lm, n = n0 + wave * WN + i * 16 + lq * 4;
-                            if (m < a.M && n < a.N) *reinterpret_cast<u32x2_u*>(a.y + static_cast<size_t>(m) * a.ldy + n) = o[i][jj];
-                        }
-                }
+            };
+            auto raise_flag = [&](int pn) MIXQ_INL {
+                // panel staged by this wave: a flag word written BEHIND the panel's stores (asm with a memory clobber: the compiler may not move
+                // it ahead of them; the LDS executes one wave's operations in order)
+                const uint32_t one = 1u, fa_ = FLAG_OFF + (pn * CW + wave) * 4;
+                asm volatile("ds_write_b32 %0, %1" :: "v"(fa_), "v"(one) : "memory");
             };
             const bool opt = has_add || has_bias || do_silu || has_amax;
             u32x4 xo2[TQ1][PJ];                                                  // X_out fragments of the current panel (from the LDS blocks)
@@ -1143,44 +1167,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     xo2[kk][jj] = *reinterpret_cast<const u32x4*>(lds + TAILX + (kk * MB + pn * PJ + jj) * 1024 + lane * 16);
             };
             auto tail_mma = [&](int j, int i, u32x4 w, u32x4 x) MIXQ_INL {
+                if constexpr (ABL == 64) return;                                 // probe: the epilogue without its tail MFMAs (results are garbage)
                 fa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), fa[j][i], 0, 0, 0);
             };
-#pragma unroll
-            for (int kk = 0; kk < TQ; ++kk) xo_read(0, kk);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) deq(0, b);
-            wr_static_for<0, NPAN>([&](auto p_c) MIXQ_INL {
-                constexpr int pn = decltype(p_c)::value;
-                if constexpr (TQ > 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    // ONE form for every outlier count (as the first form): k-steps that do not exist multiply zeros - under VALU work that is there
-                    // anyway.  Tail k-steps in order (kk-major: NB MFMAs lie between two on one accumulator); block d of the NEXT panel is
-                    // dequantised behind every TQ-th MFMA.  (The empty asm pins the dequantised block HERE: left alone, the compiler sinks the
-                    // multiplications down to their first use - behind the barrier, where nothing overlaps them.)
-#pragma unroll
-                    for (int kk = 0; kk < TQ; ++kk) {
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            const int slot = kk * NB + b;
-                            tail_mma(pn * PJ + b / WNB, b % WNB, wo2[kk][b % WNB], xo2[kk][b / WNB]);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (pn + 1 < NPAN && slot % TQ == 0) {
-                                const int d = slot / TQ, j2 = (pn + 1) * PJ + d / WNB, i2 = d % WNB;
-                                deq(pn + 1, d);
-                                asm volatile("" : "+v"(fa[j2][i2]));
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        if constexpr (pn + 1 < NPAN) xo_read(pn + 1, kk);         // (this k-step's fragments are consumed: the next panel's, in flight under what follows)
-                    }
-                } else {
-                    if constexpr (pn + 1 < NPAN) {
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) deq(pn + 1, b);
-                    }
-                }
-                // more than 32 TQ outlier columns (rare: the search stops adding beyond 128, linear.py:224): the remaining k-steps with both
-                // operands from global memory, one exposed round trip each
+            // more than 32 TQ outlier columns (rare: the search stops adding beyond 128, linear.py:224): the remaining k-steps with both
+            // operands from global memory, one exposed round trip each
+            auto extra_ksteps = [&](int pn) MIXQ_INL {
                 for (int kk = TQ; kk < ksteps; ++kk) {
                     u32x4 wt[WNB], xt[PJ];
                     wo_load(kk, wt);
@@ -1198,20 +1190,99 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
                     for (int b = 0; b < NB; ++b) tail_mma(pn * PJ + b / WNB, b % WNB, wt[b % WNB], xt[b / WNB]);
                 }
-                if (opt) finish(std::true_type{}, pn); else finish(std::false_type{}, pn);
-                if constexpr (pn + 1 == NPAN) {
-                    if (has_amax) {                                              // one slot per (wave, lane group, row): no atomics, no initialisation
+            };
 #pragma unroll
-                        for (int j = 0; j < MB; ++j) {
-                            const uint32_t lo = rmax[j] & 0xffffu, hi = rmax[j] >> 16;
-                            *reinterpret_cast<uint32_t*>(lds + AMAX_OFF + ((wave * 4 + lq) * BM + j * 16 + lm) * 4) = lo > hi ? lo : hi;
+            for (int kk = 0; kk < TQ; ++kk) xo_read(0, kk);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) deq(0, b);
+            // The pipeline (one body for every outlier count, as the first form: k-steps that do not exist multiply zeros - under VALU work
+            // that is there anyway).  Iteration pn runs panel pn's tail MFMAs in order (kk-major: NB MFMAs lie between two on one accumulator)
+            // and, BETWEEN them, dequantises block d of panel pn + 1 behind every TQ-th MFMA and converts / stages block column i of panel
+            // pn - 1 behind some of the others: one wave per SIMD hides ~4 plain VALU instructions behind a 16-cycle MFMA, and a ds_write_b64
+            // issued every ~80 cycles costs its issue slot where six in a row cost 24 cycles each (the CU's LDS takes one per 6 cycles from
+            // its four waves: tools/ubench_valu.hip).  (The empty asm statements pin a piece HERE: left alone, the compiler sinks the
+            // multiplications down to their first use, where nothing overlaps them.)  With optional terms (SiLU, bias, addend, row maxima)
+            // the staging stays behind the panel's MFMAs: its global loads and transcendentals do not fit between two MFMAs.
+            constexpr int SLOTS = TQ * NB;
+            // (staging one panel BEHIND, its conversions and LDS writes between the next panel's MFMAs - MIXQ_EPI_LAG - was built and measured:
+            // 24.71 vs 24.50 us, the flags go up a panel later and the loaders start later; the MFMAs of the tail are what the phase waits for,
+            // 0.88 us of the launch in the no-tail ablation, not the LDS writes: 0.06 us.  profiles/r04_epilogue_ablations.txt)
+#ifdef MIXQ_EPI_LAG
+            constexpr bool LAGOK = TQ > 0 && SLOTS >= 2 * WNB;
+#else
+            constexpr bool LAGOK = false;
+#endif
+            const bool lag = LAGOK && !opt && staged;
+            wr_static_for<0, NPAN + 1>([&](auto p_c) MIXQ_INL {
+                constexpr int pn = decltype(p_c)::value;                         // 0 .. NPAN: MFMAs of panel pn, dequantisation of pn + 1, staging of pn - 1 (lag) or pn
+                if constexpr (pn < NPAN && TQ > 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < TQ; ++kk) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const int slot = kk * NB + b;
+                            tail_mma(pn * PJ + b / WNB, b % WNB, wo2[kk][b % WNB], xo2[kk][b / WNB]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (pn + 1 < NPAN && slot % TQ == 0) {
+                                const int d = slot / TQ, j2 = (pn + 1) * PJ + d / WNB, i2 = d % WNB;
+                                deq(pn + 1, d);
+                                asm volatile("" : "+v"(fa[j2][i2]));
+                            }
+                            if constexpr (LAGOK && pn >= 1) {
+                                // block column c of panel pn - 1 behind slot (2 c + 1) SLOTS / (2 WNB): spread over the panel's MFMAs
+#pragma unroll
+                                for (int c = 0; c < WNB; ++c)
+                                    if (slot == ((2 * c + 1) * SLOTS) / (2 * WNB)) { if (lag) finish_col(std::false_type{}, std::true_type{}, pn - 1, c); }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
+                        if constexpr (pn + 1 < NPAN) xo_read(pn + 1, kk);         // (this k-step's fragments are consumed: the next panel's, in flight under what follows)
                     }
-                    stamp(7);
+                    extra_ksteps(pn);
+                } else if constexpr (pn < NPAN) {
+                    if constexpr (pn + 1 < NPAN) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) deq(pn + 1, b);
+                    }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // ds_write is asynchronous; s_barrier does not wait for it
-                __builtin_amdgcn_s_barrier();                                    // panel staged: the loaders (the last one: everybody) copy it out
+                if (lag) {
+                    if constexpr (pn >= 1) {
+                        if constexpr (pn == NPAN) {                              // the last panel: nothing left to hide under
+#pragma unroll
+                            for (int c = 0; c < WNB; ++c) finish_col(std::false_type{}, std::true_type{}, pn - 1, c);
+                        }
+                        stamp2(2 * (pn - 1), 0);
+                        if constexpr (pn - 1 < LP) raise_flag(pn - 1);
+                    }
+                } else {
+                    if constexpr (pn < NPAN) {
+                        // (straight-line code per case: the optional terms and the unstaged stores are compile-time switches of finish_col)
+                        if (staged && !opt) {
+#pragma unroll
+                            for (int c = 0; c < WNB; ++c) finish_col(std::false_type{}, std::true_type{}, pn, c);
+                        } else if (staged) {
+#pragma unroll
+                            for (int c = 0; c < WNB; ++c) finish_col(std::true_type{}, std::true_type{}, pn, c);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < WNB; ++c) finish_col(std::true_type{}, std::false_type{}, pn, c);
+                        }
+                        stamp2(2 * pn, 0);
+                        if constexpr (pn < LP) raise_flag(pn);
+                    }
+                }
             });
+            if (has_amax) {                                                      // one slot per (wave, lane group, row): no atomics, no initialisation
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    const uint32_t lo = rmax[j] & 0xffffu, hi = rmax[j] >> 16;
+                    *reinterpret_cast<uint32_t*>(lds + AMAX_OFF + ((wave * 4 + lq) * BM + j * 16 + lm) * 4) = lo > hi ? lo : hi;
+                }
+            }
+            stamp(7);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // ds_write is asynchronous; s_barrier does not wait for it
+            __builtin_amdgcn_s_barrier();                                        // every panel staged: what the loaders did not copy is shared by all waves
             stamp(3);
         } else {
         // fp16 outlier tail operands: 16 x 32 fragments, lane = row lm, columns kk*32 + lq*8 .. +8.  TD register sets: with two,
@@ -1436,13 +1507,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         if (m0 + tid < a.M) atomicMax(a.row_amax + m0 + tid, v);
     }
     if constexpr (EPI2) {
-        if constexpr (ABL == 61) {                                               // probe: EPI2's arithmetic with the first form's copy-out (everything at the end, by everybody)
-            if (staged) {
+        if (staged) {                                                 // (ABL 61, a probe: LP = 0 - everything here, as the first form)
 #pragma unroll
-                for (int p = 0; p < NPAN; ++p) copy_panel(p, std::integral_constant<int, NT>{}, voffA, loffA);
-            }
-        } else
-        if (staged) copy_panel(NPAN - 1, std::integral_constant<int, NT>{}, voffA, loffA);   // (the earlier panels left under the arithmetic)
+            for (int p = LP; p < NPAN; ++p) copy_panel(p, std::integral_constant<int, NT>{}, voffA, loffA);   // (the earlier panels left under the arithmetic)
+        }
     } else if (staged) {
         // all waves (loader included): 16 bytes per lane, 16 / 24 / 32 consecutive lanes cover one row segment of the tile.  Every
         // LDS read of a lane is issued before its first store, so the copy-out costs ONE LDS round trip, not one per 16 bytes.
@@ -1540,6 +1608,11 @@ const WrConfig g_wr[] = {
     { "wr128x192_f6_l4", 8, 3, 16, 4, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 4, 0>, 8 },            // four loader waves
     MIXQ_WR(8, 3, 16, 4, 2, 61, "128x192_p61_epi2_copy_at_end"),
     MIXQ_WR(8, 3, 16, 4, 2, 62, "128x192_p62_epi2_loaders_prio0"),
+    MIXQ_WR(8, 3, 16, 4, 2, 6, "128x192_abl6_no_kloop_barriers"),   // (timing probe: what the per-k-step barrier costs; results are garbage)
+    MIXQ_WR(8, 3, 16, 4, 2, 64, "128x192_p64_epi2_no_tail_mfma"),
+    MIXQ_WR(8, 3, 16, 4, 2, 65, "128x192_p65_epi2_no_staging_writes"),
+    MIXQ_WR(8, 3, 16, 4, 2, 66, "128x192_p66_epi2_no_scaling"),
+    MIXQ_WR(8, 3, 16, 4, 2, 67, "128x192_p67_epi2_loaders_copy_3_of_4"),
     MIXQ_WR(8, 3, 16, 4, 2, 60, "128x192_p60_epi1"),   // cfg 0 with the first form of the epilogue (round 3's): the A/B partner of EPI2
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic
@@ -1713,7 +1786,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
         a.ks_slots = static_cast<uint8_t*>(ws) + fb;
         units *= 2;
     }                                                  // (the prefill tiles have no nibble form, few tilings an FP6 form)
-    const size_t ring = bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 4 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
+    const size_t ring = (bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 4 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024) + 64 /* panel flags */, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
     const size_t shm = ring > stg ? ring : stg;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(units), dim3((WR_CW + g.loaders) * 64), shm, st, a);

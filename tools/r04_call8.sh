@@ -1,0 +1,11 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+cd $R
+python tools/ab_gemm.py --cfgs wr128x192_s16_d4_l2,wr128x192_p60_epi1,wr128x192_abl3_mfma > $O/r04h_ab.txt 2>&1
+WR=$(MIXQ_TUNING_LIB=1 python -c "
+from mixq_amd import _capi
+n=_capi.gemm_config_names()
+print(','.join(str(i) for i,x in enumerate(n) if x in ('wr128x192_s16_d4_l2',)))")
+python tools/trace_gemm.py --shapes 512x11008x4096 --cfgs $WR --nout 41 --panels > $O/r04h_trace.txt 2>&1
+cat $O/r04h_ab.txt $O/r04h_trace.txt

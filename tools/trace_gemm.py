@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nout", type=int, default=0, help="outlier columns (the fp16 MFMA tail of the epilogue)")
+    ap.add_argument("--panels", action="store_true", help="also print the panel pipeline of the epilogue (consumer wave 0 and loader wave 0 stamps)")
     ap.add_argument("--f6", action="store_true", help="bit 4 with both operands as FP6 codes (MIXQ_FMT_F6X128): the FP6-pipe form of the wr kernels")
     args = ap.parse_args()
     dev = "cuda"
@@ -44,7 +45,7 @@ def main():
             pad = (args.nout + 15) // 16 * 16
             xo = torch.randn((M, pad), device=dev).half()[:, :args.nout]
             wo = torch.randn((N, pad), device=dev).half()[:, :args.nout]
-        trace = torch.zeros(16 * 4096, dtype=torch.int64, device=dev)
+        trace = torch.zeros(2 * 16 * 4096, dtype=torch.int64, device=dev)
         for c in [int(v) if v.lstrip("-").isdigit() else names.index(v) for v in args.cfgs.split(",")]:
             assert lib.mixq_gemm_set_config(c) == 0
             qwp = qw_by_fmt[2 if names[c].startswith("wr") else 1]
@@ -58,8 +59,11 @@ def main():
                 trace.zero_()
                 run(); run()            # back to back: the second launch overwrites the first (steady-state clocks)
                 torch.cuda.synchronize()
-                t = trace.cpu().numpy().reshape(-1, 16)
-                t = t[t[:, 0] != 0].astype(np.float64)
+                full = trace.cpu().numpy()
+                t = full[:16 * 4096].reshape(-1, 16)
+                live = t[:, 0] != 0
+                t2 = full[16 * 4096:].reshape(-1, 16)[live].astype(np.float64)
+                t = t[live].astype(np.float64)
                 rows.append(t)
             lib.mixq_gemm_set_trace(None)
             t = rows[-1]
@@ -84,6 +88,15 @@ def main():
             for k, v in ph.items():
                 v = v / 100.0
                 print(f"  {k:22s} {v.min():7.2f} {np.median(v):7.2f} {np.percentile(v, 90):7.2f} {v.max():7.2f}")
+            if args.panels and t2[:, 0].any():
+                b1 = t[:, 6]                                   # consumer wave 0 past the epilogue's first barrier
+                print("  panel pipeline, microseconds after the first epilogue barrier (median): consumer wave 0 has staged the panel; loader wave 0 saw its flags / issued its copy")
+                for pn in range(4):
+                    line = f"    panel {pn}: staged {np.median(t2[:, 2 * pn] - b1) / 100:5.2f}"
+                    if t2[:, 9 + 2 * pn].any() and pn < 3:
+                        l0, l1 = np.median(t2[:, 9 + 2 * pn] - b1) / 100, np.median(t2[:, 10 + 2 * pn] - b1) / 100
+                        line += f"   loader: flags seen {l0:5.2f}  copy issued {l1:5.2f}"
+                    print(line)
         lib.mixq_gemm_set_config(-1)
 
 
