@@ -44,7 +44,6 @@ struct WrArgs {
     int ldxo, ldwo, n_out, lda, ldy, act;
     int tiles_m, tiles_n;
     int xblocks, wblocks;                             // 16-row blocks per k-step of each operand
-    int krot;                                         // k-step rotation between neighbouring N tiles (0: every tile starts at k = 0)
     int gm;                                           // M tiles per group of the tile order (see the tile map in the kernel)
     // reciprocals for the tile map's two divisions (q = mulhi(n, m), exact for n d < 2^32, m = floor(2^32 / d) + 1; 0 stands for d = 1):
     // by gm x tiles_n, by gm, by the last group's size - three run-time divisions (~25 dependent scalar instructions each, through the
@@ -151,6 +150,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // the memory system chokes on partial-line writes; full 384-byte row segments out of LDS are what it takes.)
     constexpr int LP = (SELF || NPAN < 3) ? 0 : (ABL == 61 ? 0 : (ABL == 67 ? NPAN - 1 : NPAN - 2));   // (NPAN - 1, probe 67: the consumers end up waiting for the loaders: 24.14 vs 23.94 us)
     constexpr int FLAG_OFF = TAILX + TQ * MB * 1024;     // LDS: "panel p staged by consumer wave w" words [NPAN][CW], behind the tail's X_out blocks
+    // EPI2: the epilogue's scales (x_scale of the tile's rows, scale_col and bias of its columns) do not ride through the k loop in the
+    // consumers' registers (20 VGPRs of the 128 x 192 tile, 14 requests and their address arithmetic in front of its second weight
+    // request): a loader wave brings them into LDS by 16-bit LDS-DMA - one dword slot per element, zero-extended; rows past M and columns
+    // past N read as zero through the buffer descriptor's range check - while the main loop runs, and the epilogue reads them from there.
+    constexpr int SX_OFF = FLAG_OFF + 64, SW_OFF = SX_OFF + BM * 4, BI_OFF = SW_OFF + BN * 4, SC_END = BI_OFF + BN * 4;
     constexpr bool EPI2 = !SELF && ABL != 50 && ABL != 60 && (MB % PJ == 0) &&
                           (((BM * OPITCH + 15) & ~15) + WR_CW * 4 * BM * 4 <= TAILX);   // (the staged tile and the row-maximum slots stay clear of the tail's X_out blocks)
     static_assert(MB % ISSUERS == 0 && (STAGE_BYTES / 1024) % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
@@ -158,7 +162,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     static_assert(!F6R || ABL == 0, "the tuple-ring form has no ablations");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
     static_assert(!SELF || (LOOK == D + 1 && !I4 && ABL == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
-    static_assert(NSTAGE * STAGE_BYTES + TQ * MB * 1024 + 64 <= 160 * 1024, "X ring + tail blocks + panel flags must fit the 160 KiB of LDS");
+    static_assert(!EPI2 || SC_END <= 160 * 1024, "X ring + tail blocks + panel flags + scales must fit the 160 KiB of LDS");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (ABL == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
@@ -166,7 +170,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // one scalar load per use site with a wait behind each (nine dependent round trips to a cold scalar cache in front of the first
     // operand request: ~0.3 us of the 1.0 us between entry and the first k-step); named together here they become a few wide loads and ONE wait.
     asm volatile("" :: "s"(a.qx), "s"(a.qw), "s"(a.sx), "s"(a.sw), "s"(a.M), "s"(a.N), "s"(a.KB), "s"(a.tiles_m), "s"(a.tiles_n),
-                 "s"(a.xblocks), "s"(a.wblocks), "s"(a.krot), "s"(a.gm), "s"(a.n_out_dev), "s"(a.bias), "s"(a.n_out), "s"(a.mg_group), "s"(a.mg_gm),
+                 "s"(a.xblocks), "s"(a.wblocks), "s"(a.gm), "s"(a.n_out_dev), "s"(a.bias), "s"(a.n_out), "s"(a.mg_group), "s"(a.mg_gm),
                  "s"(a.mg_last), "s"(a.ldy), "s"(a.y));
     const bool staged = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
 
@@ -205,10 +209,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     const int nk_all = a.KB >> 6;
     const int kbeg = KS ? (kz ? nk_all >> 1 : 0) : 0;                            // this workgroup's k-steps: [kbeg, kbeg + nk)
     const int nk = KS ? (kz ? nk_all - (nk_all >> 1) : nk_all >> 1) : nk_all;
-    // Integer accumulation is exact in any order, so a tile may walk K from any starting k-step and wrap around.  Tiles of one
-    // weight panel (same tn) start together - they share the panel's bytes in their XCD's L2 - while neighbouring panels start
-    // krot k-steps apart, so the CUs of an XCD are not all asking the L2 for the same activation slab at the same moment.
-    const int rot = (a.krot && nk > 1) ? (tn * a.krot) % nk : 0;                 // (the division only when a rotation was asked for)
+    // (Rounds 1-2 could start neighbouring weight panels a few k-steps apart - integer accumulation is exact in any order - to keep the CUs of
+    // an XCD from asking for the same activation slab at the same moment: it never changed a timing and cost two scalar counters per wave; removed.)
     auto stamp = [&](int slot) MIXQ_INL {                         // diagnostics (mixq_gemm_set_trace): tools build only
 #ifdef MIXQ_TUNING
         if (a.trace && tid == 0) {
@@ -301,8 +303,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
             for (int i = 0; i < LOADS; ++i) src[i] += static_cast<size_t>(kbeg) * xks;
         }
-        int xk = rot;                                    // k-step the next stage reads
-        size_t xoff = static_cast<size_t>(rot) * xks;
+        size_t xoff = 0;                                 // byte offset of the k-step the next stage reads
         auto stage = [&](int slot) MIXQ_INL {
             if constexpr (ABL != 2 && ABL != 3) {
 #pragma unroll
@@ -313,7 +314,6 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 }
             }
             xoff += xks;
-            if (++xk == nk) { xk = 0; xoff = 0; }
         };
         // Deep rings start with a RAMP: all 232 workgroups asking for LOOK stages at once (14 x 8 KiB each at the metric tile) puts
         // 26 MB of requests in front of everybody's first stage.  RP stages are requested up front, then two per k-step until the
@@ -354,6 +354,25 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // behind the ring - instead of being fetched from L2 by each wave (4 x 8 KiB per tail k-step: as much traffic as two
         // k-steps of the main loop, 0.6 us of a 27 us launch at 41 outlier columns).  Requested HERE, when the last X stage has been
         // issued and LOOK k-steps of the main loop are still to run, so it has landed long before the consumers reach the epilogue.
+        if constexpr (EPI2) {
+            // the scales into LDS (see SX_OFF): behind the last X stage's requests, every wait from here on is vmcnt(0)
+            if (lw == 0) {
+                const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.sx) + m0, 0, (a.M - m0) * 2, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.sw) + n0, 0, (a.N - n0) * 2, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < (BM + 63) / 64; ++q)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(lds + SX_OFF + q * 256), 2, (q * 64 + lane) * 2, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < (BN + 63) / 64; ++q)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(lds + SW_OFF + q * 256), 2, (q * 64 + lane) * 2, 0, 0, 0);
+                if (a.bias) {
+                    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.bias) + n0, 0, (a.N - n0) * 2, 0x00020000);
+#pragma unroll
+                    for (int q = 0; q < (BN + 63) / 64; ++q)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)(lds + BI_OFF + q * 256), 2, (q * 64 + lane) * 2, 0, 0, 0);
+                }
+            }
+        }
         if (a.xo && a.wo) {
             int n_out_l = a.n_out;
             if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out_l = nd < n_out_l ? nd : n_out_l; }
@@ -478,11 +497,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
             for (int i = 0; i < WNB; ++i) wb[i] += static_cast<size_t>(kbeg) * wks;
         }
-        int wk = rot;                                    // k-step the next weight loads read
-        size_t woff = static_cast<size_t>(rot) * wks;
+        size_t woff = 0;                                 // byte offset of the k-step the next weight loads read
         i32x6 wr6[F6R ? D + 1 : 1][F6R ? WNB : 1];                               // F6R: the weight ring as operand tuples (D + 1 slots, as wq below)
+        // WRAP forms request on EVERY k-step; once the tile's last k-step has been requested the surplus requests REPEAT it (valid, never
+        // consumed, and the lines are L1 / L2-hot: round 3 wrapped around to the tile's first k-steps instead - 3 MB of long-evicted weight
+        // blocks re-fetched per launch, counter traffic 1.42x the algorithmic bytes, and a drain behind the loop that waited for them)
+        int wleft = nk;                                  // k-steps not requested yet
         auto wadvance = [&](int cond) MIXQ_INL {                    // once per requested k-step (cond: wave-uniform 0 / 1; F6R requests always)
-            if (WRAP || cond) { woff += wks; if (++wk == nk) { wk = 0; woff = 0; } }
+            if constexpr (WRAP) { if (--wleft > 0) woff += wks; }
+            else if (cond) woff += wks;
         };
         auto wload6 = [&](auto d_c, int i) MIXQ_INL {               // F6R: fragment i of the k-step at woff -> tuple i of ring slot d
             constexpr int d = decltype(d_c)::value;
@@ -860,8 +883,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 xdst[i] = p * 1024;
             }
             const size_t xks = static_cast<size_t>(a.xblocks) * 1024;
-            int xkq = rot;
-            size_t xoff_g = static_cast<size_t>(rot) * xks;
+            int xkq = 0;
+            size_t xoff_g = 0;
             auto xpiece = [&](int slot, int i) MIXQ_INL { wr_glds16(xsrc[i] + xoff_g, lds + slot * STAGE_BYTES + xdst[i]); };
             auto xadvance = [&]() MIXQ_INL { xoff_g += xks; if (++xkq == nk) { xkq = 0; xoff_g = 0; } };
             constexpr int INFLIGHT = (D - 1) * (WNB + LOADS);
@@ -934,7 +957,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // vmcnt retires in order and k-step 0's wait leaves WL (D - 1) requests in flight - exactly the k-steps 1 .. D-1 issued behind
         // the scales - so the scales have landed with k-step 0 and never sit among the requests a later wait counts.
         prologue_w(std::integral_constant<int, 0>{});
-        load_scales();
+        if constexpr (!EPI2) load_scales();                                      // (EPI2: the scales travel through LDS, brought by a loader wave)
         wr_static_for<1, D>(prologue_w);
         zero_acc();
         static_assert(D >= 2 && D <= 16 && WL * (D - 1) < 64, "weight ring depth: run-time wait table / vmcnt range");
@@ -1067,13 +1090,23 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): see the first form
 #pragma unroll
             for (int kk = 0; kk < TQ; ++kk) wo_load(kk, wo2[kk]);
-#pragma unroll
-            for (int i = 0; i < WNB; ++i) unpack4(swp[i], swv[i]);
-#pragma unroll
-            for (int j = 0; j < MB; ++j) sxv[j] = h2f(sxh[j]) * PRE;
             copy_setup(tid, std::integral_constant<int, NT>{}, voffA, loffA);     // (this thread's share of the last panel's copy-out)
             __builtin_amdgcn_s_barrier();                                        // every wave is done reading the ring; X_out blocks landed and fixed up
             stamp(6);
+            {   // the scales, from the dword slots the loader's LDS-DMA filled (landed: its vmcnt(0) in front of the barrier)
+                u32x4 swr[WNB];
+                uint32_t sxr[MB];
+#pragma unroll
+                for (int i = 0; i < WNB; ++i) swr[i] = *reinterpret_cast<const u32x4*>(lds + SW_OFF + (wave * WN + i * 16 + lq * 4) * 4);
+#pragma unroll
+                for (int j = 0; j < MB; ++j) sxr[j] = *reinterpret_cast<const uint32_t*>(lds + SX_OFF + (j * 16 + lm) * 4);
+#pragma unroll
+                for (int i = 0; i < WNB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) swv[i][r] = h2f(static_cast<uint16_t>(swr[i][r]));
+#pragma unroll
+                for (int j = 0; j < MB; ++j) sxv[j] = h2f(static_cast<uint16_t>(sxr[j])) * PRE;
+            }
             // columns >= n_out in the WEIGHT fragments (the pad of weight_cache may hold anything); the X_out blocks were cleaned in LDS by the loaders
 #pragma unroll
             for (int kk = 0; kk < TQ; ++kk) {
@@ -1103,12 +1136,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 const int nc = n < a.N ? n : a.N - 4;
                 float bv[4];
                 if (OPT && has_bias) {
-                    if constexpr (PREBIAS) unpack4(bvp[i], bv);
-                    else unpack4(*reinterpret_cast<const u32x2_u*>(a.bias + nc), bv);
+                    const u32x4 br = *reinterpret_cast<const u32x4*>(lds + BI_OFF + nloc * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = h2f(static_cast<uint16_t>(br[r]));
                 }
                 uint32_t keep_lo = 0x7fff7fffu, keep_hi = 0x7fff7fffu;            // |.| of the 4 halves; the next layer's outlier columns drop out
                 if (OPT && has_amax) {
-                    // (columns past N are computed from clamped operands - values that exist nowhere in y - and count for nothing)
+                    // (columns past N are computed from zero scales - values that exist nowhere in y - and count for nothing)
                     const uint32_t mb = n >= a.N ? 0xfu : (a.amax_mask ? (a.amax_mask[nc >> 5] >> (nc & 31)) & 0xfu : 0u);
                     if (mb & 1u) keep_lo &= 0xffff0000u;
                     if (mb & 2u) keep_lo &= 0x0000ffffu;
@@ -1761,7 +1795,6 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     const int bm = g.mb * 16, bn = g.wnb * 64;
     a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, bn);
     a.xblocks = (M + 15) >> 4; a.wblocks = (N + 15) >> 4;
-    a.krot = g_wr_krot & 0xffff;
     {
         const int forced_gm = g_wr_krot >> 16;                               // (tuning build: mixq_gemm_set_krot(gm << 16 | krot); 0 = automatic)
         a.gm = forced_gm > 0 ? forced_gm : (a.tiles_m <= 8 ? a.tiles_m : 8);
@@ -1786,7 +1819,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
         a.ks_slots = static_cast<uint8_t*>(ws) + fb;
         units *= 2;
     }                                                  // (the prefill tiles have no nibble form, few tilings an FP6 form)
-    const size_t ring = (bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 4 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024) + 64 /* panel flags */, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
+    const size_t ring = (bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 4 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024) + 64 /* panel flags */ + static_cast<size_t>(bm) * 4 + static_cast<size_t>(bn) * 8 /* scales */, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
     const size_t shm = ring > stg ? ring : stg;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(units), dim3((WR_CW + g.loaders) * 64), shm, st, a);
