@@ -1665,6 +1665,8 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 31, "128x192_p31_r2order"),   // round 2's order: re-read and weight load in the same gap
     MIXQ_WR(8, 3, 16, 4, 2, 30, "128x192_p30_earlyreread"),
     MIXQ_WR(8, 3, 16, 5, 2, 0, "128x192_s16_d5_l2"),
+    MIXQ_WR8(8, 3, 16, 6, 2, "128x192_s16_d6_l2"),        // (deeper weight rings for the cold-weights protocol: tools/ab_gemm.py --cold 8)
+    MIXQ_WR8(8, 3, 12, 6, 2, "128x192_s12_d6_l2"),
     MIXQ_WR(8, 3, 16, 4, 4, 0, "128x192_s16_d4_l4"),
     MIXQ_WR(8, 3, 16, 4, 2, 25, "128x192_p25_w0first"),
     MIXQ_WR(8, 3, 16, 4, 2, 26, "128x192_p26_w0x0first"),

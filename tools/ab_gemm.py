@@ -19,6 +19,8 @@ ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--nout", type=int, default=41)
 ap.add_argument("--bit", type=int, default=8)
 ap.add_argument("--f6", action="store_true", help="bit 4 with both operands as FP6 codes (MIXQ_FMT_F6X128): the FP6-pipe form of the wr kernels")
+ap.add_argument("--cold", type=int, default=0, help="rotate the launches of a graph over this many copies of the weight image (8 x 45 MB > the 256 MB "
+                "memory-side cache: every launch streams its weights from HBM, as the layers of a model do); 0: one copy, resident after the first launch")
 ap.add_argument("--gms", default="0", help="comma list of M-tile group sizes of the weights-in-registers kernels' tile order (0 = automatic)")
 args = ap.parse_args()
 dev = "cuda"
@@ -39,6 +41,8 @@ sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
 sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
 xp = mixlib.PackOperand(qx, 4 if args.f6 else 1)
 wp = {1: mixlib.PackOperand(qw, 1), 2: mixlib.PackOperand(qw, 3 if args.f6 else 2)}
+ncopy = max(1, args.cold)
+wcopies = {k: [v] + [mixlib.set_fmt(v.clone(), mixlib.fmt_of(v)) for _ in range(ncopy - 1)] for k, v in wp.items()}
 xo = wo = None
 if args.nout:
     pad = (args.nout + 15) // 16 * 16
@@ -58,14 +62,15 @@ with torch.cuda.stream(side):
         if gm:
             nm = f"{nm}_gm{gm}"
         xa = xp if (nm.startswith("wr") or not args.f6) else mixlib.PackOperand(qx, 1)     # (the LDS-staged kernels take nibbles in P16X64)
-        run = lambda xa=xa, w=w: mixlib.FusedLinear(xa, w, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
+        ws = wcopies[2 if nm.startswith("wr") else 1]
+        run = lambda i=0, xa=xa, ws=ws: mixlib.FusedLinear(xa, ws[i % len(ws)], sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr, stream=side):
-            for _ in range(args.launches):
-                run()
+            for i in range(args.launches):
+                run(i)
         torch.cuda.synchronize()
         graphs.append((nm, gr))
     lib.mixq_gemm_set_config(-1)
@@ -79,7 +84,7 @@ with torch.cuda.stream(side):
             if r >= 2:
                 times[nm].append(e0.elapsed_time(e1) * 1e3 / args.launches)
 flops = 2.0 * M * N * K
-print(f"{args.shape} bit={args.bit} n_out={args.nout}: {args.rounds} interleaved rounds x {args.launches} launches; us per launch median / min / max")
+print(f"{args.shape} bit={args.bit} n_out={args.nout}{' COLD weights (' + str(ncopy) + ' copies in rotation)' if ncopy > 1 else ''}: {args.rounds} interleaved rounds x {args.launches} launches; us per launch median / min / max")
 for nm, _ in graphs:
     t = np.array(times[nm])
     print(f"  {nm:28s} {np.median(t):7.2f} {t.min():7.2f} {t.max():7.2f}   {flops / np.median(t) / 1e6:7.1f} TOPS ({100 * flops / np.median(t) / 1e6 / 5033:4.1f} %)", flush=True)

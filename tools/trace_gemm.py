@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nout", type=int, default=0, help="outlier columns (the fp16 MFMA tail of the epilogue)")
+    ap.add_argument("--cold", type=int, default=0, help="rotate over this many copies of the weight image (8 x 45 MB > 256 MB memory-side cache): the traced launch streams its weights from HBM")
     ap.add_argument("--panels", action="store_true", help="also print the panel pipeline of the epilogue (consumer wave 0 and loader wave 0 stamps)")
     ap.add_argument("--f6", action="store_true", help="bit 4 with both operands as FP6 codes (MIXQ_FMT_F6X128): the FP6-pipe form of the wr kernels")
     args = ap.parse_args()
@@ -49,7 +50,11 @@ def main():
         for c in [int(v) if v.lstrip("-").isdigit() else names.index(v) for v in args.cfgs.split(",")]:
             assert lib.mixq_gemm_set_config(c) == 0
             qwp = qw_by_fmt[2 if names[c].startswith("wr") else 1]
-            run = lambda: mixlib.FusedLinear(qxp, qwp, sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
+            copies = [qwp] + [mixlib.set_fmt(qwp.clone(), mixlib.fmt_of(qwp)) for _ in range(max(1, args.cold) - 1)]
+            state = {"i": 0}
+            def run():
+                state["i"] += 1
+                return mixlib.FusedLinear(qxp, copies[state["i"] % len(copies)], sx, sw, xo, wo, args.nout, None, M, N, K, bit=args.bit, out=out)
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
@@ -57,7 +62,8 @@ def main():
             rows = []
             for _ in range(args.reps):
                 trace.zero_()
-                run(); run()            # back to back: the second launch overwrites the first (steady-state clocks)
+                for _ in range(2 if not args.cold else 2 * len(copies)):
+                    run()               # back to back: the last launch overwrites the earlier ones (steady-state clocks)
                 torch.cuda.synchronize()
                 full = trace.cpu().numpy()
                 t = full[:16 * 4096].reshape(-1, 16)
@@ -83,7 +89,7 @@ def main():
             }
             mhz = (t[:, 10] - t[:, 9]) / ((t[:, 2] - t[:, 1]) / 100.0)
             cyc = np.median(t[:, 10] - t[:, 9]) / (K if args.bit == 8 else K // 2) * 64
-            print(f"{shp} bit={args.bit} n_out={args.nout} cfg{c} {names[c]}: {t.shape[0]} workgroups; s_memtime ticks per us in the k loop: "
+            print(f"{shp} bit={args.bit} n_out={args.nout}{' COLD weights' if args.cold else ''} cfg{c} {names[c]}: {t.shape[0]} workgroups; s_memtime ticks per us in the k loop: "
                   f"{np.median(mhz):.0f} ({cyc:.0f} shader cycles per 64-byte k-step); microseconds min / median / p90 / max")
             for k, v in ph.items():
                 v = v / 100.0
