@@ -130,7 +130,68 @@ def _gemm_ready(t: Tensor | None) -> Tensor | None:
     return buf[:, :n]
 
 
+class _Derived:
+    """Everything a layer DERIVES from its state (weights, `ind`, `weight_cache`, device) and keeps between forwards, in one place:
+
+      wpk / wpk_small   the packed weight image(s) the GEMM streams (after compaction `wpk` is the layer's ONLY copy of the weights)
+      wo_ready          `weight_cache` in the GEMM tail's padded layout
+      ind_buf, n_dev    `ind` padded to a capacity + the live count in device memory
+      cmask             bit-per-input-column mask of `ind` (a producer's row-maximum side output)
+      amax_buf          int32 row maxima left by the GEMM that produced this layer's input; allocated ONCE at the cache's row capacity
+      plan(s)           kept argument blocks of the one-call forward (raw device addresses of everything above)
+
+    Each derived item carries the identity (`id`, `data_ptr`, `_version`) of what it was made from and is rebuilt when that changes;
+    `invalidate` is the single place that drops them - and every call of it drops the kept argument blocks, which hold addresses of
+    all the others."""
+
+    __slots__ = ("wpk", "wpk_key", "wpk_small", "wpk_small_key", "wo_ready", "wo_key", "ind_buf", "ind_key", "n_dev", "n_dev_host",
+                 "cmask", "cmask_key", "amax_buf", "amax_dirty", "plan", "plan_key", "plans", "retired")
+
+    def __init__(self):
+        self.wpk = self.wpk_key = self.wpk_small = self.wpk_small_key = None
+        self.wo_ready = self.wo_key = self.ind_buf = self.ind_key = None
+        self.n_dev, self.n_dev_host = None, -1
+        self.cmask = self.cmask_key = None
+        self.amax_buf, self.amax_dirty = None, False
+        self.plan = self.plan_key = None
+        self.plans = {}
+        self.retired = []                     # superseded device buffers a captured graph may still address: kept alive, never re-used
+
+    def invalidate(self, weights=False, outliers=False, device=False):
+        """weights: the weight bytes or their layout changed (checkpoint load into a compacted layer); outliers: `ind` / `weight_cache`
+        were replaced; device: the module moved.  The kept argument blocks go in every case."""
+        self.plan = self.plan_key = None
+        self.plans = {}
+        if weights or device:
+            if weights:
+                self.wpk = None
+            self.wpk_key = None
+            self.wpk_small = self.wpk_small_key = None
+        if outliers or device:
+            self.wo_ready = self.wo_key = None
+            self.ind_buf = self.ind_key = None
+            self.cmask = self.cmask_key = None
+        if device:
+            self.n_dev, self.n_dev_host = None, -1
+            self.amax_buf, self.amax_dirty = None, False
+            self.retired = []
+
+
+def _derived_attr(name):
+    """The pre-round-4 attribute names (`layer._wpk`, `layer._plan`, ...) as views of the record: tests and tools read them."""
+    return property(lambda self: getattr(self._d, name), lambda self, v: setattr(self._d, name, v))
+
+
 class MixLinear_GEMM(nn.Module):
+    _wpk, _wpk_key = _derived_attr("wpk"), _derived_attr("wpk_key")
+    _wpk_small, _wpk_small_key = _derived_attr("wpk_small"), _derived_attr("wpk_small_key")
+    _wo_ready, _wo_key = _derived_attr("wo_ready"), _derived_attr("wo_key")
+    _ind_buf, _ind_key = _derived_attr("ind_buf"), _derived_attr("ind_key")
+    _n_dev, _n_dev_host = _derived_attr("n_dev"), _derived_attr("n_dev_host")
+    _cmask, _cmask_key = _derived_attr("cmask"), _derived_attr("cmask_key")
+    _amax_buf, _amax_dirty = _derived_attr("amax_buf"), _derived_attr("amax_dirty")
+    _plan, _plan_key, _plans = _derived_attr("plan"), _derived_attr("plan_key"), _derived_attr("plans")
+
     def __init__(self, in_features, out_features, bias, dev, bit, weight_only=False, cache=None, fp_features_num=128,
                  name=None):
         super().__init__()
@@ -178,24 +239,8 @@ class MixLinear_GEMM(nn.Module):
         self.arch = "gfx950"
         self.name = name
         self._wstore = None          # _ColStore behind weight_cache once outliers were appended online
-        self._wpk = None             # q_weight re-tiled to PACK_FMT (built once, on the first forward)
-        self._wpk_key = None
-        self._wpk_small = None       # 4-bit layers: the nibble image small batches stream (SMALL_BATCH_M4), built when one arrives
-        self._wpk_small_key = None
-        self._wo_ready = None        # weight_cache in the GEMM tail's padded layout (built when it is not already)
-        self._wo_key = None
-        self._ind_buf = None         # `ind` padded to a multiple of 16 entries: the capacity the kernels are given
-        self._ind_key = None
-        self._n_dev = None           # int32[1] on the device: the live outlier count (kernel.py:108-111 reads K this way)
-        self._n_dev_host = -1
         self._silu_calls = 0
-        self._plan = None            # argument block of the one-call forward of the frozen layer (mixq_linear_forward)
-        self._plan_key = None
-        self._plans = {}             # ... the last few of them by key: a server alternates prefill and decode batch sizes
-        self._cmask = None           # bit-per-input-column mask of `ind` (int32 words) for a producer's row-maximum side output
-        self._cmask_key = None
-        self._amax_buf = None        # int32 [M]: this layer's row maxima as left by the GEMM that produced its input
-        self._amax_dirty = False     # written by a producer and not yet consumed (and cleared) by this layer's quantiser
+        object.__setattr__(self, "_d", _Derived())   # every derived, rebuildable item (packed images, padded operands, kept argument blocks)
 
     # ------------------------------------------------------------------------------------------------------
     @classmethod
@@ -275,7 +320,7 @@ class MixLinear_GEMM(nn.Module):
         if name == "q_weight":
             d = self.__dict__
             bufs = d.get("_buffers")
-            if bufs is not None and "q_weight" in bufs and bufs["q_weight"] is None and d.get("_wpk") is not None:
+            if bufs is not None and "q_weight" in bufs and bufs["q_weight"] is None and "_d" in d and d["_d"].wpk is not None:
                 return self._plain_weight()
         return super().__getattr__(name)
 
@@ -319,33 +364,39 @@ class MixLinear_GEMM(nn.Module):
                     state_dict = {k: v for k, v in state_dict.items() if k != key}
                 else:
                     self._buffers["q_weight"] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self._wpk.device)
-                    self._wpk, self._wpk_key = None, None                # re-packed on the next forward
-                    self._wpk_small, self._wpk_small_key = None, None
-                    self._plan, self._plan_key, self._plans = None, None, {}     # (kept plans pin the old images)
+                    self._d.invalidate(weights=True)                     # re-packed on the next forward; kept plans pin the old images
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def _apply(self, fn, *args, **kwargs):
         """nn.Module.to / .cuda / .half walk parameters and buffers only; after compaction the weights live in `_wpk` (a plain
         attribute), so the packed image follows the module here and everything derived from the old tensors is rebuilt."""
+        d = self._d
+        captured = [pl for pl in d.plans.values() if getattr(pl, "captured", False)]
+        if captured and not getattr(self, "allow_move_after_capture", False):
+            here = captured[0].device
+            if fn(torch.empty(0, device=here)).device != here:
+                # a hipGraph captured through this layer replays raw addresses of the weight image, the outlier operands and the device
+                # count ON THIS DEVICE; moving the module frees them, and nothing can stop the graph from being replayed afterwards.
+                raise RuntimeError("MixLinear_GEMM: this layer ran under hipGraph capture; moving it to another device would leave that graph "
+                                   "with dangling addresses.  Drop the graph first, then set layer.allow_move_after_capture = True (re-capture "
+                                   "after the move).")
         out = super()._apply(fn, *args, **kwargs)
-        if self.__dict__.get("_wpk") is not None:
-            moved = fn(self._wpk)
-            if moved is not self._wpk:
-                tag = _fmt_of(self._wpk)
+        if d.wpk is not None:
+            moved = fn(d.wpk)
+            if moved is not d.wpk:
+                tag = _fmt_of(d.wpk)
                 if hasattr(_backend, "set_fmt"):
                     _backend.set_fmt(moved, tag)
-                self._wpk = moved
-        self._wpk_key = None                                             # (re-packed from q_weight when that buffer still exists)
-        self._wpk_small, self._wpk_small_key = None, None                # (rebuilt when a small batch arrives)
-        self._plan, self._plan_key, self._plans = None, None, {}         # (kept plans pin the old device's tensors)
+                d.wpk = moved
+        # everything else derived is rebuilt where the module now lives: the image is re-packed from q_weight when that buffer still
+        # exists, the small-batch image when such a batch arrives, and the kept argument blocks - which pin the OLD device's tensors and
+        # which a graph captured before the move may still replay (tests/test_gpu_round4.py) - are dropped
+        d.invalidate(device=True)
         if isinstance(self.__dict__.get("weight_cache"), Tensor):
             self.weight_cache = fn(self.weight_cache)                    # 8-bit layers keep it as a plain attribute (linear.py:42)
         if isinstance(self.__dict__.get("ind"), Tensor):
             self.ind = fn(self.ind)
         self._wstore = None
-        self._wo_ready = self._wo_key = None
-        self._ind_buf = self._ind_key = None
-        self._n_dev, self._n_dev_host = None, -1
         return out
 
     def x_fmt(self, M=None):
@@ -365,9 +416,13 @@ class MixLinear_GEMM(nn.Module):
         main = self._packed_weight()
         if main is None:
             return None
-        key = (id(main), main._version) if qw is None else (id(qw), qw.data_ptr(), qw._version)
+        # keyed on the MAIN image (which itself follows q_weight while that buffer exists): compaction drops q_weight but not the main
+        # image, so the nibble image - an address kept argument blocks and captured graphs hold - survives it
+        key = (id(main), main._version)
         if self._wpk_small is None or self._wpk_small_key != key:
             plain = qw if qw is not None else self._plain_weight()
+            if self._wpk_small is not None:
+                self._d.retired.append(self._wpk_small)
             self._wpk_small, self._wpk_small_key = _backend.PackOperand(plain, FMT_P16X64), key
         return self._wpk_small
 
@@ -433,9 +488,18 @@ class MixLinear_GEMM(nn.Module):
         layer cannot use it (outlier search still running, weight-only).  The buffer is zero when handed out."""
         if self.weight_only or self.add_outliers or not ONE_CALL_FORWARD or not hasattr(_backend, "amax_supported"):
             return None
-        if self._amax_buf is None or self._amax_buf.numel() < M or self._amax_buf.device != torch.device(device):
-            self._amax_buf = torch.zeros((max(M, 16),), dtype=torch.int32, device=device)
-            self._amax_dirty = False
+        d = self._d
+        # ONE buffer for the layer's lifetime on a device, sized for the largest batch the cache admits (x_scale has one row per
+        # token, Cache.py:8): a hipGraph captured at a small batch has this address baked into the producer's atomicMax and the
+        # quantiser's read-and-clear, so a later, larger eager batch must find the SAME buffer, not a re-allocation (ADVICE r03)
+        cap = max(int(self.cache.x_scale.numel()), 16) if self.cache is not None else max(M, 16)
+        if M > cap:
+            return None                                      # (more rows than the cache holds: that forward fails on x_scale anyway)
+        if d.amax_buf is None or d.amax_buf.device != torch.device(device) or d.amax_buf.numel() < cap:
+            if d.amax_buf is not None:
+                d.retired.append(d.amax_buf)                 # (a grown cache / another device: captured graphs may still address the old one)
+            d.amax_buf = torch.zeros((cap,), dtype=torch.int32, device=device)
+            d.amax_dirty = False
         if self._amax_dirty:
             self._amax_buf.zero_()                           # a producer ran and nobody consumed: start clean
         self._amax_dirty = True
@@ -486,7 +550,11 @@ class MixLinear_GEMM(nn.Module):
         """copy.deepcopy / pickle of a frozen layer: the kept argument block of the one-call forward is a ctypes structure full of device
         pointers - neither copyable nor meaningful in the copy, which builds its own on its first frozen forward."""
         state = dict(self.__dict__)
-        state["_plan"], state["_plan_key"], state["_plans"] = None, None, {}
+        d = _Derived()
+        for k in _Derived.__slots__:
+            setattr(d, k, getattr(self._d, k))
+        d.plan, d.plan_key, d.plans, d.retired = None, None, {}, []
+        state["_d"] = d
         return state
 
     # ---- frozen steady state: the whole forward behind ONE foreign call (include/mixq_hip.h: mixq_linear_forward) ------
@@ -502,9 +570,10 @@ class MixLinear_GEMM(nn.Module):
         if wc is None:
             wc = b.get("weight_cache")
         qw = b.get("q_weight")
-        return (M, inputs.stride(0), id(cache), id(cache.x_scale), id(ind), ind._version, id(d.get("_wpk")), id(d.get("_wpk_small")), id(qw),
+        dd = d["_d"]
+        return (M, inputs.stride(0), inputs.device, id(cache), id(cache.x_scale), id(ind), ind._version, id(dd.wpk), id(dd.wpk_small), id(qw),
                 -1 if qw is None else qw._version, id(wc), -1 if wc is None else wc._version, id(b.get("bias", d.get("bias"))),
-                id(b.get("scale_col")), PACK_FMT)
+                id(b.get("scale_col")), PACK_FMT, PACK_FMT4, SMALL_BATCH_M4)
 
     def _build_plan(self, cache, inputs, M):
         if not hasattr(_backend, "ForwardPlan") or M == 0 or inputs.dtype != torch.float16 or inputs.stride(1) != 1 \
@@ -539,6 +608,16 @@ class MixLinear_GEMM(nn.Module):
         if unfused and not self.add_outliers and self.weight_only is False and ONE_CALL_FORWARD:
             # prediction frozen: extract + quantise + GEMM enqueued by one C call on a kept argument block; bit-identical to the
             # route below (tests/test_gpu_round3.py::test_one_call_forward_is_bit_identical)
+            # The argument block takes x by ADDRESS: what the two-call route checked in QuantFused is checked here on every call - a
+            # kept block must not be replayed on a bf16 / fp32 tensor, another column count or a strided last dimension
+            if inputs.dtype != torch.float16:
+                raise RuntimeError("MixLinear_GEMM: x must be float16")
+            if inputs.shape[1] != self.in_features:
+                raise RuntimeError(f"MixLinear_GEMM: x has {inputs.shape[1]} columns, the layer {self.in_features} input features")
+            if inputs.stride(1) != 1 and M:
+                raise RuntimeError("mixq_amd.mixlib: x must be 2-D with a contiguous last dimension")
+            if not inputs.is_cuda and hasattr(_backend, "ForwardPlan"):
+                raise RuntimeError("mixq_amd.mixlib: expected a GPU (HIP) tensor; there is no CPU fallback")
             key = self._frozen_key(cache, inputs, M)
             if self._plan_key != key and key in self._plans:
                 self._plan, self._plan_key = self._plans[key], key       # (a batch size seen before, nothing else changed)

@@ -754,7 +754,7 @@ class ForwardPlan:
     a forward then costs three allocations, four pointer updates and ONE foreign call that enqueues the quantise pass and the
     GEMM (the steady state of linear.py:187-193 + :244-285).  Holds references to every tensor whose address it carries."""
 
-    __slots__ = ("args", "ref", "fn", "keep", "M", "N", "n", "ldxo", "q_shape", "q_dtype", "qfmt", "device")
+    __slots__ = ("args", "ref", "fn", "keep", "M", "N", "K", "ldx", "n", "ldxo", "q_shape", "q_dtype", "qfmt", "device", "lock", "captured")
 
     def __init__(self, M, N, K, bit, sigma, ldx, ind_buf, n, n_dev, x_scale, q_w, scale_col, w_out, bias, qfmt, act=ACT_NONE):
         import ctypes as C
@@ -778,24 +778,37 @@ class ForwardPlan:
         a.ldy = N
         self.args, self.ref, self.fn = a, C.byref(a), _capi.load().mixq_linear_forward
         self.keep = (ind_buf, n_dev, x_scale, q_w, scale_col, w_out, bias)
-        self.M, self.N, self.n, self.qfmt, self.device = M, N, n, qfmt, x_scale.device
+        self.M, self.N, self.K, self.ldx, self.n, self.qfmt, self.device = M, N, K, ldx, n, qfmt, x_scale.device
+        import threading
+        self.lock = threading.Lock()                   # (the argument block is ONE structure: filled and handed over under the lock, see run)
+        self.captured = False                          # ran under hipGraph capture: a graph out there replays the addresses this plan carries
         self.q_shape, self.q_dtype = (packed_rows(M) if qfmt else M, _q_row_bytes(K, bit, qfmt)), (torch.int8 if bit == 8 else torch.uint8)
 
     def run(self, x, row_amax=None, col_mask=None):
         """x: fp16 [M,K] with the row stride the plan was built for.  Returns (y [M,N], q_x, x_out [M,n] or None).
         row_amax (int32 [>= M] on the device): the rows' masked maxima left by the GEMM that produced x (FusedLinear(row_amax=...));
         the quantise pass is then the one-pass known-maximum kernel, which also clears the buffer."""
-        a = self.args
-        a.row_amax, a.col_mask = _ptr(row_amax), _ptr(col_mask)
         dev = self.device
+        # the block carries x by address: the same checks on every call as the two-call route's QuantFused
+        if x.device != dev:
+            raise RuntimeError(f"ForwardPlan: x lives on {x.device}, the plan was built for {dev}")
+        if x.dtype != torch.float16 or x.dim() != 2 or x.shape[0] != self.M or x.shape[1] != self.K or x.stride(1) != 1 or x.stride(0) != self.ldx:
+            raise RuntimeError(f"ForwardPlan: x must be float16 [{self.M}, {self.K}] with row stride {self.ldx} and a contiguous last dimension "
+                               f"(got {x.dtype} {tuple(x.shape)} strides {tuple(x.stride())})")
         q = torch.empty(self.q_shape, dtype=self.q_dtype, device=dev)
         y = torch.empty((self.M, self.N), dtype=torch.float16, device=dev)
-        xo = None
-        if self.ldxo:
-            xo = torch.empty((self.M, self.ldxo), dtype=torch.float16, device=dev)
-            a.x_out = xo.data_ptr()
-        a.x, a.q_x, a.y = x.data_ptr(), q.data_ptr(), y.data_ptr()
-        rc = self.fn(self.ref, torch.cuda.current_stream(dev).cuda_stream)
+        xo = torch.empty((self.M, self.ldxo), dtype=torch.float16, device=dev) if self.ldxo else None
+        if not self.captured and torch.cuda.is_current_stream_capturing():
+            self.captured = True
+        a = self.args
+        # ONE structure per plan and a foreign call that releases the GIL: two threads (or two streams driven from two threads) running
+        # the same frozen layer must not interleave "fill" and "launch" - the C side reads the block before it returns (ADVICE r03)
+        with self.lock:
+            a.row_amax, a.col_mask = _ptr(row_amax), _ptr(col_mask)
+            if xo is not None:
+                a.x_out = xo.data_ptr()
+            a.x, a.q_x, a.y = x.data_ptr(), q.data_ptr(), y.data_ptr()
+            rc = self.fn(self.ref, torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
             raise _capi.MixqError("mixq_linear_forward", rc)
         q._mixq_fmt = self.qfmt
