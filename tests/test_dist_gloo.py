@@ -94,6 +94,23 @@ def test_bench_launches_its_own_ranks_dry_run(scaling):
     assert out["value"] == pytest.approx(total / 1.1e-3 / 1e12, rel=1e-3)
 
 
+def test_config3_scale_command_rehearsed_two_ranks_strong_70b_shape():
+    """BASELINE config 3's exact SCALE command form (Llama-2-70b up_proj 8192 -> 28672, one 512-token batch split over the ranks) rehearsed
+    on CPU: `bench.py --gpus 2 --shape 8192,28672 --scaling strong` self-launches its two ranks over gloo, each takes 256 rows of the ONE
+    batch (no data-path collective: rows are independent), one all_gather of the counters, rank 0 prints the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MIXQ_BENCH_CHILD")}
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--shape", "8192,28672", "--scaling", "strong", "--steps", "4", env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 4 and out["dry_run"] is True
+    assert out["config"]["K"] == 8192 and out["config"]["N"] == 28672 and out["config"]["M"] == 512
+    assert out["rows_per_rank"] == 256 and out["per_rank_ms"] == [1.0, 1.1]
+    total = 2.0 * 512 * 28672 * 8192 * 4                                  # ONE batch per step however many ranks share it
+    assert out["value"] == pytest.approx(total / 1.1e-3 / 1e12, rel=1e-3)
+
+
 def test_bench_dry_run_under_an_external_launcher_shape_flag():
     """The torch.distributed.run form: WORLD_SIZE already equals --gpus, so bench.py must NOT spawn again.  World size 1 here
     (a second level of processes is what the test above covers); --shape / --batch reach the job description."""
