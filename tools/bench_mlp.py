@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP, fused  # noqa: E402
+import bench  # noqa: E402  (the measurement protocol)
 
 M, H, F = 512, 4096, 11008
 dev = "cuda"
@@ -53,10 +54,8 @@ for fused_mul, amax in ((False, False), (True, False), (True, True)):
             for i in range(steps):
                 block(xs[i], fused_mul)
         torch.cuda.synchronize()
-        gr.replay(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        gr.replay(); torch.cuda.synchronize()
-        us = (time.perf_counter() - t0) * 1e6 / steps
+        ms, first_ms, _ = bench.conditioned_replay(gr, side, restore=lambda: xs.copy_(base.unsqueeze(0).expand_as(xs)))
+        us = ms * 1e3 / steps
     flops = 2.0 * M * (2 * H * F + F * H)
     print(f"norm + MLP block, gate*up {'in the gate epilogue' if fused_mul else 'as a separate pass'}{', down_proj row maxima from the same epilogue' if amax else ''}: {us:7.1f} us  "
-          f"({flops / us / 1e6:6.0f} effective TFLOPS)")
+          f"({flops / us / 1e6:6.0f} effective TFLOPS; first replay {first_ms * 1e3 / steps:7.1f} us)")

@@ -4,11 +4,12 @@
   warm-up calls    wall time of forward 1 (discovers the outlier columns: detection, weight-column dequantisation, re-quantise; host
                    syncs) and forward 2 (freezes), eager;
   misprediction    a NEW outlier column appears at call 2 (the reference's cache.stop = 2 still lets it in): wall time of that call.
-Prints microseconds; -> profiles/r03_secondary_timings.txt"""
+Prints microseconds; -> profiles/r04_secondary_timings.txt"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mixq_amd import MixLibCache, MixLinear_GEMM
+import bench  # the measurement protocol (clock conditioning in front of the timed replay)
 
 M, K, N = 512, 4096, 11008
 dev = "cuda"
@@ -30,11 +31,9 @@ def graph_time(layer, steps=100):
             for i in range(steps):
                 layer(xs[i], None, True)
         torch.cuda.synchronize()
-        g.replay(); torch.cuda.synchronize()
-        xs.copy_(base.to(dev).unsqueeze(0).expand_as(xs)); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(side); g.replay(); e1.record(side); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / steps
+        bd = base.to(dev)
+        ms, _, _ = bench.conditioned_replay(g, side, restore=lambda: xs.copy_(bd.unsqueeze(0).expand_as(xs)))
+    return ms * 1e3 / steps
 
 
 def wall(fn):
