@@ -247,14 +247,15 @@ def cpu_baseline(rows):
                       f"(sweep over threads: " + ", ".join(f"{c}: {results[c][0]:.3f}" for c in cands) + f" TFLOPS; {logical} logical CPUs)"}
 
 
-def hbm_traffic_from_profile():
-    """(HBM bytes per GEMM launch, source file) from the committed rocprofv3 PMC passes (profiles/*hbm_traffic.json), or (None, None).
-    The counters need their own rocprofv3 --pmc passes (tools/profile_bench.sh), so the bench line carries the committed figure."""
+def hbm_traffic_from_profile(tag=""):
+    """(HBM bytes per GEMM launch, source file) from the committed rocprofv3 PMC passes - the newest profiles/rNN_hbm_traffic<tag>.json -
+    or (None, None).  The counters need their own rocprofv3 --pmc passes (tools/r04_profile.sh), so the bench line carries the committed
+    figure of the same configuration (tag "" = the metric shape W8A8, "_w4a4", "_8192x28672")."""
     try:
         best = src = None
         pdir = os.path.join(ROOT, "profiles")
         for f in sorted(os.listdir(pdir)):
-            if f.endswith("hbm_traffic.json"):
+            if f.endswith(f"hbm_traffic{tag}.json"):
                 best, src = json.load(open(os.path.join(pdir, f))), "profiles/" + f
         return (None, None) if best is None else (best.get("hbm_bytes_per_launch"), src)
     except Exception:
@@ -465,7 +466,8 @@ def main(argv=None):
     if rank == 0:
         fmt = layer.x_fmt()
         # (the committed PMC passes profiled the metric configuration: any other shape / bit width / per-rank batch carries no traffic figure)
-        traffic, traffic_src = hbm_traffic_from_profile() if (bit == 8 and (rows, K, N) == (512, 4096, 11008)) else (None, None)
+        ttag = {(8, 512, 4096, 11008): "", (4, 512, 4096, 11008): "_w4a4", (8, 512, 8192, 28672): "_8192x28672"}.get((bit, rows, K, N))
+        traffic, traffic_src = hbm_traffic_from_profile(ttag) if ttag is not None else (None, None)
         shape_note = "Llama-2-7b up_proj shape" if (K, N) == (4096, 11008) else f"{K}->{N}"
         out = {
             "metric": f"effective int8 TFLOPS, W{bit}A{bit}O16 MixQ Linear forward (quantise + {'int8' if bit == 8 or fmt != 4 else 'FP6-pipe'} MFMA GEMM + fused dequant/outlier "

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/rNN_hbm_traffic.json from the two rocprofv3 PMC summaries (tools/rocprof_summary.py output of separate --pmc FETCH_SIZE and
 --pmc WRITE_SIZE passes over `bench.py --no-graph`): HBM bytes per launch of the dominant GEMM kernel, FETCH_SIZE doubled (the gfx950
-correction of MI355X_MICROARCH.md, HBM section).  Usage: make_traffic_json.py fetch.txt write.txt out.json 'source note'"""
+correction of MI355X_MICROARCH.md, HBM section).  Usage: make_traffic_json.py fetch.txt write.txt out.json 'source note' [M K N bit n_out]"""
 import json
 import re
 import sys
@@ -21,10 +21,11 @@ def counter(path, name, kernel_pat="gemm_wreg_kernel"):
 fetch_txt, write_txt, out, note = sys.argv[1:5]
 kname, fetch_kb = counter(fetch_txt, "FETCH_SIZE")
 _, write_kb = counter(write_txt, "WRITE_SIZE")
-M, K, N = 512, 4096, 11008
-alg = M * K + N * K + 2 * M * N
+M, K, N, bit, n_out = (int(v) for v in sys.argv[5:10]) if len(sys.argv) >= 10 else (512, 4096, 11008, 8, 41)
+# algorithmic bytes of the GEMM launch: quantised X + W (int8; FP6 codes for the 4-bit form: 0.75 byte) + fp16 Y
+alg = int(M * K * (1 if bit == 8 else 0.75) + N * K * (1 if bit == 8 else 0.75) + 2 * M * N)
 hbm = int(round((2 * fetch_kb + write_kb) * 1024))
-json.dump({"kernel": kname + ", 512 x 4096 -> 11008, 41 outlier columns", "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+json.dump({"kernel": kname + f", {M} x {K} -> {N}, {n_out} outlier columns", "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
            "correction": "gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported",
            "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "source": note, "ratio_to_algorithmic": round(hbm / alg, 3)},
           open(out, "w"), indent=1)

@@ -102,6 +102,75 @@ class Sampler:
         return f"power W {f(ps)}   sclk MHz {f(cs)}   [{len(late)} samples]"
 
 
+def energy_table(args, smp, side):
+    """where do the joules go?  Per arm ~`--power-seconds` of back-to-back graph replays under the power sampler:
+    us per launch, mean board power, energy per launch (mJ) and TOPS/W.  The ablation arms compute garbage by design (no weight loads /
+    no activation traffic / neither) - they price the feeds, not the result."""
+    dev = "cuda"
+    lib = _capi.load()
+    names = _capi.gemm_config_names()
+    forced = [nm for nm in ("wr128x192_s16_d4_l2", "wr128x192_abl1_noW", "wr128x192_abl2_noX", "wr128x192_abl3_mfma") if nm in names]
+    if len(forced) < 4:
+        print("(the ablation kernels are only in the tuning build: run with MIXQ_TUNING_LIB=1)")
+    idle = None
+    smp.start(); time.sleep(1.0)
+    idle_s = smp.stop(skip=0.0)
+    print("idle:", idle_s)
+    for shp in args.shapes.split(","):
+        M, N, K = (int(v) for v in shp.split("x"))
+        g = torch.Generator().manual_seed(0)
+        xf = torch.randn(M, K, generator=g)
+        qx = torch.round(xf / (xf.abs().amax(dim=1, keepdim=True) / 127)).to(torch.int8).to(dev)
+        qw = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(dev)
+        sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
+        sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
+        xp, wp = mixlib.PackOperand(qx, 1), mixlib.PackOperand(qw, 2)
+        out = torch.empty((M, N), dtype=torch.float16, device=dev)
+        wt = qw.t()
+        arms = [("hipBLASLt int8 (torch._int_mm, int32 out)", -1, lambda: torch._int_mm(qx, wt)),
+                ("this library, automatic tiling", -1, lambda: mixlib.FusedLinear(xp, wp, sx, sw, None, None, 0, None, M, N, K, bit=8, out=out))]
+        for nm in forced:
+            arms.append((nm, names.index(nm), lambda: mixlib.FusedLinear(xp, wp, sx, sw, None, None, 0, None, M, N, K, bit=8, out=out)))
+        flops = 2.0 * M * N * K
+        print(f"{shp}: ~{args.power_seconds:.0f} s of back-to-back replays per arm ({args.launches} launches per graph); board power from {smp.source()}")
+        print(f"  {'arm':44s} {'us/launch':>10s} {'TOPS':>8s} {'W':>8s} {'sclk MHz':>9s} {'mJ/launch':>10s} {'TOPS/W':>7s}")
+        with torch.cuda.stream(side):
+            for label, cfg, fn in arms:
+                lib.mixq_gemm_set_config(cfg)
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    for _ in range(args.launches):
+                        fn()
+                torch.cuda.synchronize()
+                lib.mixq_gemm_set_config(-1)
+                for _ in range(200):                                   # clock conditioning in front of the sampled window
+                    gr.replay()
+                torch.cuda.synchronize()
+                smp.start()
+                t0 = time.time(); n = 0
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                while time.time() - t0 < args.power_seconds:
+                    for _ in range(50):
+                        gr.replay()
+                    n += 50
+                    torch.cuda.synchronize()
+                e1.record(side); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / (n * args.launches)
+                smp._stop.set(); smp._t.join()
+                t00 = smp.samples[0][0]
+                late = [x for x in smp.samples if x[0] - t00 >= 0.5] or smp.samples
+                pw = float(np.mean([x[1] for x in late if x[1] is not None])) if any(x[1] is not None for x in late) else float("nan")
+                ck = float(np.mean([x[2] for x in late if x[2] is not None])) if any(x[2] is not None for x in late) else float("nan")
+                tops = flops / us / 1e6
+                print(f"  {label:44s} {us:10.2f} {tops:8.1f} {pw:8.1f} {ck:9.0f} {pw * us * 1e-3:10.2f} {tops / pw:7.2f}", flush=True)
+                del gr
+    lib.mixq_gemm_set_config(-1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="512x11008x4096,2048x11008x4096,4096x11008x4096,512x28672x8192,512x4096x4096")
@@ -109,6 +178,8 @@ def main():
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--power-seconds", type=float, default=2.0)
     ap.add_argument("--no-power", action="store_true")
+    ap.add_argument("--energy", action="store_true", help="energy-per-launch table (board power x time) for the vendor int8 GEMM, this library's automatic "
+                    "choice, the 128x192 weights-in-registers tile and its feed ablations (needs MIXQ_TUNING_LIB=1); replaces the default report")
     args = ap.parse_args()
     dev = "cuda"
     print("device:", _capi.device_info())
@@ -117,6 +188,8 @@ def main():
     print("sampler:", smp.source(), "idle:", end=" ")
     smp.start(); time.sleep(0.5); print(smp.stop(skip=0.0))
     side = torch.cuda.Stream()
+    if args.energy:
+        return energy_table(args, smp, side)
     for shp in args.shapes.split(","):
         M, N, K = (int(v) for v in shp.split("x"))
         g = torch.Generator().manual_seed(0)
