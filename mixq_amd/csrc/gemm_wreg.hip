@@ -1087,6 +1087,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 }
                 return k4;
             };
+            // Does tail k-step kk (32 outlier columns) exist?  A k-step past the layer's columns is SKIPPED (its MFMAs are what the epilogue
+            // waits for: 0.88 of its 2.5 us in profiles/r04_epilogue_ablations.txt; at 20 columns the skip is worth 0.4 us of the launch).
+            // k-step 0 always runs: the dequantisation of the next panel is threaded between ITS MFMAs (absent columns multiply zeros).
+            // (A K = 16 MFMA for a k-step holding <= 16 columns - the metric's 41 = 32 + 9 - was built and measured: v_mfma_f32_16x16x16f16
+            // issues no faster than the K = 32 form on gfx950, the launch was 0.3 us slower; removed.)
+            auto tail_mode = [&](int kk) MIXQ_INL { return (kk == 0 || n_out > 32 * kk) ? 2 : 0; };
             __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): see the first form
 #pragma unroll
             for (int kk = 0; kk < TQ; ++kk) wo_load(kk, wo2[kk]);
@@ -1196,6 +1202,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             const bool opt = has_add || has_bias || do_silu || has_amax;
             u32x4 xo2[TQ1][PJ];                                                  // X_out fragments of the current panel (from the LDS blocks)
             auto xo_read = [&](int pn, int kk) MIXQ_INL {
+                if (tail_mode(kk) == 0) return;
 #pragma unroll
                 for (int jj = 0; jj < PJ; ++jj)
                     xo2[kk][jj] = *reinterpret_cast<const u32x4*>(lds + TAILX + (kk * MB + pn * PJ + jj) * 1024 + lane * 16);
@@ -1253,13 +1260,14 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kk = 0; kk < TQ; ++kk) {
+                        if (tail_mode(kk) == 0) continue;                        // (wave-uniform; k-step 0 always runs)
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
                             const int slot = kk * NB + b;
                             tail_mma(pn * PJ + b / WNB, b % WNB, wo2[kk][b % WNB], xo2[kk][b / WNB]);
                             __builtin_amdgcn_sched_barrier(0);
-                            if (pn + 1 < NPAN && slot % TQ == 0) {
-                                const int d = slot / TQ, j2 = (pn + 1) * PJ + d / WNB, i2 = d % WNB;
+                            if (pn + 1 < NPAN && kk == 0) {                      // the next panel's blocks, one behind each MFMA of k-step 0
+                                const int d = b, j2 = (pn + 1) * PJ + d / WNB, i2 = d % WNB;
                                 deq(pn + 1, d);
                                 asm volatile("" : "+v"(fa[j2][i2]));
                             }
