@@ -1636,7 +1636,9 @@ const WrConfig g_wr[] = {
     // the 17.4 us of gemm_skinny.hip's in-workgroup K split at 32 x 4096 -> 11008 with cold weights; deeper weight rings (10, 14
     // k-steps) are slower (13.8, 14.0 us), narrow layers (N = 4096: 64 panels for 256 CUs) stay with gemm_skinny.hip
     // (profiles/r02_decode.txt)
-    MIXQ_WR(2, 1, 8, 6, 1, 0, "32x64_s8_d6_l1"),       // 14 (WR_SMALL)
+    // (round 4: with an FP6 form too - 12 stages of 3 KiB, weight ring 4 k-steps of 128 elements (10 k-steps: no faster - the loop's barrier per k-step is what a 2-MFMA k-step waits for) - so a 4-bit layer serves its small
+    // batches from the ONE FP6 image it keeps; tools/time_w4_small_batch.py)
+    MIXQ_WR6(2, 1, 8, 6, 1, 12, 4, "32x64_s8_d6_l1"),  // 14 (WR_SMALL)
     MIXQ_WR(8, 2, 16, 4, 2, 50, "128x128_s16_d4_l2_k2"),   // 15 (WR_KSPLIT): two workgroups per tile, half of K each (pairwise split-K)
 #ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): only in the tools build (make tuning)
     { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
@@ -1716,6 +1718,7 @@ const char* mixq_wr_config_name(int c) { return (c >= 0 && c < NUM_WR) ? g_wr[c]
 int mixq_wr_pick(int bit, int M, int N, int KB)
 {
     if (bit == 6) {
+        if (M <= 32) return WR_SMALL;                    // a weight stream: one 64-channel panel per workgroup (as for int8 below)
         // FP6 form (k-steps of 128 elements): the tilings that exist in it, priced with the int8 model's shape - until a sweep says
         // otherwise the tile count decides, as it does for int8
         static const struct { int cfg; float tk, fixed; } cand6[] = {

@@ -44,11 +44,12 @@ PACK_FMT = FMT_F16X64
 # bit at 1.6x the int8 MFMA rate: 22.9 vs 27.6 us at 512 x 4096 -> 11008, 24.9 vs 32.3 us at 11008 -> 4096).  FMT_P16X64 selects the
 # int8-expansion kernel instead (nibbles, two thirds of the FP6 image's weight bytes: the better trade for weight-stream-bound decode).
 PACK_FMT4 = FMT_F6X128
-# Small batches of a 4-bit layer are a weight stream, and nibbles are two thirds of the FP6 image's bytes (M <= 32: 13.8 vs 16.7 us at
-# 4096 -> 11008, 9.3 vs 15.7 at 4096 -> 4096, 14.2 vs 28.0 at 11008 -> 4096; tools/time_w4_small_batch.py).  A layer that meets such a batch
-# keeps a SECOND, nibble image for it (+ 2/3 of the FP6 image: 288 GB of HBM per GPU is not what a 4-bit model runs out of); layers that
-# only ever see large batches never build it.  0 disables.
-SMALL_BATCH_M4 = 32
+# ONE resident weight image per 4-bit layer (round 4): the FP6 one, 0.75 byte per weight (33.8 MB at 4096 -> 11008; nibbles would be 22.5 MB,
+# int8 45.1 MB).  Small batches (M <= 32) run the FP6 form of the 32 x 64 weight-stream tiling on it: 11.9-13.5 us at 4096 -> 11008 (nibble
+# image: 13.6-15.8), 10.9-12.3 us at 4096 -> 4096 (9.1-10.2), 19-22 us at 11008 -> 4096 (14-16) - tools/time_w4_small_batch.py,
+# profiles/r04_w4a4_small_batch.txt.  A decode-heavy deployment of NARROW layers may opt into a SECOND, nibble image for batches of at most
+# SMALL_BATCH_M4 rows (32 is the useful value; + 2/3 of the FP6 image's bytes, built when the first such batch arrives).  0 = off, the default.
+SMALL_BATCH_M4 = 0
 # After a layer's outlier search has frozen, keep ONLY the packed weight image in HBM (the plain [N,K] `q_weight` is
 # re-created on demand for state_dict / attribute reads).  False keeps both copies (2x the reference's weight memory).
 COMPACT_WEIGHTS = True

@@ -19,7 +19,8 @@ from test_gpu_parity import _fused_case, make_x, n, t, ulp_tol  # noqa: E402
 from test_pack_properties import f6x128_reference, f6x128_unpack, r6x128_reference, r6x128_to_fragment_order  # noqa: E402
 
 DEV = "cuda"
-F6_TILINGS = ["wr128x192_s16_d4_l2", "wr128x128_s16_d4_l2", "wr64x128_s16_d4_l2", "wr64x192_s16_d4_l2", "wr64x256_s16_d4_l2"]
+F6_TILINGS = ["wr128x192_s16_d4_l2", "wr128x128_s16_d4_l2", "wr64x128_s16_d4_l2", "wr64x192_s16_d4_l2", "wr64x256_s16_d4_l2",
+              "wr32x64_s8_d6_l1"]                            # (round 4: the small-batch tiling has an FP6 form too - one weight image per layer)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -270,11 +271,38 @@ def test_mlp_block_w4a4_shares_the_fp6_activation():
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
-def test_small_batches_of_a_four_bit_layer_stream_a_nibble_image():
-    """M <= SMALL_BATCH_M4: a weight stream - the layer serves it from a second, nibble image (built when the first small batch arrives,
-    also after the plain matrix was dropped) with P16X64 activations; larger batches keep the FP6 pair.  Same bits either way."""
+def test_a_four_bit_layer_keeps_one_weight_image_by_default():
+    """Round 4 (VERDICT r03 #5b): a 4-bit layer holds ONE resident weight image - the FP6 one, 0.75 byte per weight - whatever batch sizes
+    it sees: small batches run the FP6 form of the 32 x 64 weight-stream tiling on it.  Same bits as the nibble-only layer."""
+    assert L.SMALL_BATCH_M4 == 0, "the second (nibble) image is opt-in"
     K, N, ncols = 1024, 320, 10
     outs = {}
+    for fmt in (FMT_F6X128, FMT_P16X64):
+        L.PACK_FMT4 = fmt
+        layer, cache, cols = _layer(96, K, N, ncols, True)
+        ys = []
+        for call, M in enumerate((96, 96, 96, 16, 96, 1, 32, 33)):
+            x = torch.randn(M, K, generator=torch.Generator().manual_seed(40 + call)).half()
+            x[:, cols] *= 20
+            ys.append(layer(x.to(DEV), None, True).clone())
+            if fmt == FMT_F6X128:
+                assert mixlib.fmt_of(cache.q_xcache) == FMT_R6X128 and layer._wpk_small is None, M
+        if fmt == FMT_F6X128:
+            assert layer._buffers["q_weight"] is None and mixlib.fmt_of(layer._wpk) == FMT_F6X128
+            assert layer._wpk.numel() == N * K * 3 // 4, "resident bytes of the layer: 0.75 per weight"
+        outs[fmt] = ys
+    L.PACK_FMT4 = FMT_F6X128
+    for a, b in zip(outs[FMT_F6X128], outs[FMT_P16X64]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_small_batches_of_a_four_bit_layer_stream_a_nibble_image():
+    """Opt-in (SMALL_BATCH_M4 = 32; narrow layers at decode: 9-10 vs 11-12 us at 4096 -> 4096, tools/time_w4_small_batch.py): M <= 32 is a
+    weight stream - the layer serves it from a second, nibble image (built when the first small batch arrives, also after the plain matrix
+    was dropped) with P16X64 activations; larger batches keep the FP6 pair.  Same bits either way."""
+    K, N, ncols = 1024, 320, 10
+    outs = {}
+    prev_small, L.SMALL_BATCH_M4 = L.SMALL_BATCH_M4, 32
     for fmt in (FMT_F6X128, FMT_P16X64):
         L.PACK_FMT4 = fmt
         layer, cache, cols = _layer(96, K, N, ncols, True)
@@ -291,7 +319,7 @@ def test_small_batches_of_a_four_bit_layer_stream_a_nibble_image():
         if fmt == FMT_F6X128:
             assert layer._wpk_small is not None and mixlib.fmt_of(layer._wpk_small) == FMT_P16X64 and mixlib.fmt_of(layer._wpk) == FMT_F6X128
         outs[fmt] = ys
-    L.PACK_FMT4 = FMT_F6X128
+    L.PACK_FMT4, L.SMALL_BATCH_M4 = FMT_F6X128, prev_small
     for a, b in zip(outs[FMT_F6X128], outs[FMT_P16X64]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""4-bit layer forward at small batches: FP6-coded weights (the default) against nibble weights (PACK_FMT4 = FMT_P16X64: skinny / LDS-staged
-kernels); us per forward in a graph of 50 forwards, frozen layer."""
+"""4-bit layer forward at small batches: FP6-coded weights ALONE (the default: one resident image), FP6 + the opt-in nibble image for batches
+<= 32 rows (SMALL_BATCH_M4 = 32), and nibble weights only (PACK_FMT4 = FMT_P16X64: skinny / LDS-staged kernels); us per forward in a graph of
+50 forwards, frozen layer."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +13,8 @@ names = _capi.gemm_config_names()
 for (K, N) in [(4096, 11008), (4096, 4096), (11008, 4096)]:
     for M in (1, 16, 32, 64, 128, 256):
         row = []
-        for fmt in (FMT_F6X128, FMT_P16X64):
-            L.PACK_FMT4 = fmt
+        for fmt, small in ((FMT_F6X128, 0), (FMT_F6X128, 32), (FMT_P16X64, 0)):
+            L.PACK_FMT4, L.SMALL_BATCH_M4 = fmt, small
             torch.manual_seed(0)
             cache = MixLibCache(M, bit=4, device=dev)
             ls = torch.ones(K); ls[torch.randperm(K)[:128]] = 20.0
@@ -34,6 +35,6 @@ for (K, N) in [(4096, 11008), (4096, 4096), (11008, 4096)]:
                 us = (time.perf_counter() - t0) * 1e6 / 50
             used = getattr(layer._packed_weight(M), "_mixq_fmt", 0)                   # (the FP6 layer serves small batches from its nibble image)
             cfg = names[_capi.load().mixq_gemm_pick_config_fmt(M, N, K, 4, used)] + (" on its nibble image" if used != fmt else "")
-            row.append(f"{'fp6' if fmt == FMT_F6X128 else 'nibble'} {us:6.1f} us ({cfg})")
+            row.append(f"{('fp6+nibble' if small else 'fp6 only') if fmt == FMT_F6X128 else 'nibble only'} {us:6.1f} us ({cfg})")
         print(f"{K:6d}->{N:6d} M={M:4d}: " + "   ".join(row), flush=True)
-L.PACK_FMT4 = FMT_F6X128
+L.PACK_FMT4, L.SMALL_BATCH_M4 = FMT_F6X128, 0
