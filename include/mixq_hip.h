@@ -285,7 +285,7 @@ int mixq_gemm_set_workspace(void* ws, long long bytes);
  * Force a GEMM tile configuration id (>= 0) for subsequent mixq_gemm_* calls ON THE CURRENT DEVICE (the state is kept per HIP
  * device), -1 = automatic shape-aware choice.  Returns MIXQ_EINVAL for an unknown id.  mixq_gemm_config_name writes the config's
  * description.  Every configuration of the product library computes the same (correct) result; the ablation forms used for
- * tuning, the in-kernel timeline stamps (mixq_gemm_set_trace), the K rotation (mixq_gemm_set_krot) and the quantise kernel's
+ * tuning, the in-kernel timeline stamps (mixq_gemm_set_trace), the forced tile-order group (mixq_gemm_set_krot) and the quantise kernel's
  * timing probes (mixq_quant_set_config >= 100) exist only in the -DMIXQ_TUNING build (`make -C mixq_amd/csrc tuning` ->
  * libmixq_hip_tuning.so, loaded by the tools/ scripts): in the product library those calls return MIXQ_EINVAL. */
 int mixq_gemm_set_config(int cfg);
@@ -296,10 +296,12 @@ int mixq_quant_set_config(int cfg);
 /* Diagnostics: when buf is non-null every workgroup of the data-parallel fused GEMM writes 16 x u64 to
  * buf[16 * workgroup + i]: i in 0..7 = the 100 MHz device wall clock at 0 entry, 1 first stage landed, 2 k loop
  * done, 3 epilogue arithmetic done, 4 stores issued, 5 stores retired, 6/7 inside the epilogue; 8 + i = s_memtime
- * at the same points.  buf needs 128 bytes per workgroup (tools/trace_gemm.py). */
+ * at the same points.  The weights-in-registers kernel also writes a second set 16 x 4096 entries further on (the panel pipeline of its
+ * epilogue: tools/trace_gemm.py --panels), so buf needs 2 x 16 x 4096 x 8 bytes. */
 int mixq_gemm_set_trace(unsigned long long* buf);
-/* Tuning: the weights-in-registers kernels start the K walk of N tile t at k-step (t * krot) mod (K/64) and wrap around (integer
- * accumulation is order-independent: results are bit-identical for every value).  0 = every tile starts at k = 0. */
+/* Tuning (tools build): bits 16.. = M tiles per group of the weights-in-registers kernels' tile order (0: automatic).  The low 16 bits
+ * used to rotate the K walk between neighbouring N tiles (rounds 1-2; it never changed a timing and cost two scalar counters per wave):
+ * removed in round 4, ignored.  The product library returns MIXQ_EINVAL for any non-zero value. */
 int mixq_gemm_set_krot(int krot);
 /* Diagnostics: exhaustive self-test of the division-free quantiser used by the quantise kernels (q = rint(x / s) for all
  * finite fp16 x and all finite fp16 s > 0, ~2e9 pairs, ~1 s): adds the number of disagreements with the IEEE-division form
