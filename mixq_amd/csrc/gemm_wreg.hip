@@ -113,7 +113,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #ifdef MIXQ_NO_WRAP_TAIL
     constexpr bool WRAP = F6R || ABL == 41;
 #else
-    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && (ABL == 0 || ABL == 6 || (ABL >= 60 && ABL < 70)) && LOADERS != 0);
+    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && (ABL == 0 || ABL == 6 || (ABL >= 60 && ABL < 80)) && LOADERS != 0);
 #endif
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
@@ -343,11 +343,39 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
             nxt = LOOK % NSTAGE;
         }
+        // TOUCH (probe, ABL 70 / 71): the weight lines of k-step kt + LOOK are pulled into this XCD's L2 ten k-steps before the consumers
+        // ask for them - one dword per 64-byte sector, this workgroup's share of the panel only (the gm workgroups of an XCD that stream
+        // the same weight panel split its 12 KB per k-step between them), result never read.  Cold weights (a model's layers: every
+        // launch streams 45 MB from HBM) stall the k loop by 100 cycles per k-step (profiles/r04_gemm_trace_warm_cold.txt): long-latency
+        // requests hold the CU's memory queue.  Issued behind the k-step's wait: the hand-counted waits only get stricter by it.
+        constexpr bool TOUCH = ABL == 70 || ABL == 71;
+        const uint8_t* tbase = nullptr;
+        int tlanes = 0;
+        if constexpr (TOUCH) {
+            const int nshare = a.gm < a.tiles_m ? a.gm : a.tiles_m;              // workgroups of this XCD sharing the panel (M fastest inside a group)
+            const int sectors = BN;                                              // 64-byte sectors of the panel per k-step (BN x 64 bytes)
+            const int per = (sectors + nshare - 1) / nshare;
+            const int q = tm % nshare;
+            int sec = q * per + lane;
+            const size_t slab = static_cast<size_t>(a.wblocks) * 1024;           // bytes of one k-step of the image
+            size_t off = static_cast<size_t>(n0 >> 4) * 1024 + static_cast<size_t>(sec) * 64;
+            if (off + 64 > slab) off = slab - 64;                                // (the last tile's panel hangs over the image's rows)
+            tbase = a.qw + off;
+            tlanes = (lane < per && sec < sectors && lw == (ABL == 71 ? 1 : 0)) ? 1 : 0;
+        }
+        size_t toff = static_cast<size_t>(kt + LOOK) * static_cast<size_t>(a.wblocks) * 1024;   // (the k-step whose stage the next iteration requests)
+        int tsink = 0;
         for (; kt + LOOK < nk; ++kt) {
             stage(nxt);
             if constexpr (ABL != 5) wr_wait_vmcnt<LOADS * NEWER>();              // stage kt+1 landed
             if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
             nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+            if constexpr (TOUCH) {
+                // (the destination stays a LIVE register until the loader's last vmcnt(0): a dead one would be handed to something else while
+                // the load is still in flight, and the returning dword would land in it)
+                if (tlanes) asm volatile("global_load_dword %0, %1, off" : "+v"(tsink) : "v"(tbase + toff) : "memory");
+                toff += static_cast<size_t>(a.wblocks) * 1024;
+            }
         }
         // The fp16 outlier tail's activation operand (X_out rows of this tile) is the same for the four consumer waves: like X it
         // goes through LDS once - fragment-ordered 16 x 32 blocks of the first TQ tail k-steps (64 outlier columns), DMA-ed
@@ -397,6 +425,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
         }
         wr_wait_vmcnt<0>();                                                      // (nk = 1: no drain iteration waited for the tail blocks)
+        if constexpr (TOUCH) asm volatile("" :: "v"(tsink));
         uint32_t voffL[IT_L];
         int loffL[IT_L];
         if constexpr (EPI2) {
@@ -545,7 +574,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 // the ring's registers are read-write operands of the load statements, so they need a definition in front of the first one:
                 // an EMPTY asm output (no instruction; 15 x 4 v_mov in front of the first weight request otherwise).  Ablation builds that
                 // never load them get defined, opaque values.
-                if constexpr (ABL == 0 || ABL == 6 || ABL == 50 || (ABL >= 60 && ABL < 70)) {
+                if constexpr (ABL == 0 || ABL == 6 || ABL == 50 || (ABL >= 60 && ABL < 80)) {
                     asm volatile("" : "=v"(wq[d][i]));
                     if constexpr (F6) asm volatile("" : "=v"(wq2[d][i]));
                 } else {
@@ -1656,6 +1685,7 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 64, "128x192_p64_epi2_no_tail_mfma"),
     MIXQ_WR(8, 3, 16, 4, 2, 65, "128x192_p65_epi2_no_staging_writes"),
     MIXQ_WR(8, 3, 16, 4, 2, 66, "128x192_p66_epi2_no_scaling"),
+    { "wr128x192_p70_touch", 8, 3, 16, 2, gemm_wreg_kernel<8, 3, 16, 4, 0, 2, 70>, nullptr, nullptr, 0 },   // probe: the loaders pull the panel's weight lines into L2 ahead of the consumers
     MIXQ_WR(8, 3, 16, 4, 2, 67, "128x192_p67_epi2_loaders_copy_3_of_4"),
     MIXQ_WR(8, 3, 16, 4, 2, 60, "128x192_p60_epi1"),   // cfg 0 with the first form of the epilogue (round 3's): the A/B partner of EPI2
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
