@@ -44,6 +44,13 @@ extern "C" {
                               * output as the multiplier - linear.py:372-373 (`y1 += self.bias`) followed by the
                               * `gate_output *= up_output` pass of modules/fused/mlp.py:61-63, folded into the GEMM
                               *  */
+#define MIXQ_ACT_SILU_PAIR 3 /* gate_proj and up_proj of an MLP block as ONE GEMM (modules/fused/mlp.py:57-63 in one launch).  The N weight
+                              * rows (and scale_col, bias, w_out rows) are the two layers' rows INTERLEAVED in groups of four:
+                              * row 4g+0 = up[2g], 4g+1 = up[2g+1], 4g+2 = gate[2g], 4g+3 = gate[2g+1].  y has N/2 columns:
+                              * y[m,c] = fp16((SiLU(z_gate[m,c]) + bias_gate[c]) * fp16(z_up[m,c] + bias_up[c])), z = dequant + outlier -
+                              * bit for bit what up_proj's launch followed by gate_proj's MIXQ_ACT_SILU_MUL launch leave.  int8,
+                              * MIXQ_FMT_F16X64 weights with MIXQ_FMT_P16X64 activations, N % 16 == 0, ldy >= N/2, no addend; other
+                              * operands answer MIXQ_ESHAPE (the caller then runs the two launches) */
 
 /* Quantised-operand storage formats.
  * MIXQ_FMT_PLAIN  : row-major [R, KB] bytes (KB = K for int8, K/2 for nibble-packed int4) - the reference's layout.

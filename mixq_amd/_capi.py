@@ -26,6 +26,7 @@ MIXQ_ENODEV = -3
 ACT_NONE = 0
 ACT_SILU = 1
 ACT_SILU_MUL = 2
+ACT_SILU_PAIR = 3                    # gate_proj + up_proj as one GEMM over interleaved rows: y has N / 2 columns (include/mixq_hip.h)
 FMT_PLAIN = 0
 FMT_P16X64 = 1
 FMT_F16X64 = 2

@@ -184,3 +184,12 @@ __device__ __forceinline__ void f6_store16(int fmt, uint8_t* blk, int row, int g
 __device__ __forceinline__ int wave_id_uniform() {
     return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
 }
+// SiLU of every fused epilogue.  The product carries no "contract" flag: after inlining, `silu(z) + bias` must stay a multiplication and
+// an addition in EVERY kernel form - left free, the compiler fuses them into one FMA in some instantiations and not in others, and two
+// routes that compute the same expression differ in the last fp16 bit of one element in 10^5 (found by the joint gate / up launch against
+// the two launches it replaces).  The oracle rounds the product, then adds (oracle/mixq_oracle.c).
+__device__ __forceinline__ float mixq_silu(float v) {
+#pragma clang fp contract(off)
+    const float s = v * __builtin_amdgcn_rcpf(1.f + __expf(-v));              // 1-ulp rcp: below fp16 resolution
+    return s;
+}

@@ -71,7 +71,7 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
 // physical 16-byte chunk of logical chunk c in row r (an involution in c for fixed r)
 __device__ __forceinline__ int swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 3); }
 
-__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   // 1-ulp rcp: below fp16 resolution
+__device__ __forceinline__ float silu(float v) { return mixq_silu(v); }   // (common.h: never contracted with the bias addition)
 
 // BM: activation rows per tile, BN: weight rows per tile, WAVES_M x WAVES_N consumer waves, NSTAGE ring depth,
 // MODE 0: int8 fused epilogue, 1: int4 fused epilogue, 2: int8 raw int32 output.  LOADERS: dedicated DMA waves
@@ -892,10 +892,13 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     if (wf16 && !(layout & MIXQ_X_PACKED)) return MIXQ_EINVAL;   // fragment-order weights go with P16X64 activations
     if (M < 0 || N < 0 || K <= 0 || n_out < 0) return MIXQ_EINVAL;
     if (M > 0 && N > 0 && (!q_x || !q_w || !x_scale || !scale_col || !y)) return MIXQ_EINVAL;
-    if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU && act != MIXQ_ACT_SILU_MUL) return MIXQ_EINVAL;
+    if (act != MIXQ_ACT_NONE && act != MIXQ_ACT_SILU && act != MIXQ_ACT_SILU_MUL && act != MIXQ_ACT_SILU_PAIR) return MIXQ_EINVAL;
     if (act == MIXQ_ACT_SILU_MUL && !addend) return MIXQ_EINVAL;            // the multiplier is mandatory
+    const bool pair = act == MIXQ_ACT_SILU_PAIR;                            // interleaved gate / up rows: y has N / 2 columns
+    if (pair && addend) return MIXQ_EINVAL;
+    if (pair && (bit != 8 || !wf16 || (N & 15))) return MIXQ_ESHAPE;        // (one kernel form: int8, fragment-order weights)
     const int KB = bit == 8 ? K : K / 2;
-    if ((KB % 64) || (bit == 4 && (K & 1)) || (N & 3) || (ldy & 3) || ldy < N) return MIXQ_ESHAPE;
+    if ((KB % 64) || (bit == 4 && (K & 1)) || (N & 3) || (ldy & 3) || ldy < (pair ? N / 2 : N)) return MIXQ_ESHAPE;
     if (addend && lda != 0 && lda < N) return MIXQ_EINVAL;
     if (n_out > 0 && x_out && w_out) {
         const int need = (n_out + 15) & ~15;
@@ -925,19 +928,20 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
         const bool both_packed = a.x_packed && (a.w_packed || wf16);
         // (wide layers with fragment-order int8 weights: the 32 x 64 weights-in-registers tiling streams faster, gemm_wreg.hip)
         const bool wide_wr = wf16 && bit == 8 && N >= 8192 && g_forced < 0;
-        if (!wide_wr && (g_forced < 0 || g_forced == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed)) {
+        if (!pair && !wide_wr && (g_forced < 0 || g_forced == skinny_id) && mixq_skinny_applies(bit, M, N, KB, both_packed, both_packed)) {
             if (row_amax) return MIXQ_ESHAPE;                    // the row-maximum side output lives in the weights-in-registers kernels
             return mixq_skinny_launch(bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                                       ldy, M, N, KB, act, wf16 ? 1 : 0, mixq_stream(stream));
         }
-        if (g_forced == skinny_id) return MIXQ_EINVAL;
+        if (g_forced == skinny_id && !pair) return MIXQ_EINVAL;
     }
     // fragment-order weights: the weights-in-registers kernels (gemm_wreg.hip) - except at prefill sizes, where the LDS-staged
     // 256 x 256 tiling of this file (8 waves of 64 x 128, cfg LDS256) is 2.5-9 % ahead once its tile count quantises no worse
     // (profiles/r03_prefill_ab.txt); it reads the same F16X64 weight image through a remapped DMA source
     if (wf16) {
         int c;
-        if (g_forced >= wr0) c = g_forced - wr0;
+        if (pair) c = mixq_wr_pair_config();                             // (a forced configuration does not apply: the one form there is)
+        else if (g_forced >= wr0) c = g_forced - wr0;
         else if (g_forced >= NUM_CFGS) return MIXQ_EINVAL;               // a stream-K form was forced: it takes P16X64 weights only
         else if (g_forced >= 0 || (bit == 8 && !row_amax && prefill_prefers_lds256(M, N))) {
             if (row_amax) return MIXQ_ESHAPE;

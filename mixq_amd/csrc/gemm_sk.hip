@@ -54,7 +54,7 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ int swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 3); }
-__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   // 1-ulp rcp: below fp16 resolution
+__device__ __forceinline__ float silu(float v) { return mixq_silu(v); }   // (common.h: never contracted with the bias addition)
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int MODE>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_sk_kernel(const SkArgs a)

@@ -32,7 +32,7 @@ struct SkinnyArgs {
 constexpr int SKW = 8;                                   // waves per workgroup = k splits
 
 __device__ __forceinline__ int sk_swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 3); }   // P16X64 chunk swizzle (common.h)
-__device__ __forceinline__ float sk_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float sk_silu(float v) { return mixq_silu(v); }   // (common.h: never contracted with the bias addition)
 
 // UNROLL: k-steps whose loads are in flight together (x2 buffers); MINW: waves per SIMD the register budget must allow.
 // I4: both operands nibble-packed int4 (KB = K/2 bytes per row): every 16-byte fragment is expanded in registers to the

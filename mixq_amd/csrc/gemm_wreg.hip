@@ -73,7 +73,7 @@ __device__ __forceinline__ void wr_glds16(const uint8_t* gsrc, uint8_t* lds_wave
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ float wr_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float wr_silu(float v) { return mixq_silu(v); }   // (common.h: never contracted with the bias addition)
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) (ring slots are compile-time registers)
 template <int I, int N, class F> __device__ __forceinline__ void wr_static_for(F&& f) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #ifdef MIXQ_NO_WRAP_TAIL
     constexpr bool WRAP = F6R || ABL == 41;
 #else
-    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && (ABL == 0 || ABL == 6 || (ABL >= 60 && ABL < 80)) && LOADERS != 0);
+    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && (ABL == 0 || ABL == 6 || (ABL >= 60 && ABL < 80) || ABL == 90) && LOADERS != 0);
 #endif
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
@@ -126,7 +126,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int LOADS = STAGE_BYTES / 1024 / ISSUERS;  // 1 KiB DMA pieces per issuing wave and stage
     constexpr int TLOADS = MB / ISSUERS;                 // the fp16 tail's X_out blocks per issuing wave
     constexpr int WL = F6 ? 2 * WNB : WNB;               // load instructions of one k-step's weight fragments (per wave)
-    constexpr int OPITCH = BN * 2 + 16;
+    // PAIR (ABL = 90; MIXQ_ACT_SILU_PAIR): gate_proj and up_proj of an MLP block as ONE GEMM.  The weight rows are interleaved in groups of
+    // four - up[2g], up[2g+1], gate[2g], gate[2g+1] (scale_col, bias and weight_cache rows likewise) - so the four consecutive channels a
+    // lane holds of a 16 x 16 accumulator block ARE the two (up, gate) pairs of output channels 2g, 2g+1: the product
+    // (silu(gate) + bias_gate) * fp16(up + bias_up) is lane-local, leaves the epilogue as ONE packed fp16 pair, and the tile stages and
+    // stores BN / 2 output columns.  Same operations per element as up_proj's launch followed by gate_proj's MIXQ_ACT_SILU_MUL launch
+    // (mixquant/modules/fused/mlp.py:57-63): bit-identical; up's 11 MB round trip through memory and one launch disappear.
+    constexpr bool PAIR = ABL == 90;
+    constexpr int BNO = PAIR ? BN / 2 : BN;              // output columns of the staged tile
+    constexpr int OPITCH = BNO * 2 + 16;
     constexpr bool PREBIAS = !SELF && (MB * WNB * 4 + (D + 1) * WNB * (F6 ? 6 : 4) * (I4 ? 2 : 1) + MB * (F6 ? 6 : 4) + 40 <= 232);   // registers to spare for the bias prefetch
     constexpr int AMAX_OFF = (BM * OPITCH + 15) & ~15;   // LDS: [CW][4][BM] row maxima (one slot per wave and lane group), behind the staging tile
     // tail k-steps (32 outlier columns each) whose X_out blocks go through LDS: two; four in the FP6 form - 4-bit layers carry 128
@@ -163,6 +171,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
     static_assert(!SELF || (LOOK == D + 1 && !I4 && ABL == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
     static_assert(!EPI2 || SC_END <= 160 * 1024, "X ring + tail blocks + panel flags + scales must fit the 160 KiB of LDS");
+    static_assert(!PAIR || (EPI2 && Q == 0), "the paired gate / up epilogue exists in the panel form of the int8 kernel only");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if constexpr (ABL == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
@@ -172,7 +181,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     asm volatile("" :: "s"(a.qx), "s"(a.qw), "s"(a.sx), "s"(a.sw), "s"(a.M), "s"(a.N), "s"(a.KB), "s"(a.tiles_m), "s"(a.tiles_n),
                  "s"(a.xblocks), "s"(a.wblocks), "s"(a.gm), "s"(a.n_out_dev), "s"(a.bias), "s"(a.n_out), "s"(a.mg_group), "s"(a.mg_gm),
                  "s"(a.mg_last), "s"(a.ldy), "s"(a.y));
-    const bool staged = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+    const bool staged = (((PAIR ? a.N >> 1 : a.N) & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
 
     // KS (ABL = 50): pairwise split-K.  Long-K layers with few output tiles (11008 -> 4096 at 512 tokens: 128 tiles of 128 x 128, half the
     // CUs idle, or 256 tiles of 64 x 128 at a third fewer MACs per operand byte) run TWO workgroups per tile, each over half of K: the
@@ -238,7 +247,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // before the barrier) and is the same for every panel; a panel's stores are buffer stores on a descriptor that starts at the panel's
     // first row and ends behind its last valid one, so rows past M are dropped by the hardware's range check and chunks past N (or past
     // the panel) carry an offset that is always out of range: no address arithmetic and no test per store.
-    constexpr int CPR = BN / 8;                                                  // 16-byte chunks per tile row
+    constexpr int CPR = BNO / 8;                                                 // 16-byte chunks per tile row
     constexpr int CPCH = PROWS * CPR;                                            // ... per panel
     constexpr int IT_L = SELF ? 1 : (CPCH + LOADERS * 64 - 1) / (LOADERS * 64 > 0 ? LOADERS * 64 : 1);   // per loader thread
     constexpr int IT_A = (CPCH + NT - 1) / NT;                                   // per thread when every wave copies (the last panel)
@@ -247,8 +256,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int q = t + it * NTHR, r = q / CPR, c = q - r * CPR;
-            const bool ok = q < CPCH && n0 + c * 8 < a.N;
-            voff[it] = ok ? static_cast<uint32_t>(r * a.ldy + n0 + c * 8) * 2u : 0x80000000u;
+            const int no = (PAIR ? n0 >> 1 : n0) + c * 8;                         // first output column of the chunk
+            const bool ok = q < CPCH && no < (PAIR ? a.N >> 1 : a.N);
+            voff[it] = ok ? static_cast<uint32_t>(r * a.ldy + no) * 2u : 0x80000000u;
             loff[it] = ok ? r * OPITCH + c * 16 : 0;
         }
     };
@@ -1222,6 +1232,43 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     else if (m < a.M && n < a.N) *reinterpret_cast<u32x2_u*>(a.y + static_cast<size_t>(m) * a.ldy + n) = o;
                 }
             };
+            // PAIR: the same piece for the joint gate / up launch - physical columns n .. n+3 of a lane are up[c], up[c+1], gate[c], gate[c+1]
+            // of output channels c = n / 2, c + 1.  up goes through the fp16 rounding it has as up_proj's output tensor (z + bias -> fp16,
+            // linear.py:285), the product is taken in fp32 and rounded once: what MIXQ_ACT_SILU_MUL computes from that tensor.
+            auto finish_pair = [&](auto st_c, int pn, int i) MIXQ_INL {
+                constexpr bool ST = decltype(st_c)::value;
+                const int nloc = wave * WN + i * 16 + lq * 4, n = n0 + nloc, oc = n >> 1;
+                float bv[4];
+                if (has_bias) {
+                    const u32x4 br = *reinterpret_cast<const u32x4*>(lds + BI_OFF + nloc * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = h2f(static_cast<uint16_t>(br[r]));
+                }
+                uint32_t keep = 0x7fff7fffu;
+                if (has_amax) {
+                    const uint32_t mb = n >= a.N ? 0x3u : (a.amax_mask ? (a.amax_mask[oc >> 5] >> (oc & 31)) & 0x3u : 0u);
+                    if (mb & 1u) keep &= 0xffff0000u;
+                    if (mb & 2u) keep &= 0x0000ffffu;
+                }
+#pragma unroll
+                for (int jj = 0; jj < PJ; ++jj) {
+                    const int j = pn * PJ + jj;
+                    const int m = m0 + j * 16 + lm;
+                    f32x4 f = fa[j][i];
+                    if (has_bias) { f[0] += bv[0]; f[1] += bv[1]; }
+                    const f16x2 uh = __builtin_convertvector(f32x2{f[0], f[1]}, f16x2);
+                    float g0 = wr_silu(f[2]), g1 = wr_silu(f[3]);
+                    if (has_bias) { g0 += bv[2]; g1 += bv[3]; }
+                    g0 *= static_cast<float>(uh[0]); g1 *= static_cast<float>(uh[1]);
+                    const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{g0, g1}, f16x2));
+                    if (has_amax) {
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        rmax[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, rmax[j]), __builtin_bit_cast(us2, o & keep)));
+                    }
+                    if constexpr (ST) *reinterpret_cast<uint32_t*>(lds + (j * 16 + lm) * OPITCH + nloc) = o;   // (byte offset of output column nloc / 2)
+                    else if (m < a.M && n < a.N) *reinterpret_cast<uint32_t*>(a.y + static_cast<size_t>(m) * a.ldy + oc) = o;
+                }
+            };
             auto raise_flag = [&](int pn) MIXQ_INL {
                 // panel staged by this wave: a flag word written BEHIND the panel's stores (asm with a memory clobber: the compiler may not move
                 // it ahead of them; the LDS executes one wave's operations in order)
@@ -1329,7 +1376,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 } else {
                     if constexpr (pn < NPAN) {
                         // (straight-line code per case: the optional terms and the unstaged stores are compile-time switches of finish_col)
-                        if (staged && !opt) {
+                        if constexpr (PAIR) {
+                            if (staged) {
+#pragma unroll
+                                for (int c = 0; c < WNB; ++c) finish_pair(std::true_type{}, pn, c);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < WNB; ++c) finish_pair(std::false_type{}, pn, c);
+                            }
+                        } else if (staged && !opt) {
 #pragma unroll
                             for (int c = 0; c < WNB; ++c) finish_col(std::false_type{}, std::true_type{}, pn, c);
                         } else if (staged) {
@@ -1669,6 +1724,7 @@ const WrConfig g_wr[] = {
     // batches from the ONE FP6 image it keeps; tools/time_w4_small_batch.py)
     MIXQ_WR6(2, 1, 8, 6, 1, 12, 4, "32x64_s8_d6_l1"),  // 14 (WR_SMALL)
     MIXQ_WR(8, 2, 16, 4, 2, 50, "128x128_s16_d4_l2_k2"),   // 15 (WR_KSPLIT): two workgroups per tile, half of K each (pairwise split-K)
+    { "wr128x192_s16_d4_l2_pair", 8, 3, 16, 2, gemm_wreg_kernel<8, 3, 16, 4, 0, 2, 90>, nullptr, nullptr, 0 },   // 16 (WR_PAIR): gate_proj + up_proj in one launch (96 + 96 interleaved rows per tile, 96 output columns)
 #ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): only in the tools build (make tuning)
     { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
     { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 2>, 8 },
@@ -1722,6 +1778,7 @@ const WrConfig g_wr[] = {
 };
 constexpr int WR_SMALL = 14;
 constexpr int WR_KSPLIT = 15;
+constexpr int WR_PAIR = 16;
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
 #ifdef MIXQ_TUNING
 int g_wr_krot = 0;
@@ -1783,6 +1840,7 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
 }
 
 int mixq_wr_ksplit_config() { return WR_KSPLIT; }
+int mixq_wr_pair_config() { return WR_PAIR; }
 // Can the pairwise split-K form (WR_KSPLIT) run (M, N, KB) on the current device?  MIXQ_OK, or why not: both halves of every tile must be
 // resident at once (2 x tiles <= CUs), the workspace registered with mixq_gemm_set_workspace must hold a flag word and an int32 slot per tile.
 int mixq_wr_ksplit_ok(int M, int N, int KB)
@@ -1828,6 +1886,8 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
                    unsigned long long* trace, hipStream_t st, uint32_t* row_amax, const uint32_t* amax_mask)
 {
     if (c < 0 || c >= NUM_WR) return MIXQ_EINVAL;
+    if ((act == MIXQ_ACT_SILU_PAIR) != (c == WR_PAIR)) return MIXQ_EINVAL;  // (the paired epilogue is a kernel form, not a run-time switch)
+    if (c == WR_PAIR && (bit != 8 || (N & 3) || addend)) return MIXQ_EINVAL;
     const WrConfig& g = g_wr[c];
     WrArgs a;
     memset(&a, 0, sizeof(a));

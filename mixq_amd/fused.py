@@ -24,6 +24,23 @@ def set_backend(mod):
     return prev
 
 
+def interleave_pair_rows(up: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """Rows of up_proj's and gate_proj's per-channel tensors ([N, ...] each, N even) in the order MIXQ_ACT_SILU_PAIR reads them
+    (include/mixq_hip.h): groups of four - up[2g], up[2g+1], gate[2g], gate[2g+1] - so that the four consecutive channels a lane holds
+    of an accumulator block are two complete (up, gate) pairs."""
+    if up.shape != gate.shape or up.shape[0] % 2:
+        raise ValueError("interleave_pair_rows: two tensors of one shape with an even number of rows")
+    N, rest = up.shape[0], tuple(up.shape[1:])
+    return torch.stack([up.reshape(N // 2, 2, *rest), gate.reshape(N // 2, 2, *rest)], dim=1).reshape(2 * N, *rest)
+
+
+def split_pair_rows(joint: torch.Tensor):
+    """Inverse of interleave_pair_rows: (up, gate)."""
+    N2, rest = joint.shape[0], tuple(joint.shape[1:])
+    v = joint.reshape(N2 // 4, 2, 2, *rest)
+    return v[:, 0].reshape(N2 // 2, *rest), v[:, 1].reshape(N2 // 2, *rest)
+
+
 class FasterTransformerRMSNorm(nn.Module):
     def __init__(self, weight, eps=1e-6, cache=None):
         super().__init__()

@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import _capi
-from ._capi import (ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, FMT_R6X128, X_PACKED, W_PACKED, W_F16X64,
+from ._capi import (ACT_NONE, ACT_SILU, ACT_SILU_MUL, ACT_SILU_PAIR, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, FMT_R6X128, X_PACKED, W_PACKED, W_F16X64,
                     XW_F6X128)
 
 
@@ -716,7 +716,10 @@ def FusedLinear(q_x, q_w, x_scale, scale_col, x_out, w_out, n_out, bias, M, N, K
         raise RuntimeError("FusedLinear: x_scale / scale_col are shorter than M / N")
     x_fmt = fmt_of(q_x) if x_packed is None else (FMT_P16X64 if x_packed else FMT_PLAIN)
     w_fmt = fmt_of(q_w) if w_packed is None else (FMT_P16X64 if w_packed else FMT_PLAIN)
-    y = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=q_x.device)
+    # (ACT_SILU_PAIR: N counts the interleaved gate / up rows, the product has N / 2 columns)
+    if act == ACT_SILU_PAIR and (N % 16 or not _is_zero_addend(addend)):
+        raise RuntimeError("FusedLinear: ACT_SILU_PAIR needs N % 16 == 0 and takes no addend")
+    y = out if out is not None else torch.empty((M, N // 2 if act == ACT_SILU_PAIR else N), dtype=torch.float16, device=q_x.device)
     if n_out and x_out is not None and w_out is not None:
         xop, ldxo = _rows(x_out, "x_out")
         wop, ldwo = _rows(w_out, "w_out")

@@ -1,0 +1,139 @@
+"""gate_proj + up_proj of an MLP block as ONE launch (MIXQ_ACT_SILU_PAIR, include/mixq_hip.h; mixquant/modules/fused/mlp.py:57-63): the
+interleaved weight image against the oracle and, bit for bit, against the two-launch route it replaces."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mixq_amd import _capi, mixlib  # noqa: E402
+from mixq_amd.fused import interleave_pair_rows, split_pair_rows  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from test_gpu_parity import make_x, t  # noqa: E402
+from test_gpu_round3 import n, ulp_tol  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    assert "gfx950" in _capi.device_info()
+    _capi.load().mixq_gemm_set_config(-1)
+    yield
+    _capi.load().mixq_gemm_set_config(-1)
+
+
+def _case(M, N, K, n_out, bias, seed):
+    rng = np.random.default_rng(seed)
+    ind = np.sort(rng.choice(K, n_out, replace=False)).astype(np.int32) if n_out else np.zeros(0, np.int32)
+    x = make_x(M, K, seed=seed + 1, outlier_cols=ind)
+    c = dict(M=M, N=N, K=K, ind=ind)
+    for nm in ("up", "gate"):
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+        qw, sw = O.quant_weight_w8(w)
+        c[nm] = dict(qw=qw, sw=sw, wo=O.dequant_weight_cols(qw, sw, ind, 8) if n_out else None,
+                     bias=rng.standard_normal(N).astype(np.float16) if bias else None)
+    xz = x.copy()
+    c["xo"] = O.extract_outliers_zero(xz, ind) if n_out else None
+    c["qx"], c["sx"] = O.find_row_scale(xz, 8)
+    return c
+
+
+def _operands(c):
+    M, n_out = c["M"], int(c["ind"].size)
+    pad = (n_out + 15) // 16 * 16
+    xo = None
+    if n_out:
+        xo = torch.full((M, pad), float("nan"), dtype=torch.float16, device=DEV)   # the pad is poison
+        xo[:, :n_out] = t(c["xo"])
+        xo = xo[:, :n_out]
+    sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV); sx[:, 0] = t(c["sx"])
+    qx = mixlib.PackOperand(t(c["qx"]), 1)
+
+    def wo_of(w):
+        if not n_out:
+            return None
+        b = torch.full((w.shape[0], pad), float("nan"), dtype=torch.float16, device=DEV)
+        b[:, :n_out] = w
+        return b[:, :n_out]
+    return qx, sx, xo, wo_of, n_out
+
+
+def _two_launches(c, row_amax=None, col_mask=None):
+    M, N, K = c["M"], c["N"], c["K"]
+    qx, sx, xo, wo_of, n_out = _operands(c)
+    u, g = c["up"], c["gate"]
+    b = lambda d: None if d["bias"] is None else t(d["bias"])
+    up = mixlib.FusedLinear(qx, mixlib.PackOperand(t(u["qw"]), 2), sx, t(u["sw"]), xo, wo_of(t(u["wo"])) if n_out else None, n_out, b(u), M, N, K)
+    extra = {} if row_amax is None else {"row_amax": row_amax, "col_mask": col_mask}
+    return mixlib.FusedLinear(qx, mixlib.PackOperand(t(g["qw"]), 2), sx, t(g["sw"]), xo, wo_of(t(g["wo"])) if n_out else None, n_out, b(g), M, N, K,
+                              act=_capi.ACT_SILU_MUL, addend=up, **extra)
+
+
+def _one_launch(c, row_amax=None, col_mask=None):
+    M, N, K = c["M"], c["N"], c["K"]
+    qx, sx, xo, wo_of, n_out = _operands(c)
+    u, g = c["up"], c["gate"]
+    qw = mixlib.PackOperand(interleave_pair_rows(t(u["qw"]), t(g["qw"])), 2)
+    sw = interleave_pair_rows(t(u["sw"]).reshape(-1), t(g["sw"]).reshape(-1)).reshape(1, -1)
+    wo = wo_of(interleave_pair_rows(t(u["wo"]), t(g["wo"]))) if n_out else None
+    bias = None if u["bias"] is None else interleave_pair_rows(t(u["bias"]), t(g["bias"]))
+    extra = {} if row_amax is None else {"row_amax": row_amax, "col_mask": col_mask}
+    return mixlib.FusedLinear(qx, qw, sx, sw, xo, wo, n_out, bias, M, 2 * N, K, act=_capi.ACT_SILU_PAIR, **extra)
+
+
+def test_interleave_is_a_bijection_in_groups_of_four():
+    up = torch.arange(16).reshape(8, 2)
+    gate = 100 + torch.arange(16).reshape(8, 2)
+    j = interleave_pair_rows(up, gate)
+    assert j[:, 0].tolist() == [0, 2, 100, 102, 4, 6, 104, 106, 8, 10, 108, 110, 12, 14, 112, 114]
+    u2, g2 = split_pair_rows(j)
+    assert torch.equal(u2, up) and torch.equal(g2, gate)
+
+
+@pytest.mark.parametrize("M,N,K,n_out,bias", [(512, 11008, 4096, 41, False), (200, 584, 512, 70, True), (130, 104, 256, 33, True),
+                                              (96, 96, 128, 0, False), (33, 1000, 1024, 129, False), (512, 4096, 1024, 20, False)])
+def test_one_launch_for_gate_and_up_against_the_oracle_and_the_two_launch_route(M, N, K, n_out, bias):
+    c = _case(M, N, K, n_out, bias, seed=M + N + n_out)
+    u, g = c["up"], c["gate"]
+    up_ref = O.linear_fused(c["qx"], u["qw"], c["sx"], u["sw"], xo=c["xo"], wo=u["wo"], addend=None, bias=u["bias"], act=0, bit=8)
+    ref = O.linear_fused(c["qx"], g["qw"], c["sx"], g["sw"], xo=c["xo"], wo=g["wo"], addend=up_ref, bias=g["bias"], act=2, bit=8).astype(np.float32)
+    y1 = _one_launch(c)
+    assert tuple(y1.shape) == (M, N)
+    y = n(y1).astype(np.float32)
+    assert np.isfinite(y).all()
+    assert (np.abs(y - ref) <= ulp_tol(ref)).all(), float(np.abs(y - ref).max())
+    y2 = _two_launches(c)
+    assert torch.equal(y1, y2), int((y1 != y2).sum())
+
+
+def test_row_maxima_for_down_proj_leave_the_joint_launch_as_they_leave_gate_projs():
+    M, N, K, n_out = 300, 1024, 512, 41
+    c = _case(M, N, K, n_out, False, seed=7)
+    mask = torch.zeros((N + 31) // 32, dtype=torch.int32, device=DEV)
+    for col in (0, 5, 33, 64, 1001, 1023):                               # down_proj's own outlier columns: out of its row maxima
+        mask[col // 32] |= (1 << (col % 32)) if col % 32 != 31 else -(1 << 31)
+    a1 = torch.zeros(M, dtype=torch.int32, device=DEV)
+    a2 = torch.zeros(M, dtype=torch.int32, device=DEV)
+    y1 = _one_launch(c, a1, mask)
+    y2 = _two_launches(c, a2, mask)
+    assert torch.equal(y1, y2)
+    assert torch.equal(a1, a2)
+    keep = torch.ones(N, dtype=torch.bool, device=DEV)
+    keep[[0, 5, 33, 64, 1001, 1023]] = False
+    want = y1[:, keep].abs().max(dim=1).values.view(torch.int16).to(torch.int32)
+    assert torch.equal(a1, want)
+
+
+def test_operands_the_joint_form_does_not_serve_are_refused_not_miscomputed():
+    c = _case(64, 96, 128, 0, False, seed=3)
+    qx, sx, _, _, _ = _operands(c)
+    u, g = c["up"], c["gate"]
+    j = interleave_pair_rows(t(u["qw"]), t(g["qw"]))
+    sw = interleave_pair_rows(t(u["sw"]).reshape(-1), t(g["sw"]).reshape(-1)).reshape(1, -1)
+    with pytest.raises(_capi.MixqError):                                 # P16x64 weights: the LDS-staged kernels have no paired epilogue
+        mixlib.FusedLinear(qx, mixlib.PackOperand(j, 1), sx, sw, None, None, 0, None, 64, 192, 128, act=_capi.ACT_SILU_PAIR)
+    with pytest.raises(RuntimeError):
+        mixlib.FusedLinear(qx, mixlib.PackOperand(j, 2), sx, sw, None, None, 0, None, 64, 192, 128, act=_capi.ACT_SILU_PAIR,
+                           addend=torch.zeros((64, 96), dtype=torch.float16, device=DEV))

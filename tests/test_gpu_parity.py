@@ -848,7 +848,7 @@ def test_randomized_shapes_all_tilings_bit_exact():
     rng = np.random.default_rng(2024)
     names = _capi.gemm_config_names()
     # (stream-K and pairwise split-K forms need a registered workspace and have their own tests)
-    real = [i for i, nm in enumerate(names) if "abl" not in nm and not nm.startswith("sk") and not nm.startswith("decode") and not nm.endswith("_k2")]
+    real = [i for i, nm in enumerate(names) if "abl" not in nm and not nm.startswith("sk") and not nm.startswith("decode") and not nm.endswith(("_k2", "_pair"))]
     decode = names.index("decode32")
     lib = _capi.load()
     keep = []
@@ -993,7 +993,7 @@ def test_silu_mul_needs_its_multiplier():
 # ---------------------------------------------------------------------------------------------------------------
 def _wr_configs():
     # (the pairwise split-K form needs a workspace and 2 x tiles <= CUs: it has its own tests in test_gpu_round3.py)
-    return [i for i, name in enumerate(_capi.gemm_config_names()) if name.startswith("wr") and "abl" not in name and "self" not in name and not name.endswith("_k2")]
+    return [i for i, name in enumerate(_capi.gemm_config_names()) if name.startswith("wr") and "abl" not in name and "self" not in name and not name.endswith(("_k2", "_pair"))]
 
 
 def _tiled_configs():

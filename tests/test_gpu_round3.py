@@ -232,7 +232,7 @@ def test_gemm_row_amax_side_output_is_the_exact_masked_maximum(M, N, K, act, bia
     lib = _capi.load()
     names = _capi.gemm_config_names()
     try:
-        for cfg in [-1] + [i for i, nm in enumerate(names) if nm.startswith("wr") and not nm.endswith("_k2")]:      # (split-K: own tests, needs a workspace)
+        for cfg in [-1] + [i for i, nm in enumerate(names) if nm.startswith("wr") and not nm.endswith(("_k2", "_pair"))]:      # (split-K: own tests, needs a workspace)
             assert lib.mixq_gemm_set_config(cfg) == 0
             if not mixlib.amax_supported(M, N, K, 1, 2) and cfg == -1:
                 continue

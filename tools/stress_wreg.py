@@ -31,7 +31,7 @@ for (M, N, K, n_out) in [(512, 11008, 4096, 41), (512, 4096, 11008, 110), (200, 
     lib.mixq_gemm_set_config(-1)
     torch.cuda.synchronize()
     cases.append(dict(M=M, N=N, K=K, n_out=n_out, sx=sx, sw=sw, xo=xo, wo=wo, bias=bias, ops8=ops8, ops4=ops4, ref8=ref8, ref4=ref4))
-wr8 = [nm for nm in names if nm.startswith("wr") and "abl" not in nm and "_p" not in nm and "f6" not in nm and "self" not in nm and not nm.endswith("_k2")]
+wr8 = [nm for nm in names if nm.startswith("wr") and "abl" not in nm and "_p" not in nm and "f6" not in nm and "self" not in nm and not nm.endswith(("_k2", "_pair"))]
 wr6 = ["wr128x192_s16_d4_l2", "wr128x128_s16_d4_l2", "wr64x128_s16_d4_l2", "wr64x192_s16_d4_l2", "wr64x256_s16_d4_l2"]
 bad = 0
 side = torch.cuda.Stream()
