@@ -940,7 +940,10 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     // (profiles/r03_prefill_ab.txt); it reads the same F16X64 weight image through a remapped DMA source
     if (wf16) {
         int c;
-        if (pair) c = mixq_wr_pair_config();                             // (a forced configuration does not apply: the one form there is)
+        if (pair) {
+            c = g_forced >= wr0 ? g_forced - wr0 : mixq_wr_pick_pair(M, N, KB);
+            if (!mixq_wr_has_pair(c)) return MIXQ_EINVAL;                // (a forced tiling without the paired epilogue)
+        }
         else if (g_forced >= wr0) c = g_forced - wr0;
         else if (g_forced >= NUM_CFGS) return MIXQ_EINVAL;               // a stream-K form was forced: it takes P16X64 weights only
         else if (g_forced >= 0 || (bit == 8 && !row_amax && prefill_prefers_lds256(M, N))) {

@@ -16,5 +16,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
 int mixq_wr_ksplit_config();                 // its configuration index
 int mixq_wr_ksplit_ok(int M, int N, int KB); // MIXQ_OK when it can run this problem on the current device (workspace, residency), else the reason
 bool mixq_wr_ksplit_pays(int M, int N, int KB);   // ... and the tile model says it is the faster choice
-// the joint gate_proj / up_proj form (MIXQ_ACT_SILU_PAIR: interleaved weight rows, N / 2 output columns): its configuration index
-int mixq_wr_pair_config();
+// the joint gate_proj / up_proj form (MIXQ_ACT_SILU_PAIR: interleaved weight rows, N / 2 output columns): the tiling for a problem, and
+// whether a (forced) configuration has the paired epilogue
+int mixq_wr_pick_pair(int M, int N, int KB);
+bool mixq_wr_has_pair(int c);

@@ -1677,6 +1677,7 @@ struct WrConfig {
     void (*k4)(const WrArgs);
     void (*k6)(const WrArgs);                          // int4 as FP6 codes (MIXQ_FMT_F6X128 operands); nullptr: tiling not built in that form
     int nstage6;                                      // its X ring depth (k-steps of 128 elements, 1.5 KiB blocks)
+    void (*k8p)(const WrArgs);                         // int8 with the paired gate / up epilogue (MIXQ_ACT_SILU_PAIR); nullptr: not built for this tiling
 };
 // (the int4 form expands nibbles in registers: 2 (MB + WNB) more fragment registers, so its weight ring is at most 4 deep)
 #define MIXQ_WR(MBv, WNBv, NS, Dv, LD, ABL, TAG)                                                                        \
@@ -1700,17 +1701,26 @@ struct WrConfig {
       gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, 0>,                \
       gemm_wreg_kernel<MBv, WNBv, NS6, D6, 3, LD, 0>, NS6 }
 
+// ... and with the paired gate / up epilogue (ABL = 90) of the int8 form: the tilings the joint launch of an MLP block picks from
+#define MIXQ_WR6P(MBv, WNBv, NS, Dv, LD, NS6, D6, TAG)                                                                  \
+    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 0>,                                       \
+      gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, 0>,                \
+      gemm_wreg_kernel<MBv, WNBv, NS6, D6, 3, LD, 0>, NS6, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 90> }
+#define MIXQ_WR8P(MBv, WNBv, NS, Dv, LD, TAG)                                                                           \
+    { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 0>, nullptr, nullptr, 0,                  \
+      gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 90> }
+
 const WrConfig g_wr[] = {
     // name = tile (activation rows x weight rows) _ X ring depth _ weight ring depth _ loader waves
-    MIXQ_WR6(8, 3, 16, 4, 2, 8, 2, "128x192_s16_d4_l2"),  // 0: the metric shape's tile: 232 tiles at 512 x 11008
+    MIXQ_WR6P(8, 3, 16, 4, 2, 8, 2, "128x192_s16_d4_l2"), // 0: the metric shape's tile: 232 tiles at 512 x 11008
     MIXQ_WR(8, 3, 16, 3, 2, 0, "128x192_s16_d3_l2"),   // 1
     MIXQ_WR(8, 3, 8, 4, 1, 0, "128x192_s8_d4_l1"),     // 2: the first form of this kernel (8-deep X ring, one loader)
     MIXQ_WR(8, 3, 12, 4, 2, 0, "128x192_s12_d4_l2"),   // 3
     MIXQ_WR6(8, 2, 16, 4, 2, 8, 2, "128x128_s16_d4_l2"),  // 4
-    MIXQ_WR8(8, 4, 16, 3, 2, "128x256_s16_d3_l2"),     // 5 (int8 only)
+    MIXQ_WR8P(8, 4, 16, 3, 2, "128x256_s16_d3_l2"),    // 5 (int8 only)
     MIXQ_WR6(4, 2, 16, 4, 2, 12, 3, "64x128_s16_d4_l2"),  // 6: N = 4096 at M = 512 is exactly 256 such tiles
-    MIXQ_WR6(4, 3, 16, 4, 2, 12, 3, "64x192_s16_d4_l2"),  // 7: N = 6144
-    MIXQ_WR6(4, 4, 16, 4, 2, 12, 3, "64x256_s16_d4_l2"),  // 8
+    MIXQ_WR6P(4, 3, 16, 4, 2, 12, 3, "64x192_s16_d4_l2"), // 7: N = 6144
+    MIXQ_WR6P(4, 4, 16, 4, 2, 12, 3, "64x256_s16_d4_l2"), // 8
     MIXQ_WR(8, 1, 8, 4, 1, 0, "128x64_s8_d4_l1"),      // 9
     MIXQ_WR(4, 1, 8, 4, 1, 0, "64x64_s8_d4_l1"),       // 10
     MIXQ_WR(8, 2, 8, 4, 1, 0, "128x128_s8_d4_l1"),     // 11
@@ -1722,9 +1732,8 @@ const WrConfig g_wr[] = {
     // (profiles/r02_decode.txt)
     // (round 4: with an FP6 form too - 12 stages of 3 KiB, weight ring 4 k-steps of 128 elements (10 k-steps: no faster - the loop's barrier per k-step is what a 2-MFMA k-step waits for) - so a 4-bit layer serves its small
     // batches from the ONE FP6 image it keeps; tools/time_w4_small_batch.py)
-    MIXQ_WR6(2, 1, 8, 6, 1, 12, 4, "32x64_s8_d6_l1"),  // 14 (WR_SMALL)
+    MIXQ_WR6P(2, 1, 8, 6, 1, 12, 4, "32x64_s8_d6_l1"), // 14 (WR_SMALL)
     MIXQ_WR(8, 2, 16, 4, 2, 50, "128x128_s16_d4_l2_k2"),   // 15 (WR_KSPLIT): two workgroups per tile, half of K each (pairwise split-K)
-    { "wr128x192_s16_d4_l2_pair", 8, 3, 16, 2, gemm_wreg_kernel<8, 3, 16, 4, 0, 2, 90>, nullptr, nullptr, 0 },   // 16 (WR_PAIR): gate_proj + up_proj in one launch (96 + 96 interleaved rows per tile, 96 output columns)
 #ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): only in the tools build (make tuning)
     { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
     { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 2>, 8 },
@@ -1778,7 +1787,6 @@ const WrConfig g_wr[] = {
 };
 constexpr int WR_SMALL = 14;
 constexpr int WR_KSPLIT = 15;
-constexpr int WR_PAIR = 16;
 constexpr int NUM_WR = sizeof(g_wr) / sizeof(g_wr[0]);
 #ifdef MIXQ_TUNING
 int g_wr_krot = 0;
@@ -1839,8 +1847,23 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
     return bi;
 }
 
+// The joint gate / up launch (N = the interleaved rows of both layers): the same model over the tilings that have the paired epilogue.
+int mixq_wr_pick_pair(int M, int N, int KB)
+{
+    if (M <= 32) return WR_SMALL;
+    static const struct { int cfg; float tk, fixed; } cand[] = {{0, 0.248f, 8.8f}, {5, 0.341f, 7.1f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f}};
+    const int nk = KB >> 6;
+    double best = 1e30; int bi = 0;
+    for (const auto& c : cand) {
+        const WrConfig& g = g_wr[c.cfg];
+        const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
+        const double t = cdiv(tiles, 256) * (nk * static_cast<double>(c.tk) + c.fixed);    // (the busiest CU's tiles decide: whole rounds)
+        if (t < best * 0.999) { best = t; bi = c.cfg; }
+    }
+    return bi;
+}
+bool mixq_wr_has_pair(int c) { return c >= 0 && c < NUM_WR && g_wr[c].k8p != nullptr; }
 int mixq_wr_ksplit_config() { return WR_KSPLIT; }
-int mixq_wr_pair_config() { return WR_PAIR; }
 // Can the pairwise split-K form (WR_KSPLIT) run (M, N, KB) on the current device?  MIXQ_OK, or why not: both halves of every tile must be
 // resident at once (2 x tiles <= CUs), the workspace registered with mixq_gemm_set_workspace must hold a flag word and an int32 slot per tile.
 int mixq_wr_ksplit_ok(int M, int N, int KB)
@@ -1886,8 +1909,8 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
                    unsigned long long* trace, hipStream_t st, uint32_t* row_amax, const uint32_t* amax_mask)
 {
     if (c < 0 || c >= NUM_WR) return MIXQ_EINVAL;
-    if ((act == MIXQ_ACT_SILU_PAIR) != (c == WR_PAIR)) return MIXQ_EINVAL;  // (the paired epilogue is a kernel form, not a run-time switch)
-    if (c == WR_PAIR && (bit != 8 || (N & 3) || addend)) return MIXQ_EINVAL;
+    const bool pair = act == MIXQ_ACT_SILU_PAIR;                            // (the paired epilogue is a kernel form, not a run-time switch)
+    if (pair && (bit != 8 || (N & 3) || addend)) return MIXQ_EINVAL;
     const WrConfig& g = g_wr[c];
     WrArgs a;
     memset(&a, 0, sizeof(a));
@@ -1911,7 +1934,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     }
     a.trace = trace;
     a.row_amax = row_amax; a.amax_mask = amax_mask;
-    void (*k)(const WrArgs) = bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4);
+    void (*k)(const WrArgs) = pair ? g.k8p : (bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4));
     if (!k) return MIXQ_EINVAL;
     int units = a.tiles_m * a.tiles_n;
     if (c == WR_KSPLIT) {

@@ -106,6 +106,20 @@ def test_one_launch_for_gate_and_up_against_the_oracle_and_the_two_launch_route(
     assert (np.abs(y - ref) <= ulp_tol(ref)).all(), float(np.abs(y - ref).max())
     y2 = _two_launches(c)
     assert torch.equal(y1, y2), int((y1 != y2).sum())
+    if M * N > 2e6:
+        return
+    lib, names = _capi.load(), _capi.gemm_config_names()                # every tiling that has the paired epilogue, forced
+    forms = ("wr128x192_s16_d4_l2", "wr128x256_s16_d3_l2", "wr64x192_s16_d4_l2", "wr64x256_s16_d4_l2", "wr32x64_s8_d6_l1")
+    try:
+        for nm in forms:
+            assert lib.mixq_gemm_set_config(names.index(nm)) == 0
+            y3 = _one_launch(c)
+            assert torch.equal(y3, y2), (nm, int((y3 != y2).sum()))
+        assert lib.mixq_gemm_set_config(names.index("wr128x128_s16_d4_l2")) == 0      # a tiling without it: refused
+        with pytest.raises(_capi.MixqError):
+            _one_launch(c)
+    finally:
+        lib.mixq_gemm_set_config(-1)
 
 
 def test_row_maxima_for_down_proj_leave_the_joint_launch_as_they_leave_gate_projs():

@@ -23,6 +23,7 @@ ap.add_argument("--outliers", type=int, default=41)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--amax", action="store_true", help="both arms also leave down_proj's row maxima")
+ap.add_argument("--cfgs", default="", help="comma-separated tilings to force for extra one-launch arms (e.g. wr128x256_s16_d3_l2)")
 args = ap.parse_args()
 K, N = (int(v) for v in args.shape.split(","))
 M, n_out = args.tokens, args.outliers
@@ -70,14 +71,23 @@ if args.amax:
     assert torch.equal(amax_a, amax_b)
 st = torch.cuda.Stream()
 graphs = {}
-for name, fn in (("two launches (up, gate x up)", two), ("one launch (interleaved rows)", one)):
+lib = _capi.load()
+names = _capi.gemm_config_names()
+arms = [("two launches (up, gate x up)", two, -1), ("one launch (interleaved rows)", one, -1)]
+arms += [(f"one launch, {c}", one, names.index(c)) for c in args.cfgs.split(",") if c]
+for name, fn, cfg in arms:
+    assert lib.mixq_gemm_set_config(cfg) == 0
     with torch.cuda.stream(st):
         fn()
+        if cfg >= 0:
+            torch.cuda.synchronize()
+            assert torch.equal(y_a, y_b), name
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr, stream=st):
             for _ in range(args.steps):
                 fn()
     graphs[name] = gr
+lib.mixq_gemm_set_config(-1)
 res = {k: [] for k in graphs}
 first = {}
 with torch.cuda.stream(st):
@@ -89,4 +99,4 @@ with torch.cuda.stream(st):
 print(f"gate_proj + up_proj, {M} tokens, {K} -> {N} (x2), {n_out} outlier columns{', with row maxima' if args.amax else ''}; "
       f"{args.steps} steps per graph, {args.rounds} interleaved rounds; outputs bit-identical")
 for name, v in res.items():
-    print(f"  {name:32s} median {statistics.median(v):7.2f} us   min {min(v):7.2f}   (first replay {first[name]:.2f})   all: " + " ".join(f"{x:.2f}" for x in v))
+    print(f"  {name:44s} median {statistics.median(v):7.2f} us   min {min(v):7.2f}   (first replay {first[name]:.2f})   all: " + " ".join(f"{x:.2f}" for x in v))
