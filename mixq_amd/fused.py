@@ -11,11 +11,15 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import linear as _L
 from . import mixlib as _hip_mixlib
 
 _backend = _hip_mixlib
 # gate_proj's GEMM also emits down_proj's per-row |x| maxima (include/mixq_hip.h: mixq_gemm_i8_fused_amax); False = the two-pass quantiser
 FUSE_DOWN_AMAX = True
+# gate_proj + up_proj of MixLlamaMLP as one launch over an interleaved weight image once both predictions are frozen (int8 layers);
+# False = up_proj's launch, then gate_proj's with the SiLU-and-multiply epilogue
+JOINT_GATE_UP = True
 
 
 def set_backend(mod):
@@ -79,6 +83,23 @@ class FasterTransformerRMSNorm(nn.Module):
         return output
 
 
+class _JointRows:
+    """What a layer's `_Derived.joint` holds once its weights live in the MLP block's joint image: how to get its own rows back."""
+
+    __slots__ = ("owner", "which")
+
+    def __init__(self, owner, which):
+        self.owner, self.which = owner, which
+
+    def plain_rows(self):
+        j = self.owner._joint
+        if j is None:
+            raise RuntimeError("MixLlamaMLP: the joint gate / up image this layer's weights live in is gone")
+        w = j["wpk"]
+        plain = _backend.UnpackOperand(w, j["rows"]) if w.is_cuda else _L._unpack_host(w, j["rows"], _L._fmt_of(w))
+        return split_pair_rows(plain)[self.which].contiguous()
+
+
 class MixLlamaMLP(nn.Module):
     def __init__(self, gate_proj, down_proj, up_proj, MixGemmCache=None):
         super().__init__()
@@ -87,9 +108,121 @@ class MixLlamaMLP(nn.Module):
         self.up_proj_ = up_proj
         self.out_features = down_proj.out_features
         self.MLPCache = MixGemmCache
+        # gate_proj and up_proj as ONE launch (MIXQ_ACT_SILU_PAIR): the interleaved operands, built at the first forward after both
+        # layers' outlier predictions froze.  A plain attribute, not a buffer: the state_dict stays the reference's (two q_weight tensors)
+        object.__setattr__(self, "_joint", None)
+
+    # ---- gate_proj + up_proj in one launch -------------------------------------------------------------------------------
+    def _joint_key(self):
+        up, gate = self.up_proj_, self.gate_proj_
+
+        def ident(t):
+            return None if t is None else (id(t), t._version, tuple(t.shape))
+        return tuple((ident(l._buffers.get("q_weight")), ident(l.scale_col), ident(l.bias), ident(l.weight_cache), ident(l.ind))
+                     for l in (up, gate)) + (str(up.scale_col.device), _L.PACK_FMT)
+
+    def _joint_applies(self, cache):
+        up, gate = self.up_proj_, self.gate_proj_
+        if not JOINT_GATE_UP or not getattr(_backend, "PAIR_LAUNCH", False):
+            return False
+        if up.bit != 8 or gate.bit != 8 or up.weight_only or gate.weight_only or up.add_outliers or _L.PACK_FMT != _L.FMT_F16X64:
+            return False
+        if up.in_features % 64 or up.out_features % 8 or (up.in_features, up.out_features) != (gate.in_features, gate.out_features):
+            return False
+        n = int(up.ind.shape[0])
+        if n and (gate.forward_without_precondition_len != n or gate.weight_cache is None or gate.weight_cache.shape[1] != n
+                  or up.weight_cache is None or up.weight_cache.shape[1] != n):
+            return False                                     # (gate_proj has not taken over the latest outlier columns yet: its own route does that)
+        return _L._fmt_of(cache.q_xcache) == _L.FMT_P16X64
+
+    def _joint_operands(self):
+        """The interleaved image + per-channel operands (interleave_pair_rows), rebuilt when anything they were made from changed.  The
+        two layers then give up their own packed images: the block keeps ONE copy of these weights."""
+        key = self._joint_key()
+        j = self._joint
+        if j is not None and j["key"] == key:
+            return j
+        up, gate = self.up_proj_, self.gate_proj_
+        N, n = up.out_features, int(up.ind.shape[0])
+        wpk = _backend.PackOperand(interleave_pair_rows(up.q_weight, gate.q_weight), _L.FMT_F16X64)
+        scale = interleave_pair_rows(up.scale_col.reshape(-1), gate.scale_col.reshape(-1)).reshape(1, -1)
+        bias = None
+        if up.bias is not None or gate.bias is not None:
+            zero = torch.zeros((N,), dtype=torch.float16, device=scale.device)
+            bias = interleave_pair_rows(zero if up.bias is None else up.bias, zero if gate.bias is None else gate.bias)
+        wo = None
+        if n:
+            wo = torch.zeros((2 * N, _L._pad16(n)), dtype=torch.float16, device=scale.device)
+            wo[:, :n] = interleave_pair_rows(up.weight_cache, gate.weight_cache)
+            wo = wo[:, :n]
+        old = self._joint
+        j = {"wpk": wpk, "rows": 2 * N, "scale": scale, "bias": bias, "wo": wo,
+             "retired": ([] if old is None else old["retired"] + [old["wpk"], old["wo"]])}      # (captured graphs may still address them)
+        object.__setattr__(self, "_joint", j)
+        for which, l in enumerate((up, gate)):
+            d = l._d
+            if d.wpk is not None:
+                d.retired.append(d.wpk)
+            d.invalidate()                                   # (kept argument blocks carry the old image's address)
+            d.wpk = d.wpk_key = None
+            d.joint = _JointRows(self, which)
+            if _L.COMPACT_WEIGHTS:
+                l._buffers["q_weight"] = None
+        j["key"] = self._joint_key()
+        return j
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        j = self._joint
+        if j is not None:                                    # the joint image is the only copy of gate_proj's / up_proj's weights: it follows the module
+            w = fn(j["wpk"])
+            if w is not j["wpk"] and hasattr(_backend, "set_fmt"):
+                _backend.set_fmt(w, _L._fmt_of(j["wpk"]))
+            j["wpk"], j["key"], j["retired"] = w, None, []   # (the per-channel operands are re-made from the moved layers)
+        return out
+
+    def _forward_joint(self, x, cache):
+        up, gate, down = self.up_proj_, self.gate_proj_, self.down_proj_
+        inputs = x.reshape(-1, x.shape[-1])
+        M, N, K = inputs.shape[0], up.out_features, up.in_features
+        cache.shape = x.shape[:-1] + (N,)                    # (what up_proj's forward leaves: linear.py:169-172)
+        if getattr(cache, "n_dev", None) is not up._n_dev:
+            cache.n_dev = None
+        cache.ind = up.ind
+        j = self._joint_operands()
+        n = int(up.ind.shape[0])
+        xo = wo = n_dev = None
+        n_cap = 0
+        if n:
+            xo = cache.activation_outliers
+            if xo is None or xo.shape[1] != n:
+                raise RuntimeError("MixLlamaMLP: outlier operands do not match `ind`")
+            xo, wo = _L._gemm_ready(xo), j["wo"]
+            cap = min(_L._pad16(n), xo.stride(0), wo.stride(0))
+            if cache.n_dev is not None and cap > n:
+                n_dev, n_cap = up._n_dev, cap
+            else:
+                n_cap = n
+            xo, wo = _L._wide(xo, n_cap), _L._wide(wo, n_cap)
+        extra = {}
+        target = None
+        if FUSE_DOWN_AMAX and down.bit == 8 and down.in_features == N and hasattr(_backend, "amax_supported") and \
+                _backend.amax_supported(M, 2 * N, K, _L.FMT_P16X64, _L.FMT_F16X64):
+            target = down.amax_target(M, x.device)
+            if target is not None:
+                extra = {"row_amax": target[0], "col_mask": target[1]}
+        y = _backend.FusedLinear(cache.q_xcache, j["wpk"], cache.x_scale, j["scale"], xo, wo, n_cap, j["bias"], M, 2 * N, K, bit=8,
+                                 act=_hip_mixlib.ACT_SILU_PAIR, n_out_dev=n_dev, **extra)
+        out = y.reshape(cache.shape)
+        if target is not None:
+            out._mixq_row_amax = (target[0], down, out._version)
+        return out
 
     @torch.no_grad()
     def forward(self, x):
+        if self._joint_applies(self.MLPCache):
+            # silu(gate(x)) * up(x) from ONE launch over the two layers' interleaved rows (mlp.py:57-63), bit-identical to the route below
+            return self.down_proj_(self._forward_joint(x, self.MLPCache), None, True)
         up_output = self.up_proj_(x, self.MLPCache)
         # silu(gate(x)) * up(x) in gate_proj's epilogue (the reference multiplies in a separate pass, mlp.py:61-63)
         # ... and down_proj's pre-pass row maxima leave the same epilogue (its quantiser then needs one pass over the activation)

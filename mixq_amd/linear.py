@@ -140,13 +140,15 @@ class _Derived:
       cmask             bit-per-input-column mask of `ind` (a producer's row-maximum side output)
       amax_buf          int32 row maxima left by the GEMM that produced this layer's input; allocated ONCE at the cache's row capacity
       plan(s)           kept argument blocks of the one-call forward (raw device addresses of everything above)
+      joint             set by MixLlamaMLP (fused.py) once this layer's weights live in the block's joint gate / up image: the layer then
+                        keeps NO image of its own (`wpk` None) and re-creates rows from that image on the cold paths
 
     Each derived item carries the identity (`id`, `data_ptr`, `_version`) of what it was made from and is rebuilt when that changes;
     `invalidate` is the single place that drops them - and every call of it drops the kept argument blocks, which hold addresses of
     all the others."""
 
     __slots__ = ("wpk", "wpk_key", "wpk_small", "wpk_small_key", "wo_ready", "wo_key", "ind_buf", "ind_key", "n_dev", "n_dev_host",
-                 "cmask", "cmask_key", "amax_buf", "amax_dirty", "plan", "plan_key", "plans", "retired")
+                 "cmask", "cmask_key", "amax_buf", "amax_dirty", "plan", "plan_key", "plans", "retired", "joint")
 
     def __init__(self):
         self.wpk = self.wpk_key = self.wpk_small = self.wpk_small_key = None
@@ -157,6 +159,7 @@ class _Derived:
         self.plan = self.plan_key = None
         self.plans = {}
         self.retired = []                     # superseded device buffers a captured graph may still address: kept alive, never re-used
+        self.joint = None
 
     def invalidate(self, weights=False, outliers=False, device=False):
         """weights: the weight bytes or their layout changed (checkpoint load into a compacted layer); outliers: `ind` / `weight_cache`
@@ -166,6 +169,7 @@ class _Derived:
         if weights or device:
             if weights:
                 self.wpk = None
+                self.joint = None             # (new weight bytes: the block re-builds its joint image from them)
             self.wpk_key = None
             self.wpk_small = self.wpk_small_key = None
         if outliers or device:
@@ -321,7 +325,8 @@ class MixLinear_GEMM(nn.Module):
         if name == "q_weight":
             d = self.__dict__
             bufs = d.get("_buffers")
-            if bufs is not None and "q_weight" in bufs and bufs["q_weight"] is None and "_d" in d and d["_d"].wpk is not None:
+            if bufs is not None and "q_weight" in bufs and bufs["q_weight"] is None and "_d" in d and \
+                    (d["_d"].wpk is not None or d["_d"].joint is not None):
                 return self._plain_weight()
         return super().__getattr__(name)
 
@@ -330,6 +335,8 @@ class MixLinear_GEMM(nn.Module):
         columns after compaction).  A fresh tensor every time: writes to it do not reach the layer - load_state_dict does."""
         if self.weight_only:
             raise RuntimeError("weight-only layers keep their plain q_weight")
+        if self._wpk is None and self._d.joint is not None:
+            return self._d.joint.plain_rows()                            # this layer's rows of the MLP block's joint gate / up image
         if not self._wpk.is_cuda:
             # the module was moved to the host (model.cpu() before saving): the re-tiling is pure index arithmetic, done in torch
             return _unpack_host(self._wpk, self.out_features, _fmt_of(self._wpk))
@@ -339,17 +346,20 @@ class MixLinear_GEMM(nn.Module):
         """Drop the plain [N,K] copy of q_weight, keeping only the packed image (half the weight memory of the first round)."""
         if self.weight_only or self._buffers.get("q_weight") is None:
             return self
+        if self._d.joint is not None and self._wpk is None:
+            self._buffers["q_weight"] = None                             # (the joint image holds these rows)
+            return self
         if self._packed_weight() is not None:
             self._buffers["q_weight"] = None
         return self
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         super()._save_to_state_dict(destination, prefix, keep_vars)
-        if "q_weight" in self._buffers and self._buffers["q_weight"] is None and self._wpk is not None:
+        if "q_weight" in self._buffers and self._buffers["q_weight"] is None and (self._wpk is not None or self._d.joint is not None):
             destination[prefix + "q_weight"] = self._plain_weight()      # the reference's on-disk layout (base.py:78-119)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
-        compacted = "q_weight" in self._buffers and self._buffers["q_weight"] is None and self._wpk is not None
+        compacted = "q_weight" in self._buffers and self._buffers["q_weight"] is None and (self._wpk is not None or self._d.joint is not None)
         if compacted:
             key = prefix + "q_weight"
             if key not in state_dict:
@@ -364,7 +374,7 @@ class MixLinear_GEMM(nn.Module):
                                       f"the shape in current model is {(self.out_features, KB)} ({want_dtype}).")
                     state_dict = {k: v for k, v in state_dict.items() if k != key}
                 else:
-                    self._buffers["q_weight"] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self._wpk.device)
+                    self._buffers["q_weight"] = torch.empty(tuple(src.shape), dtype=src.dtype, device=self.scale_col.device)
                     self._d.invalidate(weights=True)                     # re-packed on the next forward; kept plans pin the old images
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
@@ -402,6 +412,8 @@ class MixLinear_GEMM(nn.Module):
 
     def x_fmt(self, M=None):
         """Layout this layer wants its quantised activation in for a batch of M rows (what a fused norm in front of it should emit)."""
+        if self._d.joint is not None and self._wpk is None and self._buffers.get("q_weight") is None:
+            return FMT_P16X64                                            # (the joint gate / up image is fragment-order int8: as below)
         wpk = self._packed_weight(M)
         if wpk is None:
             return FMT_PLAIN
@@ -434,6 +446,9 @@ class MixLinear_GEMM(nn.Module):
             return self._packed_small()
         qw = self._buffers.get("q_weight")
         if qw is None:
+            if self._wpk is None and self._d.joint is not None:
+                # the layer is used on its own again (its MLP block took the joint route before): its own image, from the joint one
+                self._wpk = _backend.PackOperand(self._plain_weight(), PACK_FMT if self.bit == 8 else PACK_FMT4)
             return self._wpk                                             # compacted: the packed image is all there is
         if qw.shape[1] % 64 or not hasattr(_backend, "PackOperand"):
             return None
@@ -555,6 +570,10 @@ class MixLinear_GEMM(nn.Module):
         for k in _Derived.__slots__:
             setattr(d, k, getattr(self._d, k))
         d.plan, d.plan_key, d.plans, d.retired = None, None, {}, []
+        if d.joint is not None:                              # (the copy stands alone: its own image instead of a reference into the MLP block's)
+            if d.wpk is None and self._buffers.get("q_weight") is None:
+                d.wpk = _backend.PackOperand(self._plain_weight(), PACK_FMT if self.bit == 8 else PACK_FMT4)
+            d.joint = None
         state["_d"] = d
         return state
 

@@ -695,6 +695,9 @@ def DequantWeightCols(q_w, scale_col, ind, bit, out=None):
     return out
 
 
+PAIR_LAUNCH = True                       # FusedLinear serves ACT_SILU_PAIR (fused.MixLlamaMLP asks before taking its joint gate / up route)
+
+
 def amax_supported(M, N, K, x_fmt, w_fmt):
     """True when the GEMM can leave the next layer's row maxima as a side output for this problem (mixq_gemm_amax_supported)."""
     if x_fmt != FMT_P16X64 or w_fmt != FMT_F16X64:

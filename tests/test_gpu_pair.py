@@ -151,3 +151,95 @@ def test_operands_the_joint_form_does_not_serve_are_refused_not_miscomputed():
     with pytest.raises(RuntimeError):
         mixlib.FusedLinear(qx, mixlib.PackOperand(j, 2), sx, sw, None, None, 0, None, 64, 192, 128, act=_capi.ACT_SILU_PAIR,
                            addend=torch.zeros((64, 96), dtype=torch.float16, device=DEV))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the MLP block (mixquant/modules/fused/mlp.py:37-70) on the joint route
+# ---------------------------------------------------------------------------------------------------------------
+def _block(M, H, F, bias, seed=0):
+    from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP
+    torch.manual_seed(seed)
+    cache = MixLibCache(M, device=DEV)
+    mk = lambda k, nn_: MixLinear_GEMM.from_linear(torch.nn.Linear(k, nn_, bias=bias).half(), 8, cache=cache, dev=DEV)
+    gate, up, down = mk(H, F), mk(H, F), mk(F, H)
+    inner = MixLlamaMLP(gate, down, up, cache)
+    norm = FasterTransformerRMSNorm((torch.rand(H) + 0.5).half().to(DEV), 1e-5, cache)
+    norm.next_layer = up
+    g = torch.Generator().manual_seed(seed + 1)
+    cols = torch.randperm(H, generator=g)[:5]
+    xs = []
+    for _ in range(5):
+        x = torch.randn(M, H, generator=g).half()
+        x[:, cols] *= 20
+        xs.append(x)
+    return inner, norm, cache, xs
+
+
+@pytest.mark.parametrize("M,bias", [(96, True), (512, False), (20, False)])
+def test_mlp_block_on_the_joint_route_is_bit_identical_and_keeps_one_weight_image(M, bias):
+    from mixq_amd import fused
+    H, F = 512, 1536
+    inner, norm, cache, xs = _block(M, H, F, bias)
+    up, gate, down = inner.up_proj_, inner.gate_proj_, inner.down_proj_
+    mlp = lambda x: inner(norm(x))
+    prev = fused.JOINT_GATE_UP
+    try:
+        fused.JOINT_GATE_UP = False
+        for x in xs[:3]:
+            mlp(x.clone().to(DEV))                                    # freeze every layer's outlier search
+        assert not up.add_outliers and not down.add_outliers
+        q_up, q_gate = up.q_weight.clone(), gate.q_weight.clone()     # (re-created from the layers' own images)
+        y_ref = [mlp(x.clone().to(DEV)) for x in xs[3:]]
+        sx_ref = cache.x_scale[:M].clone()
+        assert inner._joint is None and up._wpk is not None
+        fused.JOINT_GATE_UP = True
+        y = [mlp(x.clone().to(DEV)) for x in xs[3:]]
+        assert inner._joint is not None, "the joint route did not run"
+        assert all(torch.equal(a, b) for a, b in zip(y, y_ref)) and torch.equal(cache.x_scale[:M], sx_ref)
+        # ONE copy of gate_proj's / up_proj's weights: the interleaved image; the state_dict is still the reference's
+        assert up._wpk is None and gate._wpk is None and up._buffers["q_weight"] is None and gate._buffers["q_weight"] is None
+        sd = inner.state_dict()
+        assert torch.equal(sd["up_proj_.q_weight"], q_up) and torch.equal(sd["gate_proj_.q_weight"], q_gate)
+        # under hipGraph replay
+        side = torch.cuda.Stream()
+        xg = xs[4].clone().to(DEV)
+        keep = xg.clone()
+        with torch.cuda.stream(side):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                yg = mlp(xg)
+            for _ in range(3):
+                xg.copy_(keep)
+                gr.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(yg, y_ref[1])
+        # a layer used on its own again gets its own image back (from the joint one) and computes what it always did
+        fused.JOINT_GATE_UP = False
+        y2 = mlp(xs[3].clone().to(DEV))
+        assert torch.equal(y2, y_ref[0]) and up._wpk is not None
+    finally:
+        fused.JOINT_GATE_UP = prev
+
+
+def test_new_weights_loaded_into_a_block_on_the_joint_route_reach_the_joint_image():
+    M, H, F = 64, 256, 512
+    a, norm_a, cache_a, xs = _block(M, H, F, False, seed=0)
+    b, norm_b, cache_b, _ = _block(M, H, F, False, seed=5)            # other weights
+    for blk, nrm in ((a, norm_a), (b, norm_b)):
+        for x in xs[:3]:
+            blk(nrm(x.clone().to(DEV)))
+    assert a._joint is not None and b._joint is not None
+    norm_b.weight.copy_(norm_a.weight)
+    y_a = a(norm_a(xs[3].clone().to(DEV)))
+    y_b0 = b(norm_b(xs[3].clone().to(DEV)))
+    assert not torch.equal(y_a, y_b0)
+    sd = a.state_dict()
+    missing, unexpected = b.load_state_dict(sd, strict=False)
+    assert not unexpected
+    for la, lb in ((a.up_proj_, b.up_proj_), (a.gate_proj_, b.gate_proj_), (a.down_proj_, b.down_proj_)):   # (plain attributes of 8-bit layers: base.py:78-119 saves them by hand)
+        lb.ind, lb.weight_cache = la.ind.clone(), (None if la.weight_cache is None else la.weight_cache.clone())
+        lb.forward_without_precondition_len = la.forward_without_precondition_len
+        lb._d.invalidate(outliers=True)
+    y_b = b(norm_b(xs[3].clone().to(DEV)))
+    assert torch.equal(y_b, y_a)
+    assert b.up_proj_._wpk is None and b.up_proj_._buffers["q_weight"] is None       # ... and the block is back to one image
