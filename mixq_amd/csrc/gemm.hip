@@ -896,7 +896,7 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     if (act == MIXQ_ACT_SILU_MUL && !addend) return MIXQ_EINVAL;            // the multiplier is mandatory
     const bool pair = act == MIXQ_ACT_SILU_PAIR;                            // interleaved gate / up rows: y has N / 2 columns
     if (pair && addend) return MIXQ_EINVAL;
-    if (pair && (bit != 8 || !wf16 || (N & 15))) return MIXQ_ESHAPE;        // (one kernel form: int8, fragment-order weights)
+    if (pair && (!((bit == 8 && wf16) || f6) || (N & 15))) return MIXQ_ESHAPE;   // (the weights-in-registers kernels: int8 fragment-order weights, or FP6 codes)
     const int KB = bit == 8 ? K : K / 2;
     if ((KB % 64) || (bit == 4 && (K & 1)) || (N & 3) || (ldy & 3) || ldy < (pair ? N / 2 : N)) return MIXQ_ESHAPE;
     if (addend && lda != 0 && lda < N) return MIXQ_EINVAL;
@@ -919,7 +919,8 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     if (f6) {
         if (row_amax) return MIXQ_ESHAPE;
         if (g_forced >= 0 && g_forced < wr0) return MIXQ_EINVAL;                // only the weights-in-registers kernels read this format
-        const int c = g_forced >= wr0 ? g_forced - wr0 : mixq_wr_pick(6, M, N, KB);
+        const int c = g_forced >= wr0 ? g_forced - wr0 : (pair ? mixq_wr_pick_pair(6, M, N, KB) : mixq_wr_pick(6, M, N, KB));
+        if (pair && !mixq_wr_has_pair(6, c)) return MIXQ_EINVAL;
         return mixq_wr_launch(c, 6, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                               ldy, M, N, KB, act, g_trace, mixq_stream(stream), nullptr, nullptr);
     }
@@ -941,8 +942,8 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
     if (wf16) {
         int c;
         if (pair) {
-            c = g_forced >= wr0 ? g_forced - wr0 : mixq_wr_pick_pair(M, N, KB);
-            if (!mixq_wr_has_pair(c)) return MIXQ_EINVAL;                // (a forced tiling without the paired epilogue)
+            c = g_forced >= wr0 ? g_forced - wr0 : mixq_wr_pick_pair(8, M, N, KB);
+            if (!mixq_wr_has_pair(8, c)) return MIXQ_EINVAL;                // (a forced tiling without the paired epilogue)
         }
         else if (g_forced >= wr0) c = g_forced - wr0;
         else if (g_forced >= NUM_CFGS) return MIXQ_EINVAL;               // a stream-K form was forced: it takes P16X64 weights only

@@ -18,5 +18,5 @@ int mixq_wr_ksplit_ok(int M, int N, int KB); // MIXQ_OK when it can run this pro
 bool mixq_wr_ksplit_pays(int M, int N, int KB);   // ... and the tile model says it is the faster choice
 // the joint gate_proj / up_proj form (MIXQ_ACT_SILU_PAIR: interleaved weight rows, N / 2 output columns): the tiling for a problem, and
 // whether a (forced) configuration has the paired epilogue
-int mixq_wr_pick_pair(int M, int N, int KB);
-bool mixq_wr_has_pair(int c);
+int mixq_wr_pick_pair(int bit, int M, int N, int KB);   // bit: 8, or 6 (int4 as FP6 codes)
+bool mixq_wr_has_pair(int bit, int c);

@@ -89,6 +89,9 @@ template <int I, int N, class F> __device__ __forceinline__ void wr_static_for(F
 template <int MB, int WNB, int NSTAGE, int D, int Q, int LOADERS, int ABL>
 __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const WrArgs a)
 {
+    // ABL = 90 is not an ablation but a kernel FORM - the paired gate / up epilogue (PAIR below) on the shipped loop: everywhere else in this
+    // body the loop variant is ABLK, which reads 0 for it
+    constexpr int ABLK = ABL == 90 ? 0 : ABL;
     constexpr int CW = WR_CW;
     constexpr int NT = (CW + LOADERS) * 64;
     constexpr int BM = MB * 16, WN = WNB * 16, BN = CW * WN;
@@ -111,9 +114,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // tables.  The tuple-ring FP6 form and the int8 form of the shipped loop: -0.8 ... -3.2 % over the BASELINE shapes between two product
     // builds (-1.3 % at the metric shape; profiles/r03_ab_wrap_tail.txt; -DMIXQ_NO_WRAP_TAIL builds the other one).
 #ifdef MIXQ_NO_WRAP_TAIL
-    constexpr bool WRAP = F6R || ABL == 41;
+    constexpr bool WRAP = F6R || ABLK == 41;
 #else
-    constexpr bool WRAP = F6R || ABL == 41 || (Q == 0 && (ABL == 0 || ABL == 6 || (ABL >= 60 && ABL < 80) || ABL == 90) && LOADERS != 0);
+    constexpr bool WRAP = F6R || ABLK == 41 || (Q == 0 && (ABLK == 0 || ABLK == 6 || (ABLK >= 60 && ABLK < 80) || ABLK == 90) && LOADERS != 0);
 #endif
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int LOADS = STAGE_BYTES / 1024 / ISSUERS;  // 1 KiB DMA pieces per issuing wave and stage
     constexpr int TLOADS = MB / ISSUERS;                 // the fp16 tail's X_out blocks per issuing wave
     constexpr int WL = F6 ? 2 * WNB : WNB;               // load instructions of one k-step's weight fragments (per wave)
-    // PAIR (ABL = 90; MIXQ_ACT_SILU_PAIR): gate_proj and up_proj of an MLP block as ONE GEMM.  The weight rows are interleaved in groups of
+    // PAIR (ABLK = 90; MIXQ_ACT_SILU_PAIR): gate_proj and up_proj of an MLP block as ONE GEMM.  The weight rows are interleaved in groups of
     // four - up[2g], up[2g+1], gate[2g], gate[2g+1] (scale_col, bias and weight_cache rows likewise) - so the four consecutive channels a
     // lane holds of a 16 x 16 accumulator block ARE the two (up, gate) pairs of output channels 2g, 2g+1: the product
     // (silu(gate) + bias_gate) * fp16(up + bias_up) is lane-local, leaves the epilogue as ONE packed fp16 pair, and the tile stages and
@@ -149,32 +152,32 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // flags and copy staged panels out to Y with 16-byte nt row stores while the consumers work on the next panels, so only the last
     // panels' stores (shared by all six waves behind the one closing barrier) are exposed behind the arithmetic.
     // Same operations per element in the same order as the first form (kept for the fat prefill tile, the pairwise split-K form and as
-    // the tuning build's A/B partner, ABL 60): bit-identical (tests/test_gpu_round4.py).
+    // the tuning build's A/B partner, ABLK 60): bit-identical (tests/test_gpu_round4.py).
     constexpr int PJ = MB >= 2 ? 2 : 1, NPAN = MB / PJ, PROWS = PJ * 16;
     // panels the loader waves copy out on their own (the rest is shared by all waves behind the final barrier: the path to memory takes
     // ~30 cycles per KiB stored, about as long as the consumers need to produce it, so two waves cannot drain more than half the tile in time)
     // (Tried and dropped, profiles/r04_ab_direct_stores.txt: no staging at all - block pairs exchanged between lanes with v_permlane16_swap so
     // that a lane holds 16 contiguous bytes, stored straight from registers as 64- / 32-byte row segments.  Bit-identical, 28.6 vs 24.6 us:
     // the memory system chokes on partial-line writes; full 384-byte row segments out of LDS are what it takes.)
-    constexpr int LP = (SELF || NPAN < 3) ? 0 : (ABL == 61 ? 0 : (ABL == 67 ? NPAN - 1 : NPAN - 2));   // (NPAN - 1, probe 67: the consumers end up waiting for the loaders: 24.14 vs 23.94 us)
+    constexpr int LP = (SELF || NPAN < 3) ? 0 : (ABLK == 61 ? 0 : (ABLK == 67 ? NPAN - 1 : NPAN - 2));   // (NPAN - 1, probe 67: the consumers end up waiting for the loaders: 24.14 vs 23.94 us)
     constexpr int FLAG_OFF = TAILX + TQ * MB * 1024;     // LDS: "panel p staged by consumer wave w" words [NPAN][CW], behind the tail's X_out blocks
     // EPI2: the epilogue's scales (x_scale of the tile's rows, scale_col and bias of its columns) do not ride through the k loop in the
     // consumers' registers (20 VGPRs of the 128 x 192 tile, 14 requests and their address arithmetic in front of its second weight
     // request): a loader wave brings them into LDS by 16-bit LDS-DMA - one dword slot per element, zero-extended; rows past M and columns
     // past N read as zero through the buffer descriptor's range check - while the main loop runs, and the epilogue reads them from there.
     constexpr int SX_OFF = FLAG_OFF + 64, SW_OFF = SX_OFF + BM * 4, BI_OFF = SW_OFF + BN * 4, SC_END = BI_OFF + BN * 4;
-    constexpr bool EPI2 = !SELF && ABL != 50 && ABL != 60 && (MB % PJ == 0) &&
+    constexpr bool EPI2 = !SELF && ABLK != 50 && ABLK != 60 && (MB % PJ == 0) &&
                           (((BM * OPITCH + 15) & ~15) + WR_CW * 4 * BM * 4 <= TAILX);   // (the staged tile and the row-maximum slots stay clear of the tail's X_out blocks)
     static_assert(MB % ISSUERS == 0 && (STAGE_BYTES / 1024) % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
-    static_assert(!F6 || (!SELF && (ABL == 0 || ABL == 1 || ABL == 2 || ABL == 3)), "the FP6 form exists for the shipped loop (and its feed ablations) only");
-    static_assert(!F6R || ABL == 0, "the tuple-ring form has no ablations");
+    static_assert(!F6 || (!SELF && (ABLK == 0 || ABLK == 1 || ABLK == 2 || ABLK == 3)), "the FP6 form exists for the shipped loop (and its feed ablations) only");
+    static_assert(!F6R || ABLK == 0, "the tuple-ring form has no ablations");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
-    static_assert(!SELF || (LOOK == D + 1 && !I4 && ABL == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
+    static_assert(!SELF || (LOOK == D + 1 && !I4 && ABLK == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
     static_assert(!EPI2 || SC_END <= 160 * 1024, "X ring + tail blocks + panel flags + scales must fit the 160 KiB of LDS");
-    static_assert(!PAIR || (EPI2 && Q == 0), "the paired gate / up epilogue exists in the panel form of the int8 kernel only");
+    static_assert(!PAIR || (EPI2 && (Q == 0 || Q == 3)), "the paired gate / up epilogue exists in the panel form of the int8 and the FP6 tuple-ring kernels");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if constexpr (ABL == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
+    if constexpr (ABLK == 9) { if (a.act != 12345) return; }                      // launch floor of this grid / LDS footprint
     // Every argument the prologue needs, asked for in the FIRST basic block: the compiler requests a kernel argument where it is first used,
     // one scalar load per use site with a wait behind each (nine dependent round trips to a cold scalar cache in front of the first
     // operand request: ~0.3 us of the 1.0 us between entry and the first k-step); named together here they become a few wide loads and ONE wait.
@@ -183,13 +186,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                  "s"(a.mg_last), "s"(a.ldy), "s"(a.y));
     const bool staged = (((PAIR ? a.N >> 1 : a.N) & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
 
-    // KS (ABL = 50): pairwise split-K.  Long-K layers with few output tiles (11008 -> 4096 at 512 tokens: 128 tiles of 128 x 128, half the
+    // KS (ABLK = 50): pairwise split-K.  Long-K layers with few output tiles (11008 -> 4096 at 512 tokens: 128 tiles of 128 x 128, half the
     // CUs idle, or 256 tiles of 64 x 128 at a third fewer MACs per operand byte) run TWO workgroups per tile, each over half of K: the
     // second publishes its int32 accumulators (register order, write-through 16-byte stores) into the tile's workspace slot and raises the
     // tile's flag, the first adds them to its own and runs the epilogue.  Integer sums: exact in any order, the result is bit-identical.
     // The hand-off costs 2.9 us between partners on one XCD (tools/ubench_handoff.hip) - the tile map below puts the halves of a tile next
     // to each other in an XCD's run.  Both halves must be resident at once: the host launches this form only when 2 x tiles <= CUs.
-    constexpr bool KS = ABL == 50;
+    constexpr bool KS = ABLK == 50;
     const int ntiles = a.tiles_m * a.tiles_n;
     int tile, kz = 0;
     {
@@ -270,9 +273,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         u32x4 v[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) v[it] = *reinterpret_cast<const u32x4*>(lds + p * PROWS * OPITCH + loff[it]);
-        if (ABL != 7 || a.act == 12345) {
+        if (ABLK != 7 || a.act == 12345) {
 #pragma unroll
-            for (int it = 0; it < IT; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs, voff[it], 0, ABL == 8 ? 0 : 2 /* nt */);
+            for (int it = 0; it < IT; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs, voff[it], 0, ABLK == 8 ? 0 : 2 /* nt */);
         }
     };
     uint32_t voffA[IT_A];                                                        // this thread's chunks when all NT threads copy a panel
@@ -315,12 +318,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         }
         size_t xoff = 0;                                 // byte offset of the k-step the next stage reads
         auto stage = [&](int slot) MIXQ_INL {
-            if constexpr (ABL != 2 && ABL != 3) {
+            if constexpr (ABLK != 2 && ABLK != 3) {
 #pragma unroll
                 for (int i = 0; i < LOADS; ++i) {
                     wr_glds16(src[i] + xoff, lds + slot * STAGE_BYTES + dsto[i]);
-                    if constexpr (ABL == 22 || ABL == 23) __builtin_amdgcn_s_sleep(1);     // probe: the loader's pieces spread over the k-step
-                    if constexpr (ABL == 24) __builtin_amdgcn_s_sleep(2);
+                    if constexpr (ABLK == 22 || ABLK == 23) __builtin_amdgcn_s_sleep(1);     // probe: the loader's pieces spread over the k-step
+                    if constexpr (ABLK == 24) __builtin_amdgcn_s_sleep(2);
                 }
             }
             xoff += xks;
@@ -329,11 +332,11 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // 26 MB of requests in front of everybody's first stage.  RP stages are requested up front, then two per k-step until the
         // loader is LOOK stages ahead.  (slot of stage RP + 2 i + 1 was last read LOOK + 2 k-steps earlier: free, as in steady state)
         // (FP6 form at 128-row tiles: 8 stages of 12 KiB - three up front instead of all six: -0.6 .. -1.1 % per launch, same-run A/B of two builds)
-        constexpr int RP = (LOOK > 6 && ABL != 12) ? 4 : (F6 && LOOK > 3 ? 3 : LOOK);
+        constexpr int RP = (LOOK > 6 && ABLK != 12) ? 4 : (F6 && LOOK > 3 ? 3 : LOOK);
         int nxt, kt = 0;
         if (RP < LOOK && nk >= 2 * LOOK) {
 #pragma unroll
-            for (int s = 0; s < RP; ++s) { stage(s); if constexpr (ABL == 26 || ABL == 27) { if (s == 0) __builtin_amdgcn_s_sleep(8); } }
+            for (int s = 0; s < RP; ++s) { stage(s); if constexpr (ABLK == 26 || ABLK == 27) { if (s == 0) __builtin_amdgcn_s_sleep(8); } }
             wr_wait_vmcnt<LOADS * (RP - 1)>();
             __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
             wr_static_for<0, LOOK - RP>([&](auto i_c) MIXQ_INL {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 stage((RP + 2 * i) % NSTAGE);
                 stage((RP + 2 * i + 1) % NSTAGE);
                 wr_wait_vmcnt<LOADS * (RP + i)>();                               // stage i + 1 landed: RP + i younger stages may be in flight
-                if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
+                if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
             });
             kt = LOOK - RP;
             nxt = (2 * LOOK - RP) % NSTAGE;
@@ -353,12 +356,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
             nxt = LOOK % NSTAGE;
         }
-        // TOUCH (probe, ABL 70 / 71): the weight lines of k-step kt + LOOK are pulled into this XCD's L2 ten k-steps before the consumers
+        // TOUCH (probe, ABLK 70 / 71): the weight lines of k-step kt + LOOK are pulled into this XCD's L2 ten k-steps before the consumers
         // ask for them - one dword per 64-byte sector, this workgroup's share of the panel only (the gm workgroups of an XCD that stream
         // the same weight panel split its 12 KB per k-step between them), result never read.  Cold weights (a model's layers: every
         // launch streams 45 MB from HBM) stall the k loop by 100 cycles per k-step (profiles/r04_gemm_trace_warm_cold.txt): long-latency
         // requests hold the CU's memory queue.  Issued behind the k-step's wait: the hand-counted waits only get stricter by it.
-        constexpr bool TOUCH = ABL == 70 || ABL == 71;
+        constexpr bool TOUCH = ABLK == 70 || ABLK == 71;
         const uint8_t* tbase = nullptr;
         int tlanes = 0;
         if constexpr (TOUCH) {
@@ -371,14 +374,14 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             size_t off = static_cast<size_t>(n0 >> 4) * 1024 + static_cast<size_t>(sec) * 64;
             if (off + 64 > slab) off = slab - 64;                                // (the last tile's panel hangs over the image's rows)
             tbase = a.qw + off;
-            tlanes = (lane < per && sec < sectors && lw == (ABL == 71 ? 1 : 0)) ? 1 : 0;
+            tlanes = (lane < per && sec < sectors && lw == (ABLK == 71 ? 1 : 0)) ? 1 : 0;
         }
         size_t toff = static_cast<size_t>(kt + LOOK) * static_cast<size_t>(a.wblocks) * 1024;   // (the k-step whose stage the next iteration requests)
         int tsink = 0;
         for (; kt + LOOK < nk; ++kt) {
             stage(nxt);
-            if constexpr (ABL != 5) wr_wait_vmcnt<LOADS * NEWER>();              // stage kt+1 landed
-            if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
+            if constexpr (ABLK != 5) wr_wait_vmcnt<LOADS * NEWER>();              // stage kt+1 landed
+            if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
             nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
             if constexpr (TOUCH) {
                 // (the destination stays a LIVE register until the loader's last vmcnt(0): a dead one would be handed to something else while
@@ -432,7 +435,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         }
         for (; kt + 1 < nk; ++kt) {
             wr_wait_vmcnt<0>();
-            if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
+            if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
         }
         wr_wait_vmcnt<0>();                                                      // (nk = 1: no drain iteration waited for the tail blocks)
         if constexpr (TOUCH) asm volatile("" :: "v"(tsink));
@@ -479,7 +482,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             // EPI2: panels 0 .. LP-1 are copied out HERE, each as soon as all four consumer waves have raised its flag, under the consumers'
             // work on the later panels (which are shared by all waves behind the closing barrier).  Outputs that cannot be staged are
             // stored by the consumers themselves.
-            if constexpr (ABL == 62) __builtin_amdgcn_s_setprio(0);              // probe: the copying loaders below the consumers they share SIMDs with
+            if constexpr (ABLK == 62) __builtin_amdgcn_s_setprio(0);              // probe: the copying loaders below the consumers they share SIMDs with
             stamp2(8, CW * 64);
             if (staged) {
 #pragma unroll
@@ -514,7 +517,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     int n_out_dev_v = 0;
 
     if (wave < CW) {
-        if constexpr (ABL == 28) __builtin_amdgcn_s_setprio(3);                  // probe: the MFMA waves above the loaders
+        if constexpr (ABLK == 28) __builtin_amdgcn_s_setprio(3);                  // probe: the MFMA waves above the loaders
         if (a.n_out_dev) n_out_dev_v = *a.n_out_dev;
         auto zero_acc = [&]() MIXQ_INL {
 #pragma unroll
@@ -576,7 +579,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         constexpr int XR = F6 ? (MB < MIXQ_XR ? MB : MIXQ_XR) : 1;
         i32x6 xf6[XR];
         static_assert(!F6 || MB % XR == 0, "window slots must be compile-time");
-        i32x4 xc[2];                                     // (probe ABL 30: copies of the last two fragments)
+        i32x4 xc[2];                                     // (probe ABLK 30: copies of the last two fragments)
 #pragma unroll
         for (int d = 0; d < NSLOT; ++d)
 #pragma unroll
@@ -584,7 +587,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 // the ring's registers are read-write operands of the load statements, so they need a definition in front of the first one:
                 // an EMPTY asm output (no instruction; 15 x 4 v_mov in front of the first weight request otherwise).  Ablation builds that
                 // never load them get defined, opaque values.
-                if constexpr (ABL == 0 || ABL == 6 || ABL == 50 || (ABL >= 60 && ABL < 80)) {
+                if constexpr (ABLK == 0 || ABLK == 6 || ABLK == 50 || (ABLK >= 60 && ABLK < 80)) {
                     asm volatile("" : "=v"(wq[d][i]));
                     if constexpr (F6) asm volatile("" : "=v"(wq2[d][i]));
                 } else {
@@ -593,7 +596,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     asm volatile("" : "+v"(wq[d][i]));
                 }
             }
-        if constexpr (ABL != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
+        if constexpr (ABLK != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
 #pragma unroll
             for (int j = 0; j < MB; ++j) { xf[j] = i32x4{lane, 1, lane, 1}; asm volatile("" : "+v"(xf[j])); }
             if constexpr (F6) {
@@ -620,7 +623,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 const int l16 = lane16;
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(l16), "s"(src) : "memory");
             }
-            else if constexpr (ABL != 1 && ABL != 3) {
+            else if constexpr (ABLK != 1 && ABLK != 3) {
                 const int cs = __builtin_amdgcn_readfirstlane(cond);             // provably wave-uniform for the "s" constraint
                 const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];                     // (named outside the statement: implicit capture does not look into asm operands)
@@ -638,7 +641,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         auto wload1_always = [&](auto d_c, int i) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
             if constexpr (F6R) wload6(d_c, i);
-            else if constexpr (ABL != 1 && ABL != 3) {
+            else if constexpr (ABLK != 1 && ABLK != 3) {
                 const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];
                 const int l16 = lane16;
@@ -664,7 +667,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             } else
-            if constexpr (ABL != 1 && ABL != 3) {
+            if constexpr (ABLK != 1 && ABLK != 3) {
                 if constexpr (WNB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wq[d][0]) : "i"(CNT));
                 if constexpr (WNB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wq[d][0]), "+v"(wq[d][1]) : "i"(CNT));
                 if constexpr (WNB == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wq[d][0]), "+v"(wq[d][1]), "+v"(wq[d][2]) : "i"(CNT));
@@ -680,7 +683,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         auto wwait_rt = [&](auto d_c, int younger) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
             if constexpr (WRAP) { (void)younger; wwait(d_c, std::integral_constant<int, WL * (D - 1)>{}); }   // (every k-step requests: the count is fixed)
-            else if constexpr (ABL != 1 && ABL != 3) {
+            else if constexpr (ABLK != 1 && ABLK != 3) {
                 const int sel = __builtin_amdgcn_readfirstlane(younger >= D - 1 ? D - 1 : younger);   // k-steps requested after this one, capped at the ring depth
 #define MIXQ_WR_W1(n, l) "s_cmp_lt_u32 %[sel], " #n "\n\ts_cbranch_scc1 " #l "f\n\t"
 #define MIXQ_WR_W2(l, c) #l ":\n\ts_waitcnt vmcnt(%[" #c "])\n\ts_branch 199f\n"
@@ -713,14 +716,14 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             }
         };
         auto xread = [&](int slot, int j) MIXQ_INL {
-            if constexpr (F6 && (ABL == 2 || ABL == 3)) {
+            if constexpr (F6 && (ABLK == 2 || ABLK == 3)) {
                 // (ablation: no LDS reads)
             } else if constexpr (F6) {
                 const i32x4 p4 = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * BLK + xoff);
                 const i32x2 p2 = *reinterpret_cast<const i32x2*>(lds + slot * STAGE_BYTES + j * BLK + xoff8);
                 xf6[j % XR] = i32x6{p4[0], p4[1], p4[2], p4[3], p2[0], p2[1]};
             } else
-            if constexpr (ABL != 2 && ABL != 3)
+            if constexpr (ABLK != 2 && ABLK != 3)
                 xf[j] = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * 1024 + xoff);
         };
         uint32_t nib = 0xf0f0f0f0u;
@@ -744,8 +747,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
                 for (int i = 0; i < WNB; ++i) {
                     int pos = (WNB >= MB) ? (i % MB) : ((2 * i + 1) * MB) / (2 * WNB);      // spread evenly over the MB groups
-                    if constexpr (ABL == 20 || ABL == 23) pos = MB - WNB + i;            // probe: behind the last groups (away from the loaders' burst after the barrier)
-                    if constexpr (ABL == 21) pos = (i * MB) / WNB;                        // probe: 0, 2, 5: earlier
+                    if constexpr (ABLK == 20 || ABLK == 23) pos = MB - WNB + i;            // probe: behind the last groups (away from the loaders' burst after the barrier)
+                    if constexpr (ABLK == 21) pos = (i * MB) / WNB;                        // probe: 0, 2, 5: earlier
                     if (pos == j) { if constexpr (FULL) wload1_always(LC{}, i); else wload1(LC{}, i, issue); }
                 }
             };
@@ -814,7 +817,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             } else if constexpr (!I4) {
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
-                    if constexpr (ABL == 30 && MB >= 4 && WNB >= 3) {
+                    if constexpr (ABLK == 30 && MB >= 4 && WNB >= 3) {
                         // probe: the k-step boundary drains ALL fragment reads (the compiler's lgkmcnt(0)), so the last re-read,
                         // issued a few cycles before it, is an exposed LDS round trip per k-step.  The last two groups therefore run on
                         // COPIES of their fragments taken at the top of the step, and those two fragments are re-read early (behind the
@@ -840,7 +843,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #ifdef MIXQ_R2_ORDER                                 // (a second product build with round 2's order, for tools/ab_libs.py; never shipped)
                     constexpr bool NEW_ORDER = false;
 #else
-                    constexpr bool NEW_ORDER = ABL != 31;
+                    constexpr bool NEW_ORDER = ABLK != 31;
 #endif
                     if constexpr (NEW_ORDER) {
                         // At most ONE memory instruction per MFMA gap: a wave issues in order and a 16-cycle MFMA leaves ~12 cycles in
@@ -987,8 +990,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             for (int i = 0; i < WNB; ++i) wload1(d_c, i, decltype(d_c)::value < nk ? 1 : 0);
             wadvance(decltype(d_c)::value < nk ? 1 : 0);
             // probes: hold the requests of k-steps 1.. back so every CU's first k-step is served first
-            if constexpr (ABL == 25 || ABL == 26) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(8); }
-            if constexpr (ABL == 27) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(16); }
+            if constexpr (ABLK == 25 || ABLK == 26) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(8); }
+            if constexpr (ABLK == 27) { if (decltype(d_c)::value == 0) __builtin_amdgcn_s_sleep(16); }
         };
         // Request order: the weights of k-step 0 FIRST - they and the loaders' first stage are what the first MFMA waits for - then the
         // epilogue's scales (round 3 asked for those before anything else: ~30 address instructions and 14 requests in front of the first
@@ -1013,13 +1016,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         auto one = [&](auto c_c, auto full_c) MIXQ_INL {
             constexpr bool FULL = decltype(full_c)::value;                       // FULL: stage kt+1 and k-step kt+D exist
             if constexpr (FULL) {
-                if constexpr (ABL != 4) wwait(c_c, std::integral_constant<int, WL * (D - 1)>{});    // the D-1 younger k-steps stay in flight
-                if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();            // stage kt+1 landed; stage kt-2's slot is free
+                if constexpr (ABLK != 4) wwait(c_c, std::integral_constant<int, WL * (D - 1)>{});    // the D-1 younger k-steps stay in flight
+                if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();            // stage kt+1 landed; stage kt-2's slot is free
                 step(c_c, full_c, true, 1, slot1);
             } else {
                 wwait_rt(c_c, nk - 1 - kt);
                 const bool more = kt + 1 < nk;
-                if (more && ABL != 6) __builtin_amdgcn_s_barrier();
+                if (more && ABLK != 6) __builtin_amdgcn_s_barrier();
                 step(c_c, full_c, more, kt + D < nk ? 1 : 0, slot1);
             }
             slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
@@ -1169,7 +1172,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 const int j = pn * PJ + b / WNB, i = b % WNB;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if constexpr (ABL == 66) fa[j][i][r] = static_cast<float>(acc[j][i][r]);   // probe: no scaling
+                    if constexpr (ABLK == 66) fa[j][i][r] = static_cast<float>(acc[j][i][r]);   // probe: no scaling
                     else fa[j][i][r] = static_cast<float>(acc[j][i][r]) * sxv[j] * swv[i][r];
                 }
             };
@@ -1227,7 +1230,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                         const us2 mx = __builtin_elementwise_max(__builtin_bit_cast(us2, o.x & keep_lo), __builtin_bit_cast(us2, o.y & keep_hi));
                         rmax[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, rmax[j]), mx));
                     }
-                    if constexpr (ABL == 65) { asm volatile("" :: "v"(o)); }      // probe: converted, never staged
+                    if constexpr (ABLK == 65) { asm volatile("" :: "v"(o)); }      // probe: converted, never staged
                     else if constexpr (ST) *reinterpret_cast<u32x2*>(lds + (j * 16 + lm) * OPITCH + nloc * 2) = o;
                     else if (m < a.M && n < a.N) *reinterpret_cast<u32x2_u*>(a.y + static_cast<size_t>(m) * a.ldy + n) = o;
                 }
@@ -1284,7 +1287,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     xo2[kk][jj] = *reinterpret_cast<const u32x4*>(lds + TAILX + (kk * MB + pn * PJ + jj) * 1024 + lane * 16);
             };
             auto tail_mma = [&](int j, int i, u32x4 w, u32x4 x) MIXQ_INL {
-                if constexpr (ABL == 64) return;                                 // probe: the epilogue without its tail MFMAs (results are garbage)
+                if constexpr (ABLK == 64) return;                                 // probe: the epilogue without its tail MFMAs (results are garbage)
                 fa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), fa[j][i], 0, 0, 0);
             };
             // more than 32 TQ outlier columns (rare: the search stops adding beyond 128, linear.py:224): the remaining k-steps with both
@@ -1633,7 +1636,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         if (m0 + tid < a.M) atomicMax(a.row_amax + m0 + tid, v);
     }
     if constexpr (EPI2) {
-        if (staged) {                                                 // (ABL 61, a probe: LP = 0 - everything here, as the first form)
+        if (staged) {                                                 // (ABLK 61, a probe: LP = 0 - everything here, as the first form)
 #pragma unroll
             for (int p = LP; p < NPAN; ++p) copy_panel(p, std::integral_constant<int, NT>{}, voffA, loffA);   // (the earlier panels left under the arithmetic)
         }
@@ -1654,8 +1657,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             const int r = q / CPR, c = q - r * CPR;
             const int m = m0 + r, n = n0 + c * 8;
             // streaming (nt) store: Y is written once and not re-read by this kernel
-            if (q < BM * CPR && m < a.M && n < a.N && (ABL != 7 || a.act == 12345)) {
-                if constexpr (ABL == 8) *reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n) = v[it];
+            if (q < BM * CPR && m < a.M && n < a.N && (ABLK != 7 || a.act == 12345)) {
+                if constexpr (ABLK == 8) *reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n) = v[it];
                 else __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * a.ldy + n));
             }
         }
@@ -1678,6 +1681,7 @@ struct WrConfig {
     void (*k6)(const WrArgs);                          // int4 as FP6 codes (MIXQ_FMT_F6X128 operands); nullptr: tiling not built in that form
     int nstage6;                                      // its X ring depth (k-steps of 128 elements, 1.5 KiB blocks)
     void (*k8p)(const WrArgs);                         // int8 with the paired gate / up epilogue (MIXQ_ACT_SILU_PAIR); nullptr: not built for this tiling
+    void (*k6p)(const WrArgs);                         // ... the FP6 form with it
 };
 // (the int4 form expands nibbles in registers: 2 (MB + WNB) more fragment registers, so its weight ring is at most 4 deep)
 #define MIXQ_WR(MBv, WNBv, NS, Dv, LD, ABL, TAG)                                                                        \
@@ -1705,10 +1709,11 @@ struct WrConfig {
 #define MIXQ_WR6P(MBv, WNBv, NS, Dv, LD, NS6, D6, TAG)                                                                  \
     { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 0>,                                       \
       gemm_wreg_kernel<MBv, WNBv, NS, ((Dv) > 4 ? 4 : (Dv)) - ((MBv) * (WNBv) >= 32 ? 1 : 0), 1, LD, 0>,                \
-      gemm_wreg_kernel<MBv, WNBv, NS6, D6, 3, LD, 0>, NS6, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 90> }
+      gemm_wreg_kernel<MBv, WNBv, NS6, D6, 3, LD, 0>, NS6, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 90>,              \
+      gemm_wreg_kernel<MBv, WNBv, NS6, D6, 3, LD, 90> }
 #define MIXQ_WR8P(MBv, WNBv, NS, Dv, LD, TAG)                                                                           \
     { "wr" TAG, MBv, WNBv, NS, LD, gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 0>, nullptr, nullptr, 0,                  \
-      gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 90> }
+      gemm_wreg_kernel<MBv, WNBv, NS, Dv, 0, LD, 90>, nullptr }
 
 const WrConfig g_wr[] = {
     // name = tile (activation rows x weight rows) _ X ring depth _ weight ring depth _ loader waves
@@ -1848,10 +1853,13 @@ int mixq_wr_pick(int bit, int M, int N, int KB)
 }
 
 // The joint gate / up launch (N = the interleaved rows of both layers): the same model over the tilings that have the paired epilogue.
-int mixq_wr_pick_pair(int M, int N, int KB)
+int mixq_wr_pick_pair(int bit, int M, int N, int KB)
 {
     if (M <= 32) return WR_SMALL;
-    static const struct { int cfg; float tk, fixed; } cand[] = {{0, 0.248f, 8.8f}, {5, 0.341f, 7.1f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f}};
+    struct Cand { int cfg; float tk, fixed; };
+    static const Cand cand8[4] = {{0, 0.248f, 8.8f}, {5, 0.341f, 7.1f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f}};
+    static const Cand cand6[4] = {{0, 0.37f, 10.0f}, {7, 0.29f, 5.9f}, {8, 0.35f, 6.5f}, {8, 0.35f, 6.5f}};   // (the FP6 forms, priced as in mixq_wr_pick)
+    const Cand (&cand)[4] = bit == 6 ? cand6 : cand8;
     const int nk = KB >> 6;
     double best = 1e30; int bi = 0;
     for (const auto& c : cand) {
@@ -1862,7 +1870,7 @@ int mixq_wr_pick_pair(int M, int N, int KB)
     }
     return bi;
 }
-bool mixq_wr_has_pair(int c) { return c >= 0 && c < NUM_WR && g_wr[c].k8p != nullptr; }
+bool mixq_wr_has_pair(int bit, int c) { return c >= 0 && c < NUM_WR && (bit == 6 ? g_wr[c].k6p : g_wr[c].k8p) != nullptr; }
 int mixq_wr_ksplit_config() { return WR_KSPLIT; }
 // Can the pairwise split-K form (WR_KSPLIT) run (M, N, KB) on the current device?  MIXQ_OK, or why not: both halves of every tile must be
 // resident at once (2 x tiles <= CUs), the workspace registered with mixq_gemm_set_workspace must hold a flag word and an int32 slot per tile.
@@ -1910,7 +1918,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
 {
     if (c < 0 || c >= NUM_WR) return MIXQ_EINVAL;
     const bool pair = act == MIXQ_ACT_SILU_PAIR;                            // (the paired epilogue is a kernel form, not a run-time switch)
-    if (pair && (bit != 8 || (N & 3) || addend)) return MIXQ_EINVAL;
+    if (pair && ((bit != 8 && bit != 6) || (N & 3) || addend)) return MIXQ_EINVAL;
     const WrConfig& g = g_wr[c];
     WrArgs a;
     memset(&a, 0, sizeof(a));
@@ -1934,7 +1942,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     }
     a.trace = trace;
     a.row_amax = row_amax; a.amax_mask = amax_mask;
-    void (*k)(const WrArgs) = pair ? g.k8p : (bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4));
+    void (*k)(const WrArgs) = pair ? (bit == 8 ? g.k8p : g.k6p) : (bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4));
     if (!k) return MIXQ_EINVAL;
     int units = a.tiles_m * a.tiles_n;
     if (c == WR_KSPLIT) {

@@ -119,21 +119,25 @@ class MixLlamaMLP(nn.Module):
         def ident(t):
             return None if t is None else (id(t), t._version, tuple(t.shape))
         return tuple((ident(l._buffers.get("q_weight")), ident(l.scale_col), ident(l.bias), ident(l.weight_cache), ident(l.ind))
-                     for l in (up, gate)) + (str(up.scale_col.device), _L.PACK_FMT)
+                     for l in (up, gate)) + (str(up.scale_col.device), _L.PACK_FMT, _L.PACK_FMT4)
 
     def _joint_applies(self, cache):
         up, gate = self.up_proj_, self.gate_proj_
         if not JOINT_GATE_UP or not getattr(_backend, "PAIR_LAUNCH", False):
             return False
-        if up.bit != 8 or gate.bit != 8 or up.weight_only or gate.weight_only or up.add_outliers or _L.PACK_FMT != _L.FMT_F16X64:
+        if up.bit != gate.bit or up.weight_only or gate.weight_only or up.add_outliers:
             return False
-        if up.in_features % 64 or up.out_features % 8 or (up.in_features, up.out_features) != (gate.in_features, gate.out_features):
+        # the kernels with the paired epilogue: int8 on fragment-order weights, int4 as FP6 codes (the default image of either width)
+        if (_L.PACK_FMT != _L.FMT_F16X64) if up.bit == 8 else (_L.PACK_FMT4 != _L.FMT_F6X128):
+            return False
+        if up.in_features % (64 if up.bit == 8 else 128) or up.out_features % 8 or \
+                (up.in_features, up.out_features) != (gate.in_features, gate.out_features):
             return False
         n = int(up.ind.shape[0])
         if n and (gate.forward_without_precondition_len != n or gate.weight_cache is None or gate.weight_cache.shape[1] != n
                   or up.weight_cache is None or up.weight_cache.shape[1] != n):
             return False                                     # (gate_proj has not taken over the latest outlier columns yet: its own route does that)
-        return _L._fmt_of(cache.q_xcache) == _L.FMT_P16X64
+        return _L._fmt_of(cache.q_xcache) == (_L.FMT_P16X64 if up.bit == 8 else _L.FMT_R6X128)
 
     def _joint_operands(self):
         """The interleaved image + per-channel operands (interleave_pair_rows), rebuilt when anything they were made from changed.  The
@@ -144,7 +148,7 @@ class MixLlamaMLP(nn.Module):
             return j
         up, gate = self.up_proj_, self.gate_proj_
         N, n = up.out_features, int(up.ind.shape[0])
-        wpk = _backend.PackOperand(interleave_pair_rows(up.q_weight, gate.q_weight), _L.FMT_F16X64)
+        wpk = _backend.PackOperand(interleave_pair_rows(up.q_weight, gate.q_weight), _L.FMT_F16X64 if up.bit == 8 else _L.FMT_F6X128)
         scale = interleave_pair_rows(up.scale_col.reshape(-1), gate.scale_col.reshape(-1)).reshape(1, -1)
         bias = None
         if up.bias is not None or gate.bias is not None:
@@ -206,12 +210,12 @@ class MixLlamaMLP(nn.Module):
             xo, wo = _L._wide(xo, n_cap), _L._wide(wo, n_cap)
         extra = {}
         target = None
-        if FUSE_DOWN_AMAX and down.bit == 8 and down.in_features == N and hasattr(_backend, "amax_supported") and \
+        if FUSE_DOWN_AMAX and up.bit == 8 and down.bit == 8 and down.in_features == N and hasattr(_backend, "amax_supported") and \
                 _backend.amax_supported(M, 2 * N, K, _L.FMT_P16X64, _L.FMT_F16X64):
             target = down.amax_target(M, x.device)
             if target is not None:
                 extra = {"row_amax": target[0], "col_mask": target[1]}
-        y = _backend.FusedLinear(cache.q_xcache, j["wpk"], cache.x_scale, j["scale"], xo, wo, n_cap, j["bias"], M, 2 * N, K, bit=8,
+        y = _backend.FusedLinear(cache.q_xcache, j["wpk"], cache.x_scale, j["scale"], xo, wo, n_cap, j["bias"], M, 2 * N, K, bit=up.bit,
                                  act=_hip_mixlib.ACT_SILU_PAIR, n_out_dev=n_dev, **extra)
         out = y.reshape(cache.shape)
         if target is not None:
@@ -220,7 +224,8 @@ class MixLlamaMLP(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        if self._joint_applies(self.MLPCache):
+        rows = x.numel() // x.shape[-1]
+        if not self.up_proj_._small_batch_image(rows) and self._joint_applies(self.MLPCache):
             # silu(gate(x)) * up(x) from ONE launch over the two layers' interleaved rows (mlp.py:57-63), bit-identical to the route below
             return self.down_proj_(self._forward_joint(x, self.MLPCache), None, True)
         up_output = self.up_proj_(x, self.MLPCache)

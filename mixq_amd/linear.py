@@ -412,8 +412,8 @@ class MixLinear_GEMM(nn.Module):
 
     def x_fmt(self, M=None):
         """Layout this layer wants its quantised activation in for a batch of M rows (what a fused norm in front of it should emit)."""
-        if self._d.joint is not None and self._wpk is None and self._buffers.get("q_weight") is None:
-            return FMT_P16X64                                            # (the joint gate / up image is fragment-order int8: as below)
+        if self._d.joint is not None and self._wpk is None and self._buffers.get("q_weight") is None and not self._small_batch_image(M):
+            return FMT_P16X64 if self.bit == 8 else FMT_R6X128           # (the joint gate / up image: fragment-order int8 / FP6 codes, as below)
         wpk = self._packed_weight(M)
         if wpk is None:
             return FMT_PLAIN

@@ -24,20 +24,28 @@ def _device():
     _capi.load().mixq_gemm_set_config(-1)
 
 
-def _case(M, N, K, n_out, bias, seed):
+def _case(M, N, K, n_out, bias, seed, bit=8):
     rng = np.random.default_rng(seed)
     ind = np.sort(rng.choice(K, n_out, replace=False)).astype(np.int32) if n_out else np.zeros(0, np.int32)
     x = make_x(M, K, seed=seed + 1, outlier_cols=ind)
-    c = dict(M=M, N=N, K=K, ind=ind)
+    c = dict(M=M, N=N, K=K, ind=ind, bit=bit)
     for nm in ("up", "gate"):
         w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
-        qw, sw = O.quant_weight_w8(w)
-        c[nm] = dict(qw=qw, sw=sw, wo=O.dequant_weight_cols(qw, sw, ind, 8) if n_out else None,
-                     bias=rng.standard_normal(N).astype(np.float16) if bias else None)
+        if bit == 8:
+            qw, sw = O.quant_weight_w8(w)
+            wo = O.dequant_weight_cols(qw, sw, ind, 8) if n_out else None
+        else:
+            qw, sw, wo = O.quant_weight_w4(w, ind)                  # fp columns keep their exact fp16 weights (linear.py:129)
+            wo = wo if n_out else None
+        c[nm] = dict(qw=qw, sw=sw, wo=wo, bias=rng.standard_normal(N).astype(np.float16) if bias else None)
     xz = x.copy()
     c["xo"] = O.extract_outliers_zero(xz, ind) if n_out else None
-    c["qx"], c["sx"] = O.find_row_scale(xz, 8)
+    c["qx"], c["sx"] = O.find_row_scale(xz, bit)
     return c
+
+
+def _fmts(c):
+    return (1, 2) if c["bit"] == 8 else (_capi.FMT_R6X128, _capi.FMT_F6X128)       # (activations, weights)
 
 
 def _operands(c):
@@ -49,7 +57,7 @@ def _operands(c):
         xo[:, :n_out] = t(c["xo"])
         xo = xo[:, :n_out]
     sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV); sx[:, 0] = t(c["sx"])
-    qx = mixlib.PackOperand(t(c["qx"]), 1)
+    qx = mixlib.PackOperand(t(c["qx"]), _fmts(c)[0])
 
     def wo_of(w):
         if not n_out:
@@ -65,22 +73,24 @@ def _two_launches(c, row_amax=None, col_mask=None):
     qx, sx, xo, wo_of, n_out = _operands(c)
     u, g = c["up"], c["gate"]
     b = lambda d: None if d["bias"] is None else t(d["bias"])
-    up = mixlib.FusedLinear(qx, mixlib.PackOperand(t(u["qw"]), 2), sx, t(u["sw"]), xo, wo_of(t(u["wo"])) if n_out else None, n_out, b(u), M, N, K)
+    wf = _fmts(c)[1]
+    up = mixlib.FusedLinear(qx, mixlib.PackOperand(t(u["qw"]), wf), sx, t(u["sw"]), xo, wo_of(t(u["wo"])) if n_out else None, n_out, b(u), M, N, K,
+                            bit=c["bit"])
     extra = {} if row_amax is None else {"row_amax": row_amax, "col_mask": col_mask}
-    return mixlib.FusedLinear(qx, mixlib.PackOperand(t(g["qw"]), 2), sx, t(g["sw"]), xo, wo_of(t(g["wo"])) if n_out else None, n_out, b(g), M, N, K,
-                              act=_capi.ACT_SILU_MUL, addend=up, **extra)
+    return mixlib.FusedLinear(qx, mixlib.PackOperand(t(g["qw"]), wf), sx, t(g["sw"]), xo, wo_of(t(g["wo"])) if n_out else None, n_out, b(g), M, N, K,
+                              bit=c["bit"], act=_capi.ACT_SILU_MUL, addend=up, **extra)
 
 
 def _one_launch(c, row_amax=None, col_mask=None):
     M, N, K = c["M"], c["N"], c["K"]
     qx, sx, xo, wo_of, n_out = _operands(c)
     u, g = c["up"], c["gate"]
-    qw = mixlib.PackOperand(interleave_pair_rows(t(u["qw"]), t(g["qw"])), 2)
+    qw = mixlib.PackOperand(interleave_pair_rows(t(u["qw"]), t(g["qw"])), _fmts(c)[1])
     sw = interleave_pair_rows(t(u["sw"]).reshape(-1), t(g["sw"]).reshape(-1)).reshape(1, -1)
     wo = wo_of(interleave_pair_rows(t(u["wo"]), t(g["wo"]))) if n_out else None
     bias = None if u["bias"] is None else interleave_pair_rows(t(u["bias"]), t(g["bias"]))
     extra = {} if row_amax is None else {"row_amax": row_amax, "col_mask": col_mask}
-    return mixlib.FusedLinear(qx, qw, sx, sw, xo, wo, n_out, bias, M, 2 * N, K, act=_capi.ACT_SILU_PAIR, **extra)
+    return mixlib.FusedLinear(qx, qw, sx, sw, xo, wo, n_out, bias, M, 2 * N, K, bit=c["bit"], act=_capi.ACT_SILU_PAIR, **extra)
 
 
 def test_interleave_is_a_bijection_in_groups_of_four():
@@ -243,3 +253,63 @@ def test_new_weights_loaded_into_a_block_on_the_joint_route_reach_the_joint_imag
     y_b = b(norm_b(xs[3].clone().to(DEV)))
     assert torch.equal(y_b, y_a)
     assert b.up_proj_._wpk is None and b.up_proj_._buffers["q_weight"] is None       # ... and the block is back to one image
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# W4A4 (int4 as FP6 codes): the same joint launch on the FP6 form of the kernel
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,n_out,bias", [(512, 11008, 4096, 128, False), (200, 584, 512, 70, True), (96, 96, 128, 0, False), (20, 1000, 1024, 129, False)])
+def test_w4a4_one_launch_for_gate_and_up(M, N, K, n_out, bias):
+    c = _case(M, N, K, n_out, bias, seed=M + N + n_out + 4, bit=4)
+    u, g = c["up"], c["gate"]
+    up_ref = O.linear_fused(c["qx"], u["qw"], c["sx"], u["sw"], xo=c["xo"], wo=u["wo"], addend=None, bias=u["bias"], act=0, bit=4)
+    ref = O.linear_fused(c["qx"], g["qw"], c["sx"], g["sw"], xo=c["xo"], wo=g["wo"], addend=up_ref, bias=g["bias"], act=2, bit=4).astype(np.float32)
+    y1 = _one_launch(c)
+    y = n(y1).astype(np.float32)
+    assert tuple(y1.shape) == (M, N) and np.isfinite(y).all()
+    assert (np.abs(y - ref) <= ulp_tol(ref)).all(), float(np.abs(y - ref).max())
+    y2 = _two_launches(c)
+    assert torch.equal(y1, y2), int((y1 != y2).sum())
+    if M * N > 2e6:
+        return
+    lib, names = _capi.load(), _capi.gemm_config_names()
+    try:
+        for nm in ("wr128x192_s16_d4_l2", "wr64x192_s16_d4_l2", "wr64x256_s16_d4_l2", "wr32x64_s8_d6_l1"):
+            assert lib.mixq_gemm_set_config(names.index(nm)) == 0
+            y3 = _one_launch(c)
+            assert torch.equal(y3, y2), (nm, int((y3 != y2).sum()))
+    finally:
+        lib.mixq_gemm_set_config(-1)
+
+
+def test_w4a4_mlp_block_on_the_joint_route_is_bit_identical():
+    from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP, fused
+    from mixq_amd import linear as L
+    assert L.PACK_FMT4 == _capi.FMT_F6X128
+    M, H, F = 64, 512, 1024
+    outs = {}
+    prev = fused.JOINT_GATE_UP
+    try:
+        for joint in (False, True):
+            fused.JOINT_GATE_UP = joint
+            torch.manual_seed(0)
+            cache = MixLibCache(M, sigma=6, bit=4, device=DEV)
+            cols = torch.randperm(H, generator=torch.Generator().manual_seed(1))[:8]
+            ls = torch.ones(H); ls[cols] = 20.0
+            mk = lambda k, nn_, sc: MixLinear_GEMM.from_linear(torch.nn.Linear(k, nn_, bias=False).half(), 4, cache=cache, layer_scales=sc, dev=DEV)
+            lsd = torch.ones(F); lsd[:12] = 20.0
+            gate, up, down = mk(H, F, ls), mk(H, F, ls), mk(F, H, lsd)
+            norm = FasterTransformerRMSNorm((torch.rand(H) + 0.5).half().to(DEV), 1e-5, cache)
+            norm.next_layer = up
+            mlp = MixLlamaMLP(gate, down, up, cache)
+            x = torch.randn(M, H, generator=torch.Generator().manual_seed(2)).half()
+            x[:, cols] *= 20
+            outs[joint] = [mlp(norm(x.clone().to(DEV))).clone() for _ in range(6)]
+            if joint:
+                assert mlp._joint is not None, "the joint route did not run"
+                assert mixlib.fmt_of(mlp._joint["wpk"]) == _capi.FMT_F6X128 and up._wpk is None and gate._wpk is None
+                assert mlp._joint["wpk"].numel() == 2 * F * H * 3 // 4          # 0.75 byte per weight, once
+    finally:
+        fused.JOINT_GATE_UP = prev
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
