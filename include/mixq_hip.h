@@ -134,6 +134,13 @@ int mixq_extract_outliers_zero(uint16_t* x, const int32_t* ind, int n, uint16_t*
 int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev,
                      uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                      int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
+/* The same pass for a caller that KEEPS the bit-per-column mask of its outlier columns in device memory (a layer whose prediction is
+ * frozen: `ind` never changes again): col_mask = little-endian words, bit c set <=> column c is one of ind[0 .. live count), at least
+ * K / 32 words (required when n > 0).  Same bytes out; the row maximum no longer waits for the device-resident count, `ind` and the
+ * two barriers around building that mask inside the kernel.  mixq_linear_forward takes this route when args->col_mask is set. */
+int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
+                            uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
+                            int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
 
 /* ---- online outlier-column detection ------------------------------------------------------------------
  * Replaces torch.unique(torch.where(abs(X) > sigma)[1]).int32  (linear.py:157-161, FindOutliers).
@@ -213,7 +220,8 @@ int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, const int32_t*
  *   x [M,K] fp16 ldx (outlier columns zeroed in place), ind / n_cap / n_dev, x_scale [M] (written), q_x (written, format qfmt),
  *   x_out [M,ldxo] (written; NULL when n_cap = 0), flag (optional), q_w in format wfmt (MIXQ_FMT_*), scale_col [N],
  *   w_out [N,ldwo], addend / lda, bias, y [M,ldy], act (MIXQ_ACT_*), row_amax / col_mask (optional: a producer left the row maxima,
- *   see mixq_gemm_i8_fused_amax - the quantise pass is then mixq_quant_known_amax).  qfmt must be what the GEMM takes for wfmt:
+ *   see mixq_gemm_i8_fused_amax - the quantise pass is then mixq_quant_known_amax; col_mask alone: the caller's kept mask of `ind`,
+ *   the pass is mixq_quant_fused_masked).  qfmt must be what the GEMM takes for wfmt:
  *   PLAIN / P16X64 with wfmt PLAIN / P16X64 in any combination, P16X64 with wfmt F16X64. */
 typedef struct mixq_linear_args {
     uint16_t* x; int ldx;

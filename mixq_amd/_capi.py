@@ -61,6 +61,7 @@ SIGNATURES = {
     "mixq_find_row_scale": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mixq_extract_outliers_zero": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
     "mixq_quant_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "mixq_quant_fused_masked": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "mixq_detect_outlier_cols": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
     "mixq_dequant_weight_cols": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "mixq_gemm_i8_fused": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],

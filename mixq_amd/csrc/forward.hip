@@ -27,8 +27,11 @@ extern "C" int mixq_linear_forward(const mixq_linear_args* a, mixq_stream_t stre
     int rc = a->row_amax
         ? mixq_quant_known_amax(a->x, a->ind, a->n_cap, a->n_dev, a->row_amax, a->col_mask, a->x_scale, a->q_x, a->x_out, a->flag, a->M,
                                 a->K, a->ldx, a->ldxo, a->bit, a->sigma, a->qfmt, stream)
-        : mixq_quant_fused(a->x, a->ind, a->n_cap, a->n_dev, a->x_scale, a->q_x, a->x_out, a->flag, a->M, a->K, a->ldx, a->ldxo,
-                           a->bit, a->sigma, a->qfmt, stream);
+        : (a->col_mask && a->n_cap > 0         // a frozen layer keeps the mask of its outlier columns: no mask build in front of the row maximum
+           ? mixq_quant_fused_masked(a->x, a->ind, a->n_cap, a->n_dev, a->col_mask, a->x_scale, a->q_x, a->x_out, a->flag, a->M, a->K, a->ldx,
+                                     a->ldxo, a->bit, a->sigma, a->qfmt, stream)
+           : mixq_quant_fused(a->x, a->ind, a->n_cap, a->n_dev, a->x_scale, a->q_x, a->x_out, a->flag, a->M, a->K, a->ldx, a->ldxo,
+                              a->bit, a->sigma, a->qfmt, stream));
     if (rc) return rc;
     if (a->bit == 8)
         return mixq_gemm_i8_fused(static_cast<const int8_t*>(a->q_x), static_cast<const int8_t*>(a->q_w), a->x_scale, a->scale_col,

@@ -196,7 +196,7 @@ template <int BIT, int TPR, int RPB, int NCH>
 __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
     uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int ldo,
-    int32_t* __restrict__ flag, int M, int K, float thr_scale, int rows16, int fmt, int dbg)
+    int32_t* __restrict__ flag, int M, int K, float thr_scale, int rows16, int fmt, int dbg, const uint32_t* __restrict__ col_mask)
 {
     constexpr int NT = TPR * RPB, WPR = TPR / 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32] column bitmask, RPB * WPR floats
@@ -220,6 +220,17 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         const int c = chunk(i);
         keep[i] = (valid && c < nchunk) ? xv[c] : make_uint4(0, 0, 0, 0);
     }
+    // col_mask (mixq_quant_fused_masked): the caller keeps the bit-per-column mask of `ind` in device memory (a frozen layer's never
+    // changes).  A chunk's eight mask bits are ONE byte of it, requested here beside the row: the maximum then waits for neither the
+    // device-resident count, nor `ind`, nor the two barriers around building the same mask in LDS - `ind` is only needed for the gather,
+    // which is consumed behind the quantised stores.
+    const uint8_t* cm = reinterpret_cast<const uint8_t*>(col_mask);
+    uint32_t m8g[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = chunk(i);
+        m8g[i] = (cm && c < nchunk) ? cm[c] : 0u;
+    }
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
     const bool have_out = (n > 0) && ind != nullptr && !(dbg & 4);
@@ -231,20 +242,22 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     int gcol[GQ] = {-1, -1};
     uint16_t gval[GQ] = {0, 0};
     if (have_out) {
-        for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
+        if (!cm) for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
 #pragma unroll
         for (int g = 0; g < GQ; ++g) { const int j = t + g * TPR; if (j < n) gcol[g] = ind[j]; }
-        __syncthreads();
-        if (rw == 0) {                                         // one row's threads build the mask for the whole workgroup
+        if (!cm) {
+            __syncthreads();
+            if (rw == 0) {                                     // one row's threads build the mask for the whole workgroup
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0) atomicOr(&smem[gcol[g] >> 5], 1u << (gcol[g] & 31));
-            for (int j = t + GQ * TPR; j < n; j += TPR) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
+                for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0) atomicOr(&smem[gcol[g] >> 5], 1u << (gcol[g] & 31));
+                for (int j = t + GQ * TPR; j < n; j += TPR) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
+            }
         }
         if (valid) {
 #pragma unroll
             for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0 && !(dbg & 2)) gval[g] = xr[gcol[g]];
         }
-        __syncthreads();
+        if (!cm) __syncthreads();
     }
 
     uint32_t amax_acc = 0u;
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     for (int i = 0; i < NCH; ++i) {
         const int c = chunk(i);
         if (c < nchunk) {
-            const uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
+            const uint32_t m8 = cm ? m8g[i] : (have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u);
             amax_acc = amax8_masked(keep[i], m8, amax_acc);
         }
     }
@@ -582,13 +595,14 @@ constexpr int NUM_QUANT_CFGS = 10;
 
 template <int BIT, int TPR, int RPB>
 int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
-                       uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st)
+                       uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st,
+                       const uint32_t* col_mask)
 {
     const int nchunk = K >> 3;
     const size_t shm = (static_cast<size_t>((K + 31) >> 5) + RPB * (TPR / 64)) * sizeof(uint32_t);
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g((M + RPB - 1) / RPB), b(TPR * RPB);
-#define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt, g_quant_dbg)
+#define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt, g_quant_dbg, col_mask)
     if      (nchunk <= 1 * TPR)  MIXQ_QLAUNCH2(1);
     else if (nchunk <= 2 * TPR)  MIXQ_QLAUNCH2(2);
     else if (nchunk <= 4 * TPR)  MIXQ_QLAUNCH2(4);
@@ -601,7 +615,8 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
 
 template <int BIT>
 int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
-                      uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st)
+                      uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st,
+                      const uint32_t* col_mask = nullptr)      // (optional: the kept bit-per-column mask of `ind`; the round-1 kernel builds its own)
 {
     const int nchunk = K >> 3;
     int cfg = g_quant_cfg.get();
@@ -616,7 +631,7 @@ int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int
         if (qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) cfg = nchunk <= 256 ? 5 : (qfmt == MIXQ_FMT_F6X128 && nchunk <= 512 ? 7 : 9);
     }
     int rc = -100;
-#define MIXQ_Q2(TPR, RPB) rc = launch_quant_rows2<BIT, TPR, RPB>(x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, qfmt, st)
+#define MIXQ_Q2(TPR, RPB) rc = launch_quant_rows2<BIT, TPR, RPB>(x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, qfmt, st, col_mask)
     switch (cfg) {
         case 1: MIXQ_Q2(64, 1); break;
         case 2: MIXQ_Q2(64, 2); break;
@@ -694,9 +709,9 @@ extern "C" int mixq_find_row_scale(const uint16_t* x, uint16_t* x_scale, void* q
     return launch_quant_rows<4>(xm, ldx, nullptr, 0, nullptr, x_scale, q, nullptr, 0, nullptr, M, K, 0.f, qfmt, mixq_stream(stream));
 }
 
-extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
-                                uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt,
-                                mixq_stream_t stream)
+static int quant_fused_common(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask, uint16_t* x_scale, void* q,
+                              uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt,
+                              mixq_stream_t stream)
 {
     if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !((qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) && bit == 4)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
@@ -709,8 +724,24 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
     // reference: `x_scale.max() > self.sigma / qmax` with sigma an fp16 [1,1] tensor -> fp16(fp16(sigma)/qmax)
     const float thr = fp16_round(fp16_round(sigma) / qmax);
     uint16_t* xo = (n > 0) ? x_out : nullptr;
-    if (bit == 8) return launch_quant_rows<8>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream));
-    return launch_quant_rows<4>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream));
+    if (bit == 8) return launch_quant_rows<8>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream), col_mask);
+    return launch_quant_rows<4>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream), col_mask);
+}
+
+extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
+                                uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt,
+                                mixq_stream_t stream)
+{
+    return quant_fused_common(x, ind, n, n_dev, nullptr, x_scale, q, x_out, flag, M, K, ldx, ldo, bit, sigma, qfmt, stream);
+}
+// ... with the bit-per-column mask of the live `ind` entries kept by the caller (bit c of the little-endian word array = column c is an
+// outlier column; at least K / 32 words): same bytes out, without the in-kernel mask build in front of the row maximum
+extern "C" int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
+                                       uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo,
+                                       int bit, float sigma, int qfmt, mixq_stream_t stream)
+{
+    if (n > 0 && !col_mask) return MIXQ_EINVAL;
+    return quant_fused_common(x, ind, n, n_dev, n > 0 ? col_mask : nullptr, x_scale, q, x_out, flag, M, K, ldx, ldo, bit, sigma, qfmt, stream);
 }
 
 extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint32_t* row_amax,

@@ -614,8 +614,9 @@ class MixLinear_GEMM(nn.Module):
             if wo is None or wo.shape[1] != n or wo.stride(0) < _pad16(n):
                 return None
             wo = _wide(wo, _pad16(n))
+        # (frozen: `ind` never changes again, so the quantise pass gets the kept bit mask of its columns instead of building one per launch)
         return _backend.ForwardPlan(M, self.out_features, self.in_features, self.bit, self._sigma_f, inputs.stride(0), ind_buf, n, n_dev,
-                                    cache.x_scale, wpk, self.scale_col, wo, self.bias, self.x_fmt(M))
+                                    cache.x_scale, wpk, self.scale_col, wo, self.bias, self.x_fmt(M), kept_mask=self._col_mask() if n else None)
 
     # ------------------------------------------------------------------------------------------------------
     @torch.no_grad()

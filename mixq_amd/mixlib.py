@@ -621,12 +621,14 @@ def _want_fmt(packed, fmt):
     return FMT_P16X64 if packed else FMT_PLAIN
 
 
-def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, packed=False, fmt=None):
+def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, packed=False, fmt=None, col_mask=None):
     """(i)+(ii) in one pass over X: extract/zero the known outlier columns `ind`, per-row scale into x_scale[0:M],
     quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n]).  With fmt = FMT_P16X64 /
     FMT_F16X64 (or packed=True: P16x64) q_x is emitted directly in that layout ([roundup(M,16), KB] bytes) and tagged.
-    `n_dev` (device int32[1]) overrides the count: `ind` then is a buffer of capacity ind.numel()."""
-    _dev_check(x, x_scale, ind)
+    `n_dev` (device int32[1]) overrides the count: `ind` then is a buffer of capacity ind.numel().
+    `col_mask` (device int32 words, bit c <=> column c is one of the live `ind` entries): the caller's kept mask - the pass skips its
+    own mask build (mixq_quant_fused_masked; same bytes out)."""
+    _dev_check(x, x_scale, ind, col_mask)
     fmt = _want_fmt(packed, fmt)
     xp, ldx = _rows(x, "x")
     M, K = x.shape
@@ -646,8 +648,14 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
         ip = ind.data_ptr()
     else:
         op, ldo, ip = None, 0, None
-    _capi.call("mixq_quant_fused", xp, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K, ldx,
-               ldo, bit, float(sigma), fmt, _stream())
+    if col_mask is not None and n:
+        if col_mask.element_size() != 4 or col_mask.numel() * 32 < K or not col_mask.is_contiguous():
+            raise RuntimeError("QuantFused: col_mask must be contiguous 4-byte words covering all K columns")
+        _capi.call("mixq_quant_fused_masked", xp, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K,
+                   ldx, ldo, bit, float(sigma), fmt, _stream())
+    else:
+        _capi.call("mixq_quant_fused", xp, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K, ldx,
+                   ldo, bit, float(sigma), fmt, _stream())
     return set_fmt(q, fmt), (x_out[:, :n] if n else None)
 
 
@@ -760,9 +768,9 @@ class ForwardPlan:
     a forward then costs three allocations, four pointer updates and ONE foreign call that enqueues the quantise pass and the
     GEMM (the steady state of linear.py:187-193 + :244-285).  Holds references to every tensor whose address it carries."""
 
-    __slots__ = ("args", "ref", "fn", "keep", "M", "N", "K", "ldx", "n", "ldxo", "q_shape", "q_dtype", "qfmt", "device", "lock", "captured")
+    __slots__ = ("args", "ref", "fn", "keep", "M", "N", "K", "ldx", "n", "ldxo", "q_shape", "q_dtype", "qfmt", "device", "lock", "captured", "kept_mask")
 
-    def __init__(self, M, N, K, bit, sigma, ldx, ind_buf, n, n_dev, x_scale, q_w, scale_col, w_out, bias, qfmt, act=ACT_NONE):
+    def __init__(self, M, N, K, bit, sigma, ldx, ind_buf, n, n_dev, x_scale, q_w, scale_col, w_out, bias, qfmt, act=ACT_NONE, kept_mask=None):
         import ctypes as C
         _dev_check(x_scale, q_w, scale_col, ind_buf, n_dev, w_out, bias)
         if x_scale.numel() < M or scale_col.numel() < N:
@@ -783,7 +791,13 @@ class ForwardPlan:
             a.w_out, a.ldwo = wop, ldwo
         a.ldy = N
         self.args, self.ref, self.fn = a, C.byref(a), _capi.load().mixq_linear_forward
-        self.keep = (ind_buf, n_dev, x_scale, q_w, scale_col, w_out, bias)
+        # kept_mask: the layer's bit-per-column mask of `ind` (int32 words, >= K / 32): the quantise pass then skips its own mask build
+        if kept_mask is not None:
+            _dev_check(kept_mask)
+            if kept_mask.element_size() != 4 or kept_mask.numel() * 32 < K or not kept_mask.is_contiguous():
+                raise RuntimeError("ForwardPlan: kept_mask must be contiguous 4-byte words covering all K columns")
+        self.kept_mask = kept_mask if n_cap else None
+        self.keep = (ind_buf, n_dev, x_scale, q_w, scale_col, w_out, bias, kept_mask)
         self.M, self.N, self.K, self.ldx, self.n, self.qfmt, self.device = M, N, K, ldx, n, qfmt, x_scale.device
         import threading
         self.lock = threading.Lock()                   # (the argument block is ONE structure: filled and handed over under the lock, see run)
@@ -810,7 +824,7 @@ class ForwardPlan:
         # ONE structure per plan and a foreign call that releases the GIL: two threads (or two streams driven from two threads) running
         # the same frozen layer must not interleave "fill" and "launch" - the C side reads the block before it returns
         with self.lock:
-            a.row_amax, a.col_mask = _ptr(row_amax), _ptr(col_mask)
+            a.row_amax, a.col_mask = _ptr(row_amax), _ptr(col_mask if col_mask is not None else self.kept_mask)
             if xo is not None:
                 a.x_out = xo.data_ptr()
             a.x, a.q_x, a.y = x.data_ptr(), q.data_ptr(), y.data_ptr()

@@ -258,3 +258,52 @@ def test_panel_epilogue_edge_cases_against_the_oracle(M, N, K, n_out, bias, act)
             assert (np.abs(y - ref) <= ulp_tol(ref)).all(), (names[cfg], float(np.abs(y - ref).max()))
     finally:
         lib.mixq_gemm_set_config(-1)
+
+
+@pytest.mark.parametrize("bit,fmt,M,K,ncols,cap", [(8, 1, 512, 4096, 41, 48), (8, 0, 37, 512, 3, 3), (8, 1, 100, 11008, 130, 144), (4, 4, 96, 1024, 128, 128),
+                                                   (4, 1, 64, 512, 17, 32), (8, 1, 16, 256, 1, 16)])
+def test_quantise_pass_with_the_kept_column_mask_writes_the_same_bytes(bit, fmt, M, K, ncols, cap):
+    """mixq_quant_fused_masked (the frozen layer's route: its bit-per-column mask of `ind` is kept in device memory) against
+    mixq_quant_fused, which builds that mask in LDS on every launch: q_x, x_scale, x_out, the zeroed columns of x and the misprediction
+    flag, with the live count in device memory below the capacity of `ind` (poison behind it)."""
+    g = torch.Generator().manual_seed(bit * 1000 + K + ncols)
+    x = torch.randn(M, K, generator=g).half()
+    cols = torch.sort(torch.randperm(K, generator=g)[:ncols])[0].to(torch.int32)
+    x[:, cols.long()] *= 30
+    ind = torch.full((cap,), K - 1, dtype=torch.int32)                   # (entries behind the live count: never read as columns)
+    ind[:ncols] = cols
+    ind, n_dev = ind.to(DEV), torch.tensor([ncols], dtype=torch.int32, device=DEV)
+    words = (K + 31) // 32
+    bits = torch.zeros(words * 32, dtype=torch.int64)
+    bits[cols.long()] = 1
+    w = (bits.view(words, 32) << torch.arange(32, dtype=torch.int64)).sum(dim=1)
+    mask = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).to(DEV)
+    outs = []
+    for cm in (None, mask):
+        xd = x.clone().to(DEV)
+        sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        q, xo = mixlib.QuantFused(xd, ind, sx, bit, 6.0, flag=flag, n_dev=n_dev if cap > ncols else None, fmt=fmt, col_mask=cm)
+        torch.cuda.synchronize()
+        if fmt:                                                         # (the packed image's pad rows beyond M are not written: compare the rows)
+            q = mixlib.UnpackOperand(q, M)
+        outs.append((q.clone(), sx, xo[:, :ncols].clone(), xd, flag))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int((outs[1][3][:, cols.long().to(DEV)] != 0).sum()) == 0
+
+
+def test_frozen_layer_hands_its_kept_mask_to_the_one_call_forward():
+    """The plan of a frozen layer carries the layer's column mask; the forward equals the two-call route's bit for bit."""
+    M, K, N = 96, 1024, 512
+    layer, cache, cols = frozen_layer(M, K, N, 8, 7, True, seed=11)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(5)).half()
+    x[:, cols] *= 20
+    y1 = layer(x.clone().to(DEV), None, True)
+    assert layer._plan is not None and layer._plan.kept_mask is not None and layer._plan.kept_mask is layer._col_mask()
+    L.ONE_CALL_FORWARD = False
+    try:
+        y2 = layer(x.clone().to(DEV), None, True)
+    finally:
+        L.ONE_CALL_FORWARD = True
+    assert torch.equal(y1, y2)

@@ -22,6 +22,7 @@ ap.add_argument("--shape", default="4096,11008")
 ap.add_argument("--outliers", type=int, default=41)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--bit", type=int, default=8, choices=[8, 4], help="4: W4A4 on the FP6 pipe (give --outliers 128)")
 ap.add_argument("--amax", action="store_true", help="both arms also leave down_proj's row maxima")
 ap.add_argument("--cfgs", default="", help="comma-separated tilings to force for extra one-launch arms (e.g. wr128x256_s16_d3_l2)")
 args = ap.parse_args()
@@ -29,17 +30,20 @@ K, N = (int(v) for v in args.shape.split(","))
 M, n_out = args.tokens, args.outliers
 dev = "cuda"
 g = torch.Generator().manual_seed(1)
-qx = mixlib.PackOperand(torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(dev), 1)
+XF, WF = (1, 2) if args.bit == 8 else (_capi.FMT_R6X128, _capi.FMT_F6X128)
+rnd = (lambda r, k: torch.randint(-127, 128, (r, k), generator=g, dtype=torch.int8)) if args.bit == 8 else \
+      (lambda r, k: torch.randint(0, 256, (r, k // 2), generator=g, dtype=torch.uint8))        # (nibble pairs)
+qx = mixlib.PackOperand(rnd(M, K).to(dev), XF)
 sx = (torch.rand((M, 1), generator=g) * 0.01 + 0.001).half().to(dev)
 pad = (n_out + 15) // 16 * 16
 xo = (torch.randn((M, pad), generator=g) * 4).half().to(dev)[:, :n_out]
 lay = {}
 for nm in ("up", "gate"):
-    qw = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(dev)
+    qw = rnd(N, K).to(dev)
     sw = (torch.rand((1, N), generator=g) * 0.001 + 0.0001).half().to(dev)
     wo = (torch.randn((N, pad), generator=g) * 0.02).half().to(dev)
-    lay[nm] = dict(qw=qw, wpk=mixlib.PackOperand(qw, 2), sw=sw, wo=wo[:, :n_out])
-jw = mixlib.PackOperand(interleave_pair_rows(lay["up"]["qw"], lay["gate"]["qw"]), 2)
+    lay[nm] = dict(qw=qw, wpk=mixlib.PackOperand(qw, WF), sw=sw, wo=wo[:, :n_out])
+jw = mixlib.PackOperand(interleave_pair_rows(lay["up"]["qw"], lay["gate"]["qw"]), WF)
 jsw = interleave_pair_rows(lay["up"]["sw"].reshape(-1), lay["gate"]["sw"].reshape(-1)).reshape(1, -1)
 jwo_full = torch.zeros((2 * N, pad), dtype=torch.float16, device=dev)
 jwo_full[:, :n_out] = interleave_pair_rows(lay["up"]["wo"], lay["gate"]["wo"])
@@ -55,13 +59,13 @@ ex_b = {"row_amax": amax_b, "col_mask": mask} if args.amax else {}
 
 
 def two():
-    mixlib.FusedLinear(qx, lay["up"]["wpk"], sx, lay["up"]["sw"], xo, lay["up"]["wo"], n_out, None, M, N, K, out=y_up)
-    mixlib.FusedLinear(qx, lay["gate"]["wpk"], sx, lay["gate"]["sw"], xo, lay["gate"]["wo"], n_out, None, M, N, K, act=_capi.ACT_SILU_MUL,
+    mixlib.FusedLinear(qx, lay["up"]["wpk"], sx, lay["up"]["sw"], xo, lay["up"]["wo"], n_out, None, M, N, K, bit=args.bit, out=y_up)
+    mixlib.FusedLinear(qx, lay["gate"]["wpk"], sx, lay["gate"]["sw"], xo, lay["gate"]["wo"], n_out, None, M, N, K, bit=args.bit, act=_capi.ACT_SILU_MUL,
                        addend=y_up, out=y_a, **ex_a)
 
 
 def one():
-    mixlib.FusedLinear(qx, jw, sx, jsw, xo, jwo, n_out, None, M, 2 * N, K, act=_capi.ACT_SILU_PAIR, out=y_b, **ex_b)
+    mixlib.FusedLinear(qx, jw, sx, jsw, xo, jwo, n_out, None, M, 2 * N, K, bit=args.bit, act=_capi.ACT_SILU_PAIR, out=y_b, **ex_b)
 
 
 two(); one()
@@ -96,7 +100,7 @@ with torch.cuda.stream(st):
             ms, f, _ = bench.conditioned_replay(gr, st)
             res[name].append(ms * 1e3 / args.steps)
             first.setdefault(name, f * 1e3 / args.steps)
-print(f"gate_proj + up_proj, {M} tokens, {K} -> {N} (x2), {n_out} outlier columns{', with row maxima' if args.amax else ''}; "
+print(f"gate_proj + up_proj, W{args.bit}A{args.bit}, {M} tokens, {K} -> {N} (x2), {n_out} outlier columns{', with row maxima' if args.amax else ''}; "
       f"{args.steps} steps per graph, {args.rounds} interleaved rounds; outputs bit-identical")
 for name, v in res.items():
     print(f"  {name:44s} median {statistics.median(v):7.2f} us   min {min(v):7.2f}   (first replay {first[name]:.2f})   all: " + " ".join(f"{x:.2f}" for x in v))
