@@ -270,6 +270,11 @@ int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weight, uint16_t
                              const int32_t* n_dev, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                              int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma, int qfmt,
                              mixq_stream_t stream);
+/* ... with the next layer's kept bit-per-column mask of its outlier columns (see mixq_quant_fused_masked): same bytes out */
+int mixq_rmsnorm_quant_fused_masked(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
+                                    const int32_t* n_dev, const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out,
+                                    int32_t* flag, int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma,
+                                    int qfmt, mixq_stream_t stream);
 
 /* ---- weight-only W8A16 Linear -----------------------------------------------------
  * mixq_gemm_w8a16 replaces EETQ's w8_a16_gemm(x, q_weight, scale_col) as called at modules/linear.py:178-184:

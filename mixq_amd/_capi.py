@@ -82,6 +82,7 @@ SIGNATURES = {
     "mixq_gemm_pick_config_fmt": [_I, _I, _I, _I, _I],
     "mixq_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "mixq_rmsnorm_quant_fused": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
+    "mixq_rmsnorm_quant_fused_masked": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
     "mixq_pack_w8a16": [_P, _P, _I, _I, _P],
     "mixq_gemm_w8a16": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mixq_gemm_w8a16_set_config": [_I],

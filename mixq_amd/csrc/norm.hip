@@ -48,7 +48,8 @@ template <int BIT, int NCH, bool QUANT>
 __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ w, float eps, uint16_t* __restrict__ out, int ldout,
     const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev, uint16_t* __restrict__ x_scale,
-    void* __restrict__ q, uint16_t* __restrict__ x_out, int ldxo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt)
+    void* __restrict__ q, uint16_t* __restrict__ x_out, int ldxo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt,
+    const uint32_t* __restrict__ col_mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];     // column bitmask, then 8 floats
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -65,6 +66,21 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
             keep[i] = reinterpret_cast<const uint4*>(xr)[c];
             wk[i] = reinterpret_cast<const uint4*>(w)[c];
         }
+    }
+    // col_mask (mixq_rmsnorm_quant_fused_masked): the caller's kept bit-per-column mask of `ind`.  A chunk's eight bits are one byte of
+    // it, requested here with the row, and so are the live count and this thread's `ind` entry: behind the sum of squares the row maximum
+    // starts at once - unmasked it waits for three dependent round trips (count, ind[j], x[ind[j]]) and two barriers around the LDS mask
+    const uint8_t* cm = QUANT ? reinterpret_cast<const uint8_t*>(col_mask) : nullptr;
+    uint32_t m8g[NCH];
+    int nd0 = n_cap, c0 = 0;
+    if (cm) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NT;
+            m8g[i] = c < nchunk ? cm[c] : 0u;
+        }
+        if (n_dev) nd0 = *n_dev;
+        if (tid < n_cap) c0 = ind[tid];                                 // (inside the capacity-padded buffer; used only below the live count)
     }
     float ss = 0.f;
 #pragma unroll
@@ -89,9 +105,16 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     bool have_out = false;
     if constexpr (QUANT) {
         n = n_cap;
-        if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
+        if (cm) n = nd0 < n_cap ? nd0 : n_cap;
+        else if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
         have_out = (n > 0) && ind != nullptr;
-        if (have_out) {
+        if (have_out && cm) {
+            for (int j = tid; j < n; j += NT) {                          // (the gather only: nothing below waits for it)
+                const int c = j == tid ? c0 : ind[j];
+                const uint16_t yv = norm1(xr[c], inv, w[c]);
+                if (x_out) x_out[static_cast<size_t>(row) * ldxo + j] = yv;
+            }
+        } else if (have_out) {
             for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
             __syncthreads();
             for (int j = tid; j < n; j += NT) {
@@ -102,7 +125,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
             }
         }
         if (x_out) for (int j = (have_out ? n : 0) + tid; j < ldxo; j += NT) x_out[static_cast<size_t>(row) * ldxo + j] = 0;
-        if (have_out) __syncthreads();
+        if (have_out && !cm) __syncthreads();
     }
 
     float amax = 0.f;
@@ -112,7 +135,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
         if (c < nchunk) {
             const uint32_t d[4] = {keep[i].x, keep[i].y, keep[i].z, keep[i].w};
             const uint32_t g[4] = {wk[i].x, wk[i].y, wk[i].z, wk[i].w};
-            const uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
+            const uint32_t m8 = cm ? m8g[i] : (have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u);
             uint32_t y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -199,13 +222,13 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
 template <int BIT, bool QUANT>
 int launch_norm(const uint16_t* x, int ldx, const uint16_t* w, float eps, uint16_t* out, int ldout, const int32_t* ind, int n,
                 const int32_t* n_dev, uint16_t* x_scale, void* q, uint16_t* x_out, int ldxo, int32_t* flag, int M, int K,
-                float thr, int qfmt, hipStream_t st)
+                float thr, int qfmt, hipStream_t st, const uint32_t* col_mask = nullptr)
 {
     const size_t shm = (static_cast<size_t>((K + 31) >> 5) + 8) * sizeof(uint32_t);
     const int nchunk = K >> 3;
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g(M), b(NT);
-#define MIXQ_NLAUNCH(NCH) hipLaunchKernelGGL((rmsnorm_kernel<BIT, NCH, QUANT>), g, b, shm, st, x, ldx, w, eps, out, ldout, ind, n, n_dev, x_scale, q, x_out, ldxo, flag, K, thr, rows16, qfmt)
+#define MIXQ_NLAUNCH(NCH) hipLaunchKernelGGL((rmsnorm_kernel<BIT, NCH, QUANT>), g, b, shm, st, x, ldx, w, eps, out, ldout, ind, n, n_dev, x_scale, q, x_out, ldxo, flag, K, thr, rows16, qfmt, col_mask)
     if      (nchunk <= 2 * NT)  MIXQ_NLAUNCH(2);
     else if (nchunk <= 4 * NT)  MIXQ_NLAUNCH(4);
     else if (nchunk <= 8 * NT)  MIXQ_NLAUNCH(8);
@@ -229,10 +252,10 @@ extern "C" int mixq_rmsnorm(const uint16_t* x, const uint16_t* weight, uint16_t*
                                  0.f, 0, mixq_stream(stream));
 }
 
-extern "C" int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
-                                        const int32_t* n_dev, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M,
-                                        int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma, int qfmt,
-                                        mixq_stream_t stream)
+static int rmsnorm_quant_common(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
+                                const int32_t* n_dev, const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M,
+                                int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma, int qfmt,
+                                mixq_stream_t stream)
 {
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !weight || !out || !x_scale || !q))) return MIXQ_EINVAL;
     if (bit != 8 && bit != 4) return MIXQ_EINVAL;
@@ -246,7 +269,25 @@ extern "C" int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weigh
     uint16_t* xo = (n > 0) ? x_out : nullptr;
     if (bit == 8)
         return launch_norm<8, true>(x, ldx, weight, eps, out, ldout, ind, n, n_dev, x_scale, q, xo, ldxo, flag, M, K, thr, qfmt,
-                                    mixq_stream(stream));
+                                    mixq_stream(stream), col_mask);
     return launch_norm<4, true>(x, ldx, weight, eps, out, ldout, ind, n, n_dev, x_scale, q, xo, ldxo, flag, M, K, thr, qfmt,
-                                mixq_stream(stream));
+                                mixq_stream(stream), col_mask);
+}
+
+extern "C" int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
+                                        const int32_t* n_dev, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M,
+                                        int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma, int qfmt,
+                                        mixq_stream_t stream)
+{
+    return rmsnorm_quant_common(x, weight, out, ind, n, n_dev, nullptr, x_scale, q, x_out, flag, M, K, ldx, ldout, ldxo, eps, bit, sigma, qfmt, stream);
+}
+// ... for a next layer whose prediction is frozen: its kept bit-per-column mask of the live `ind` entries (as mixq_quant_fused_masked)
+extern "C" int mixq_rmsnorm_quant_fused_masked(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
+                                               const int32_t* n_dev, const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out,
+                                               int32_t* flag, int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma,
+                                               int qfmt, mixq_stream_t stream)
+{
+    if (n > 0 && !col_mask) return MIXQ_EINVAL;
+    return rmsnorm_quant_common(x, weight, out, ind, n, n_dev, n > 0 ? col_mask : nullptr, x_scale, q, x_out, flag, M, K, ldx, ldout, ldxo, eps, bit,
+                                sigma, qfmt, stream);
 }

@@ -20,6 +20,9 @@ FUSE_DOWN_AMAX = True
 # gate_proj + up_proj of MixLlamaMLP as one launch over an interleaved weight image once both predictions are frozen (int8 layers);
 # False = up_proj's launch, then gate_proj's with the SiLU-and-multiply epilogue
 JOINT_GATE_UP = True
+# the fused norm hands the next (frozen) layer's kept column mask to its quantise step (mixq_rmsnorm_quant_fused_masked); False = the mask
+# is built inside the kernel on every launch
+NORM_KEPT_MASK = True
 
 
 def set_backend(mod):
@@ -72,8 +75,10 @@ class FasterTransformerRMSNorm(nn.Module):
         else:
             ind, n_dev = (nl.ind if n else None), None
         if hasattr(_backend, "PackOperand"):
+            # (a next layer whose prediction is frozen hands over its kept column mask: no mask build in front of the row maximum)
+            cm = nl._col_mask() if (NORM_KEPT_MASK and n and hasattr(nl, "_col_mask") and not nl.add_outliers) else None
             q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
-                                               sigma=getattr(cache, "sigma_value", 6.0), fmt=fmt, n_dev=n_dev)
+                                               sigma=getattr(cache, "sigma_value", 6.0), fmt=fmt, n_dev=n_dev, col_mask=cm)
         else:                                                # host stand-in of the CPU tests
             q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
                                                sigma=getattr(cache, "sigma_value", 6.0))

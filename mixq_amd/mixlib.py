@@ -849,10 +849,10 @@ def layernorm_forward_cuda(x, weight, out, eps):
     return out
 
 
-def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=None, packed=False, fmt=None, n_dev=None):
+def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=None, packed=False, fmt=None, n_dev=None, col_mask=None):
     """RMSNorm fused with the next linear's extract + zero + scale + quantise.  Returns (q_x, x_out_view[M,n]); q_x carries
-    its format tag."""
-    _dev_check(x, weight, out, x_scale, ind)
+    its format tag.  `col_mask`: the next layer's kept bit-per-column mask of `ind` (as QuantFused)."""
+    _dev_check(x, weight, out, x_scale, ind, col_mask)
     fmt = _want_fmt(packed, fmt)
     K = x.shape[-1]
     x2, o2 = x.reshape(-1, K), out.reshape(-1, K)
@@ -870,8 +870,14 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
         xop, ldxo, ip = x_out.data_ptr(), x_out.stride(0), ind.data_ptr()
     else:
         x_out, xop, ldxo, ip = None, None, 0, None
-    _capi.call("mixq_rmsnorm_quant_fused", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), xop,
-               _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), fmt, _stream())
+    if col_mask is not None and n:
+        if col_mask.element_size() != 4 or col_mask.numel() * 32 < K or not col_mask.is_contiguous():
+            raise RuntimeError("RMSNormQuantFused: col_mask must be contiguous 4-byte words covering all K columns")
+        _capi.call("mixq_rmsnorm_quant_fused_masked", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(),
+                   q.data_ptr(), xop, _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), fmt, _stream())
+    else:
+        _capi.call("mixq_rmsnorm_quant_fused", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), xop,
+                   _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), fmt, _stream())
     return set_fmt(q, fmt), (x_out[:, :n] if n else None)
 
 

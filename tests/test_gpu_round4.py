@@ -307,3 +307,34 @@ def test_frozen_layer_hands_its_kept_mask_to_the_one_call_forward():
     finally:
         L.ONE_CALL_FORWARD = True
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("bit,fmt,M,K,ncols,cap", [(8, 1, 512, 4096, 41, 48), (8, 0, 37, 512, 3, 3), (4, 4, 96, 1024, 128, 128), (8, 1, 40, 8192, 300, 304)])
+def test_fused_norm_with_the_kept_column_mask_writes_the_same_bytes(bit, fmt, M, K, ncols, cap):
+    """mixq_rmsnorm_quant_fused_masked against mixq_rmsnorm_quant_fused: normalised output, q_x, x_scale, x_out - also with more outlier
+    columns than the workgroup has threads' first entries (300) and the live count below the capacity of `ind`."""
+    g = torch.Generator().manual_seed(bit * 1000 + K + ncols)
+    x = torch.randn(M, K, generator=g).half()
+    cols = torch.sort(torch.randperm(K, generator=g)[:ncols])[0].to(torch.int32)
+    x[:, cols.long()] *= 30
+    wgt = (torch.rand(K, generator=g) + 0.5).half().to(DEV)
+    ind = torch.full((cap,), K - 1, dtype=torch.int32)
+    ind[:ncols] = cols
+    ind, n_dev = ind.to(DEV), torch.tensor([ncols], dtype=torch.int32, device=DEV)
+    words = (K + 31) // 32
+    bits = torch.zeros(words * 32, dtype=torch.int64)
+    bits[cols.long()] = 1
+    w = (bits.view(words, 32) << torch.arange(32, dtype=torch.int64)).sum(dim=1)
+    mask = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).to(DEV)
+    outs = []
+    for cm in (None, mask):
+        xd = x.clone().to(DEV)
+        out = torch.empty_like(xd)
+        sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        q, xo = mixlib.RMSNormQuantFused(xd, wgt, out, 1e-5, ind, sx, bit, n_dev=n_dev if cap > ncols else None, fmt=fmt, col_mask=cm)
+        torch.cuda.synchronize()
+        if fmt:
+            q = mixlib.UnpackOperand(q, M)
+        outs.append((q.clone(), sx, xo[:, :ncols].clone(), out))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
