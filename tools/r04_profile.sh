@@ -31,4 +31,15 @@ python bench.py > gpurun_out/r04p_bench.json 2> gpurun_out/r04p_bench.err
 python bench.py --bit 4 --no-cpu-baseline > gpurun_out/r04p_bench_w4.json 2>> gpurun_out/r04p_bench.err
 python bench.py --shape 8192,28672 --no-cpu-baseline --steps 100 > gpurun_out/r04p_bench_70b.json 2>> gpurun_out/r04p_bench.err
 cp profiles/r04_hbm_traffic*.json gpurun_out/ 2>/dev/null
+# the secondary tables (no profiler attached), same box
+python tools/bench_mlp.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04p_mlp_block.txt
+python tools/bench_block.py --layers 32 --passes 1 2>&1 | grep -v amdgpu.ids > gpurun_out/r04p_block.txt
+python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04p_configs_operator.txt
+{ for t in 16 32 64 128 256 512 1024 2048 4096; do python tools/bench_pair.py --tokens $t --rounds 5; done
+  python tools/bench_pair.py --tokens 512 --amax --rounds 5
+  python tools/bench_pair.py --tokens 512 --shape 8192,28672 --rounds 5
+  python tools/bench_pair.py --tokens 512 --shape 4096,14336 --rounds 5
+  for t in 16 128 512 2048; do python tools/bench_pair.py --bit 4 --outliers 128 --tokens $t --rounds 5; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/r04p_pair_launch_ab.txt
+{ python tools/time_quant_mask.py; python tools/time_quant_mask.py --bit 4; python tools/time_quant_mask.py --shape 4096,4096; } 2>&1 | grep -v amdgpu.ids > gpurun_out/r04p_quant_kept_mask.txt
+python tools/yardstick.py --no-power --rounds 10 2>&1 | grep -v amdgpu.ids > gpurun_out/r04p_ceiling.txt
 head -8 gpurun_out/r04p_kt.txt; tail -12 gpurun_out/r04p_traffic.log; tail -c 1500 gpurun_out/r04p_bench.json; echo; tail -c 700 gpurun_out/r04p_bench_w4.json; echo; tail -c 700 gpurun_out/r04p_bench_70b.json
