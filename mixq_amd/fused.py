@@ -116,6 +116,7 @@ class MixLlamaMLP(nn.Module):
         # gate_proj and up_proj as ONE launch (MIXQ_ACT_SILU_PAIR): the interleaved operands, built at the first forward after both
         # layers' outlier predictions froze.  A plain attribute, not a buffer: the state_dict stays the reference's (two q_weight tensors)
         object.__setattr__(self, "_joint", None)
+        object.__setattr__(self, "_two_launch_captured", False)   # a hipGraph out there replays the two layers' OWN images
 
     # ---- gate_proj + up_proj in one launch -------------------------------------------------------------------------------
     def _joint_key(self):
@@ -142,7 +143,15 @@ class MixLlamaMLP(nn.Module):
         if n and (gate.forward_without_precondition_len != n or gate.weight_cache is None or gate.weight_cache.shape[1] != n
                   or up.weight_cache is None or up.weight_cache.shape[1] != n):
             return False                                     # (gate_proj has not taken over the latest outlier columns yet: its own route does that)
-        return _L._fmt_of(cache.q_xcache) == (_L.FMT_P16X64 if up.bit == 8 else _L.FMT_R6X128)
+        if _L._fmt_of(cache.q_xcache) != (_L.FMT_P16X64 if up.bit == 8 else _L.FMT_R6X128):
+            return False
+        j = self._joint
+        if (j is None or j["key"] != self._joint_key()) and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # the joint image is never BUILT under capture (its packing kernels would be replayed with the graph, and the layers' own
+            # images - which that graph is about to address through the two-launch route - would be freed by the build)
+            object.__setattr__(self, "_two_launch_captured", True)
+            return False
+        return True
 
     def _joint_operands(self):
         """The interleaved image + per-channel operands (interleave_pair_rows), rebuilt when anything they were made from changed.  The
@@ -166,12 +175,14 @@ class MixLlamaMLP(nn.Module):
             wo = wo[:, :n]
         old = self._joint
         j = {"wpk": wpk, "rows": 2 * N, "scale": scale, "bias": bias, "wo": wo,
-             "retired": ([] if old is None else old["retired"] + [old["wpk"], old["wo"]])}      # (captured graphs may still address them)
+             # a superseded joint image may still be addressed by a graph captured on this route: kept alive (rebuilds are rare: new weights
+             # loaded, new outlier columns, a device move)
+             "retired": ([] if old is None else old["retired"] + [old["wpk"], old["wo"], old["scale"], old["bias"]])}
         object.__setattr__(self, "_joint", j)
         for which, l in enumerate((up, gate)):
             d = l._d
-            if d.wpk is not None:
-                d.retired.append(d.wpk)
+            if d.wpk is not None and (self._two_launch_captured or any(getattr(pl, "captured", False) for pl in d.plans.values())):
+                d.retired.append(d.wpk)                      # (a captured graph still addresses the layer's own image: kept alive, else freed here)
             d.invalidate()                                   # (kept argument blocks carry the old image's address)
             d.wpk = d.wpk_key = None
             d.joint = _JointRows(self, which)

@@ -313,3 +313,47 @@ def test_w4a4_mlp_block_on_the_joint_route_is_bit_identical():
         fused.JOINT_GATE_UP = prev
     for a, b in zip(outs[True], outs[False]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_joint_image_is_never_built_under_capture_and_a_graph_of_the_two_launch_route_survives_it():
+    """The first frozen forward of a block happens under hipGraph capture: that graph takes the two-launch route (no packing kernels in
+    the graph).  The next eager forward builds the joint image; the layers' own images, which the graph addresses, are kept alive for it
+    - otherwise they are freed (one copy of the weights)."""
+    from mixq_amd import fused
+    M, H, F = 96, 512, 1536
+    inner, norm, cache, xs = _block(M, H, F, False)
+    up, gate = inner.up_proj_, inner.gate_proj_
+    mlp = lambda x: inner(norm(x))
+    prev = fused.JOINT_GATE_UP
+    try:
+        fused.JOINT_GATE_UP = False
+        for x in xs[:3]:
+            mlp(x.clone().to(DEV))
+        y_ref = mlp(xs[3].clone().to(DEV))
+        fused.JOINT_GATE_UP = True
+        side = torch.cuda.Stream()
+        xg = xs[3].clone().to(DEV)
+        keep = xg.clone()
+        with torch.cuda.stream(side):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                yg = mlp(xg)
+        torch.cuda.synchronize()
+        assert inner._joint is None and inner._two_launch_captured
+        own = (up._wpk, gate._wpk)
+        y = mlp(xs[3].clone().to(DEV))                                # eager: builds the joint image
+        assert inner._joint is not None and up._wpk is None and torch.equal(y, y_ref)
+        assert any(t is own[0] for t in up._d.retired) and any(t is own[1] for t in gate._d.retired)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                xg.copy_(keep)
+                gr.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(yg, y_ref)
+        # without a graph in the way the layers' own images are FREED by the build
+        inner2, norm2, _, _ = _block(M, H, F, False, seed=3)
+        for x in xs[:4]:
+            inner2(norm2(x.clone().to(DEV)))
+        assert inner2._joint is not None and not inner2.up_proj_._d.retired and not inner2.gate_proj_._d.retired
+    finally:
+        fused.JOINT_GATE_UP = prev
