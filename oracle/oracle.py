@@ -172,6 +172,45 @@ def linear_fused(qx, qw, sx, sw, xo=None, wo=None, addend=None, bias=None, act=0
     return y
 
 
+def pair_rows_interleave(up, gate):
+    """The row order MIXQ_ACT_SILU_PAIR reads two layers' per-channel arrays in (include/mixq_hip.h): row 4g+0 = up[2g], 4g+1 = up[2g+1],
+    4g+2 = gate[2g], 4g+3 = gate[2g+1].  Written out element by element: the definition the product's helper is held to."""
+    up, gate = np.asarray(up), np.asarray(gate)
+    assert up.shape == gate.shape and up.shape[0] % 2 == 0
+    out = np.empty((2 * up.shape[0],) + up.shape[1:], dtype=up.dtype)
+    for c in range(up.shape[0]):
+        g, e = divmod(c, 2)
+        out[4 * g + e] = up[c]
+        out[4 * g + 2 + e] = gate[c]
+    return out
+
+
+def pair_rows_split(joint):
+    joint = np.asarray(joint)
+    n = joint.shape[0] // 2
+    up = np.empty((n,) + joint.shape[1:], dtype=joint.dtype)
+    gate = np.empty_like(up)
+    for c in range(n):
+        g, e = divmod(c, 2)
+        up[c], gate[c] = joint[4 * g + e], joint[4 * g + 2 + e]
+    return up, gate
+
+
+def linear_fused_pair(qx, qw2, sx, sw2, xo=None, wo2=None, bias2=None, bit=8):
+    """gate_proj + up_proj over INTERLEAVED operands -> fp16 [M, N/2]: what mixquant/modules/fused/mlp.py:57-63 computes from the two
+    layers - up_output = up_proj(x) (linear.py:244-285, an fp16 tensor), gate_output = silu-fused gate_proj(x) (linear.py:320-373),
+    gate_output *= up_output - restated as up_proj's compute step followed by gate_proj's with the multiplier folded in (act = 2)."""
+    qw_u, qw_g = pair_rows_split(qw2)
+    sw_u, sw_g = pair_rows_split(_h(sw2).reshape(-1))
+    wo_u = wo_g = b_u = b_g = None
+    if wo2 is not None and xo is not None and np.asarray(xo).shape[1] > 0:
+        wo_u, wo_g = pair_rows_split(_h(wo2))
+    if bias2 is not None:
+        b_u, b_g = pair_rows_split(_h(bias2).reshape(-1))
+    up = linear_fused(qx, qw_u, sx, sw_u, xo=xo, wo=wo_u, addend=None, bias=b_u, act=0, bit=bit)
+    return linear_fused(qx, qw_g, sx, sw_g, xo=xo, wo=wo_g, addend=up, bias=b_g, act=2, bit=bit)
+
+
 def linear_dequant_ref(qx, qw, sx, sw, xo=None, ind=None, bias=None, wo=None):
     """north_star's gate: CPU Linear over the same dequantised operands, fp64 -> float64 [M,N] (int8 operands).
     wo: the fp16 weight_cache the reference multiplies the outlier columns with (linear.py:207); None -> qw*sw."""

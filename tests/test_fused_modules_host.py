@@ -83,3 +83,40 @@ def test_mlp_wrapper_matches_composition(oracle_backend):
 def norm_ref(x):
     xf = x.float()
     return xf / torch.sqrt((xf ** 2).mean(dim=-1, keepdim=True) + 1e-6)
+
+
+def test_pair_row_order_of_the_joint_gate_up_launch():
+    """mixq_amd.fused.interleave_pair_rows (what MixLlamaMLP builds its joint image with) against the oracle's element-by-element
+    definition of the MIXQ_ACT_SILU_PAIR row order, and the oracle's paired compute step against the two steps it stands for."""
+    rng = np.random.default_rng(3)
+    for shape in [(8,), (16, 5), (96, 32)]:
+        up = rng.integers(-100, 100, size=shape).astype(np.int8)
+        gate = rng.integers(-100, 100, size=shape).astype(np.int8)
+        j = F.interleave_pair_rows(torch.from_numpy(up), torch.from_numpy(gate)).numpy()
+        assert np.array_equal(j, O.pair_rows_interleave(up, gate))
+        u2, g2 = F.split_pair_rows(torch.from_numpy(j))
+        assert np.array_equal(u2.numpy(), up) and np.array_equal(g2.numpy(), gate)
+        u3, g3 = O.pair_rows_split(j)
+        assert np.array_equal(u3, up) and np.array_equal(g3, gate)
+    with pytest.raises(ValueError):
+        F.interleave_pair_rows(torch.zeros(3, 2), torch.zeros(3, 2))
+    M, N, K, n_out = 10, 24, 64, 5
+    qx = rng.integers(-127, 128, size=(M, K)).astype(np.int8)
+    sx = (rng.random(M) * 0.01 + 0.001).astype(np.float16)
+    xo = rng.standard_normal((M, n_out)).astype(np.float16)
+    lay = []
+    for _ in range(2):
+        lay.append(dict(qw=rng.integers(-127, 128, size=(N, K)).astype(np.int8), sw=(rng.random(N) * 0.01 + 0.001).astype(np.float16),
+                        wo=(rng.standard_normal((N, n_out)) * 0.1).astype(np.float16), b=rng.standard_normal(N).astype(np.float16)))
+    u, g = lay
+    up = O.linear_fused(qx, u["qw"], sx, u["sw"], xo=xo, wo=u["wo"], bias=u["b"], act=0)
+    ref = O.linear_fused(qx, g["qw"], sx, g["sw"], xo=xo, wo=g["wo"], addend=up, bias=g["b"], act=2)
+    got = O.linear_fused_pair(qx, O.pair_rows_interleave(u["qw"], g["qw"]), sx, O.pair_rows_interleave(u["sw"], g["sw"]), xo=xo,
+                              wo2=O.pair_rows_interleave(u["wo"], g["wo"]), bias2=O.pair_rows_interleave(u["b"], g["b"]))
+    assert got.shape == (M, N) and np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+    # ... which is silu(gate) * up of the fp64 definition within fp16 resolution
+    z = lambda d: (qx.astype(np.float64) @ d["qw"].astype(np.float64).T) * sx.astype(np.float64)[:, None] * d["sw"].astype(np.float64)[None, :] \
+        + xo.astype(np.float64) @ d["wo"].astype(np.float64).T
+    zu, zg = z(u) + u["b"].astype(np.float64), z(g)
+    want = (zg / (1 + np.exp(-zg)) + g["b"].astype(np.float64)) * zu
+    assert np.abs(got.astype(np.float64) - want).max() <= 4e-3 * np.abs(want).max() + 1e-3

@@ -114,6 +114,15 @@ def test_one_launch_for_gate_and_up_against_the_oracle_and_the_two_launch_route(
     y = n(y1).astype(np.float32)
     assert np.isfinite(y).all()
     assert (np.abs(y - ref) <= ulp_tol(ref)).all(), float(np.abs(y - ref).max())
+    if M * N <= 2e6:
+        # the oracle's paired step on the INTERLEAVED operands (its own, element-by-element definition of the row order): the same bits
+        # as its two steps, and the image the product builds is that definition
+        il = O.pair_rows_interleave
+        ref2 = O.linear_fused_pair(c["qx"], il(u["qw"], g["qw"]), c["sx"], il(np.asarray(u["sw"]).reshape(-1), np.asarray(g["sw"]).reshape(-1)),
+                                   xo=c["xo"], wo2=None if u["wo"] is None else il(u["wo"], g["wo"]),
+                                   bias2=None if u["bias"] is None else il(u["bias"], g["bias"]))
+        assert np.array_equal(ref2.astype(np.float32), ref)
+        assert np.array_equal(n(interleave_pair_rows(t(u["qw"]), t(g["qw"]))), il(u["qw"], g["qw"]))
     y2 = _two_launches(c)
     assert torch.equal(y1, y2), int((y1 != y2).sum())
     if M * N > 2e6:
