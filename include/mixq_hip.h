@@ -235,6 +235,14 @@ typedef struct mixq_linear_args {
 } mixq_linear_args;
 int mixq_linear_forward(const mixq_linear_args* args, mixq_stream_t stream);
 
+/* ---- weight prefetch into the memory-side cache --------------------------------------------------------------
+ * Touch `bytes` of a device buffer (one dword per 128-byte line) from a handful of light workgroups: enqueued on a SIDE stream while
+ * another kernel computes, it pulls a layer's weight image into the MI355X's 256 MB memory-side cache ahead of the GEMM that streams it
+ * (a GEMM with cache-resident weights runs its k loop 20 % faster than one fed from HBM).  Nothing is written.  A model runner calls it
+ * for the NEXT GEMM's image when it enqueues the current one; the images are k-major, so the walk stays ahead of that GEMM's own reads.
+ * No reference counterpart (the reference's GPUs have no such cache level). */
+int mixq_prefetch(const void* ptr, long long bytes, mixq_stream_t stream);
+
 /* ---- operand re-tiling ------------------------------------------------------------------------------------
  * Copy a plain [R,KB] byte matrix (int8 weights, or nibble-packed int4) into MIXQ_FMT_P16X64.
  * dst holds roundup(R,16) * KB bytes; rows >= R are zero-filled.  KB % 64 == 0.  Done once per weight at load. */
