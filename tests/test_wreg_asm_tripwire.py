@@ -16,4 +16,6 @@ def test_no_compiler_copy_or_spill_of_an_in_flight_ring_register():
     lines = [l for l in r.stdout.splitlines() if l.startswith("MB=")]
     assert len(lines) >= 30, r.stdout[-2000:]                     # 15 tilings x (int8, nibble) + the FP6 forms
     fp6 = [l for l in lines if " Q=3 " in l]
-    assert len(fp6) == 6 and all("suspicious 0" in l for l in fp6), fp6
+    assert len(fp6) == 10 and all("suspicious 0" in l for l in fp6), fp6      # six tilings + the paired gate / up form (ABL=90) of four of them
+    pair = [l for l in lines if l.rstrip().split(":")[0].endswith("ABL=90")]
+    assert len(pair) == 9 and all("suspicious 0" in l for l in pair), pair   # int8: five tilings, FP6: four
