@@ -404,6 +404,7 @@ def main(argv=None):
         # ---- secondary timings, outside the timed region of `value` --------------------------------------
         eager_ms = cold_ms = None
         cold_note = None
+        mlp_ms = {}
         if not args.no_secondary and rank == 0:                 # (rank 0 only: the other ranks wait for it in the counter gather)
             # (a) the reference's own protocol, examples/benchbitsand.py:534-550: NO graph, 10 warm-up + 100 timed back-to-back
             # `layer(x)` calls from Python between two events - what a plain Hugging Face loop pays per layer, host cost included
@@ -455,6 +456,38 @@ def main(argv=None):
             cold_ms = c0.elapsed_time(c1) / csteps
             cold_note = f"one hipGraph of {csteps} steps rotating over {copies} layer copies ({copies * wbytes >> 20} MB of weights > 256 MB MALL)"
             del layers, cg
+            # (c) the MLP block this layer sits in (mixquant/modules/fused/mlp.py:57-70: fused norm -> up_proj, gate_proj -> down_proj) at the
+            # same batch: gate_proj + up_proj as ONE launch over their interleaved rows (MIXQ_ACT_SILU_PAIR) against the two launches
+            try:
+                from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP, fused
+                bcache = MixLibCache(rows, sigma=SIGMA, bit=bit, device=device)
+                _, _, up_l = build_layer(device, rows, seed=21, bit=bit, cache=bcache)
+                _, _, gate_l = build_layer(device, rows, seed=22, bit=bit, cache=bcache)
+                torch.manual_seed(23)
+                down_l = MixLinear_GEMM.from_linear(torch.nn.Linear(N, K, bias=False).half(), 8, cache=bcache, dev=device, name="down_proj")
+                norm = FasterTransformerRMSNorm((torch.rand(K) + 0.5).half().to(device), 1e-5, bcache)
+                norm.next_layer = up_l
+                block = MixLlamaMLP(gate_l, down_l, up_l, bcache)
+                bsteps = 20
+                bx = base.unsqueeze(0).repeat(bsteps, 1, 1).contiguous()
+                prev_joint = fused.JOINT_GATE_UP
+                for joint in (False, True):
+                    fused.JOINT_GATE_UP = joint
+                    for _ in range(4):
+                        block(norm(base.clone()))                   # freezes the predictions; the joint image is built on the first frozen forward
+                    torch.cuda.synchronize()
+                    bg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(bg, stream=side):
+                        for i in range(bsteps):
+                            block(norm(bx[i]))
+                    torch.cuda.synchronize()
+                    bms, _, _ = conditioned_replay(bg, side, restore=lambda: bx.copy_(base.unsqueeze(0).expand_as(bx)))
+                    mlp_ms[joint] = bms / bsteps
+                    del bg
+                fused.JOINT_GATE_UP = prev_joint
+                del block, up_l, gate_l, down_l, bx
+            except Exception as exc:                                # (a secondary figure must not take the bench line down)
+                print(f"bench.py: MLP-block secondary timing skipped: {exc!r}", file=sys.stderr)
 
     flops_step = 2.0 * rows * N * K
     max_elapsed, total_flops, per_rank = gather_counters(elapsed, flops_step * steps, world, device, per_rank=True)
@@ -491,7 +524,11 @@ def main(argv=None):
                        "first_replay_ms_per_step": None if first_replay_ms is None else round(first_replay_ms / steps, 5),
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 5),
                        "eager_protocol": "no graph: 10 warm-up + 100 back-to-back layer(x) calls from Python between two events (examples/benchbitsand.py:534-550), rank 0",
-                       "cold_weights_ms_per_step": None if cold_ms is None else round(cold_ms, 5), "cold_weights_protocol": cold_note},
+                       "cold_weights_ms_per_step": None if cold_ms is None else round(cold_ms, 5), "cold_weights_protocol": cold_note,
+                       "mlp_block_ms": None if True not in mlp_ms else round(mlp_ms[True], 5),
+                       "mlp_block_two_launches_ms": None if False not in mlp_ms else round(mlp_ms[False], 5),
+                       "mlp_block_protocol": "fused RMSNorm + quantise -> gate_proj + up_proj (one launch over interleaved rows | two launches) -> down_proj with the row "
+                                             "maxima from the producer, same batch and shape (hidden -> intermediate -> hidden), graph of 20 blocks, same clock conditioning"},
             "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
             "max_abs_err_vs_dequant_linear": round(max_abs_err, 6),
             # (W4A4 on the FP6 pipe is priced against the FP6 dense peak, 2x the int8 one: MI355X_MICROARCH.md "Peak FP6/FP4 MFMA ~10 PF dense")

@@ -146,7 +146,9 @@ class MixLlamaMLP(nn.Module):
         if _L._fmt_of(cache.q_xcache) != (_L.FMT_P16X64 if up.bit == 8 else _L.FMT_R6X128):
             return False
         j = self._joint
-        if (j is None or j["key"] != self._joint_key()) and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        key = self._joint_key()
+        object.__setattr__(self, "_key_now", key)            # (handed to _joint_operands: one identity sweep per forward)
+        if (j is None or j["key"] != key) and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             # the joint image is never BUILT under capture (its packing kernels would be replayed with the graph, and the layers' own
             # images - which that graph is about to address through the two-launch route - would be freed by the build)
             object.__setattr__(self, "_two_launch_captured", True)
@@ -156,7 +158,7 @@ class MixLlamaMLP(nn.Module):
     def _joint_operands(self):
         """The interleaved image + per-channel operands (interleave_pair_rows), rebuilt when anything they were made from changed.  The
         two layers then give up their own packed images: the block keeps ONE copy of these weights."""
-        key = self._joint_key()
+        key = self.__dict__.pop("_key_now", None) or self._joint_key()
         j = self._joint
         if j is not None and j["key"] == key:
             return j
