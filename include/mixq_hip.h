@@ -135,9 +135,11 @@ int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_de
                      uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                      int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
 /* The same pass for a caller that KEEPS the bit-per-column mask of its outlier columns in device memory (a layer whose prediction is
- * frozen: `ind` never changes again): col_mask = little-endian words, bit c set <=> column c is one of ind[0 .. live count), at least
- * K / 32 words (required when n > 0).  Same bytes out; the row maximum no longer waits for the device-resident count, `ind` and the
- * two barriers around building that mask inside the kernel.  mixq_linear_forward takes this route when args->col_mask is set. */
+ * frozen: `ind` never changes again): col_mask = ceil(K / 32) little-endian words, bit c set <=> column c is one of ind[0 .. live count),
+ * FOLLOWED BY ONE WORD holding the number of columns the mask marks (required when n > 0).  Same bytes out; the row maximum no longer waits for the device-resident count, `ind` and the
+ * two barriers around building that mask inside the kernel.  A mask built for another count than the live one (n, or *n_dev when given -
+ * device code may lower it without the host knowing) is ignored: the kernel then builds its own, as mixq_quant_fused does.
+ * mixq_linear_forward takes this route when args->col_mask is set. */
 int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
                             uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                             int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);

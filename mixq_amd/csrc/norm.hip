@@ -72,8 +72,9 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     // starts at once - unmasked it waits for three dependent round trips (count, ind[j], x[ind[j]]) and two barriers around the LDS mask
     const uint8_t* cm = QUANT ? reinterpret_cast<const uint8_t*>(col_mask) : nullptr;
     uint32_t m8g[NCH];
-    int nd0 = n_cap, c0 = 0;
+    int nd0 = n_cap, c0 = 0, mcount = 0;
     if (cm) {
+        mcount = static_cast<int>(col_mask[mask_words]);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * NT;
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
         if (cm) n = nd0 < n_cap ? nd0 : n_cap;
         else if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
         have_out = (n > 0) && ind != nullptr;
+        // (a kept mask built for another count than the live one - lowered in device memory behind the host's back - is not used: quant.hip)
+        if (cm && mcount != (have_out ? n : 0)) cm = nullptr;
         if (have_out && cm) {
             for (int j = tid; j < n; j += NT) {                          // (the gather only: nothing below waits for it)
                 const int c = j == tid ? c0 : ind[j];

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     // device-resident count, nor `ind`, nor the two barriers around building the same mask in LDS - `ind` is only needed for the gather,
     // which is consumed behind the quantised stores.
     const uint8_t* cm = reinterpret_cast<const uint8_t*>(col_mask);
+    const int mcount = col_mask ? static_cast<int>(col_mask[mask_words]) : 0;
     uint32_t m8g[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -234,6 +235,9 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
     const bool have_out = (n > 0) && ind != nullptr && !(dbg & 4);
+    // (the kept mask must describe the LIVE count, which device code may have lowered behind the host's back: the word behind the mask
+    // says how many columns it marks - requested with the row - and a mask built for another count is not used: the kernel builds its own)
+    if (cm && mcount != (have_out ? n : 0)) cm = nullptr;
     // The gather of the outlier values (ind[j] -> x[row][ind[j]]) is a second, dependent memory round trip.  Only the column
     // bitmask has to exist before the row can be processed; the gathered values are REQUESTED here (up to GQ per thread, the rest
     // in the tail loop) and only consumed - stored to x_out, their column zeroed in x - after the quantised row has been written,

@@ -484,7 +484,8 @@ class MixLinear_GEMM(nn.Module):
 
     # ---- this layer's pre-pass maximum as a side output of the GEMM that produces its input (fused/mlp.py:57-70) --------
     def _col_mask(self):
-        """int32 words, bit k set <=> input column k is one of this layer's outlier columns; None without outliers."""
+        """int32 words, bit k set <=> input column k is one of this layer's outlier columns, followed by ONE word holding the number of
+        columns marked (what the quantise passes check a kept mask against: include/mixq_hip.h); None without outliers."""
         n = int(self.ind.shape[0])
         if n == 0:
             return None
@@ -496,6 +497,7 @@ class MixLinear_GEMM(nn.Module):
             bits[ind.long()] = 1
             w = (bits.view(words, 32) << torch.arange(32, device=ind.device, dtype=torch.int64)).sum(dim=1)
             w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)       # the same 32 bits as a signed word
+            w = torch.cat([w, torch.tensor([n], dtype=torch.int32, device=w.device)])
             self._cmask, self._cmask_key = w, key
         return self._cmask
 

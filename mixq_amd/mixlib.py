@@ -649,8 +649,8 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
     else:
         op, ldo, ip = None, 0, None
     if col_mask is not None and n:
-        if col_mask.element_size() != 4 or col_mask.numel() * 32 < K or not col_mask.is_contiguous():
-            raise RuntimeError("QuantFused: col_mask must be contiguous 4-byte words covering all K columns")
+        if col_mask.element_size() != 4 or col_mask.numel() < (K + 31) // 32 + 1 or not col_mask.is_contiguous():
+            raise RuntimeError("QuantFused: col_mask must be contiguous 4-byte words covering all K columns + the count word behind them")
         _capi.call("mixq_quant_fused_masked", xp, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K,
                    ldx, ldo, bit, float(sigma), fmt, _stream())
     else:
@@ -804,8 +804,8 @@ class ForwardPlan:
         # kept_mask: the layer's bit-per-column mask of `ind` (int32 words, >= K / 32): the quantise pass then skips its own mask build
         if kept_mask is not None:
             _dev_check(kept_mask)
-            if kept_mask.element_size() != 4 or kept_mask.numel() * 32 < K or not kept_mask.is_contiguous():
-                raise RuntimeError("ForwardPlan: kept_mask must be contiguous 4-byte words covering all K columns")
+            if kept_mask.element_size() != 4 or kept_mask.numel() < (K + 31) // 32 + 1 or not kept_mask.is_contiguous():
+                raise RuntimeError("ForwardPlan: kept_mask must be contiguous 4-byte words covering all K columns + the count word behind them")
         self.kept_mask = kept_mask if n_cap else None
         self.keep = (ind_buf, n_dev, x_scale, q_w, scale_col, w_out, bias, kept_mask)
         self.M, self.N, self.K, self.ldx, self.n, self.qfmt, self.device = M, N, K, ldx, n, qfmt, x_scale.device
@@ -881,8 +881,8 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
     else:
         x_out, xop, ldxo, ip = None, None, 0, None
     if col_mask is not None and n:
-        if col_mask.element_size() != 4 or col_mask.numel() * 32 < K or not col_mask.is_contiguous():
-            raise RuntimeError("RMSNormQuantFused: col_mask must be contiguous 4-byte words covering all K columns")
+        if col_mask.element_size() != 4 or col_mask.numel() < (K + 31) // 32 + 1 or not col_mask.is_contiguous():
+            raise RuntimeError("RMSNormQuantFused: col_mask must be contiguous 4-byte words covering all K columns + the count word behind them")
         _capi.call("mixq_rmsnorm_quant_fused_masked", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(),
                    q.data_ptr(), xop, _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), fmt, _stream())
     else:

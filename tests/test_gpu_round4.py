@@ -277,7 +277,7 @@ def test_quantise_pass_with_the_kept_column_mask_writes_the_same_bytes(bit, fmt,
     bits = torch.zeros(words * 32, dtype=torch.int64)
     bits[cols.long()] = 1
     w = (bits.view(words, 32) << torch.arange(32, dtype=torch.int64)).sum(dim=1)
-    mask = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).to(DEV)
+    mask = torch.cat([torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32), torch.tensor([ncols], dtype=torch.int32)]).to(DEV)   # (+ the count word)
     outs = []
     for cm in (None, mask):
         xd = x.clone().to(DEV)
@@ -325,7 +325,7 @@ def test_fused_norm_with_the_kept_column_mask_writes_the_same_bytes(bit, fmt, M,
     bits = torch.zeros(words * 32, dtype=torch.int64)
     bits[cols.long()] = 1
     w = (bits.view(words, 32) << torch.arange(32, dtype=torch.int64)).sum(dim=1)
-    mask = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).to(DEV)
+    mask = torch.cat([torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32), torch.tensor([ncols], dtype=torch.int32)]).to(DEV)   # (+ the count word)
     outs = []
     for cm in (None, mask):
         xd = x.clone().to(DEV)
