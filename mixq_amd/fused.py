@@ -194,6 +194,14 @@ class MixLlamaMLP(nn.Module):
         return j
 
     def _apply(self, fn, *args, **kwargs):
+        j = self._joint
+        if j is not None and j.get("captured") and not getattr(self, "allow_move_after_capture", False) and j["wpk"].is_cuda:
+            here = j["wpk"].device
+            if fn(torch.empty(0, device=here)).device != here:
+                # (as MixLinear_GEMM._apply: a hipGraph captured through the joint route replays the raw address of the joint image)
+                raise RuntimeError("MixLlamaMLP: this block ran under hipGraph capture; moving it to another device would leave that graph with "
+                                   "dangling addresses.  Drop the graph first, then set block.allow_move_after_capture = True (re-capture after "
+                                   "the move).")
         out = super()._apply(fn, *args, **kwargs)
         j = self._joint
         if j is not None:                                    # the joint image is the only copy of gate_proj's / up_proj's weights: it follows the module
@@ -212,6 +220,8 @@ class MixLlamaMLP(nn.Module):
             cache.n_dev = None
         cache.ind = up.ind
         j = self._joint_operands()
+        if not j.get("captured") and torch.cuda.is_current_stream_capturing():
+            j["captured"] = True                             # a graph out there replays the joint image's address (see _apply)
         n = int(up.ind.shape[0])
         xo = wo = n_dev = None
         n_cap = 0

@@ -366,3 +366,31 @@ def test_joint_image_is_never_built_under_capture_and_a_graph_of_the_two_launch_
         assert inner2._joint is not None and not inner2.up_proj_._d.retired and not inner2.gate_proj_._d.retired
     finally:
         fused.JOINT_GATE_UP = prev
+
+
+def test_moving_a_block_captured_on_the_joint_route_raises():
+    """A graph captured through the joint route replays the joint image's raw address: .to(another device) must not free it silently."""
+    M, H, F = 64, 256, 512
+    inner, norm, cache, xs = _block(M, H, F, False)
+    for x in xs[:4]:
+        inner(norm(x.clone().to(DEV)))
+    assert inner._joint is not None
+    side = torch.cuda.Stream()
+    xg = xs[4].clone().to(DEV)
+    with torch.cuda.stream(side):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            inner(norm(xg))
+    torch.cuda.synchronize()
+    assert inner._joint.get("captured")
+    with pytest.raises(RuntimeError, match="hipGraph capture"):
+        inner.cpu()
+    inner.to(DEV)                                                      # (same device: nothing moves, nothing raised)
+    del gr
+    inner.allow_move_after_capture = True
+    for l in (inner.up_proj_, inner.gate_proj_, inner.down_proj_):
+        l.allow_move_after_capture = True
+    inner.cpu()
+    assert not inner._joint["wpk"].is_cuda
+    sd = inner.state_dict()                                            # the layers' rows come back out of the (host) joint image
+    assert sd["up_proj_.q_weight"].shape == (F, H) and sd["gate_proj_.q_weight"].dtype == torch.int8
