@@ -116,7 +116,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #ifdef MIXQ_NO_WRAP_TAIL
     constexpr bool WRAP = F6R || ABLK == 41;
 #else
-    constexpr bool WRAP = F6R || ABLK == 41 || (Q == 0 && (ABLK == 0 || ABLK == 6 || (ABLK >= 60 && ABLK < 80) || ABLK == 90) && LOADERS != 0);
+    constexpr bool WRAP = F6R || ABLK == 41 || (Q == 0 && (ABLK == 0 || ABLK == 6 || (ABLK >= 60 && ABLK < 80)) && LOADERS != 0);
 #endif
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int LOADS = STAGE_BYTES / 1024 / ISSUERS;  // 1 KiB DMA pieces per issuing wave and stage
     constexpr int TLOADS = MB / ISSUERS;                 // the fp16 tail's X_out blocks per issuing wave
     constexpr int WL = F6 ? 2 * WNB : WNB;               // load instructions of one k-step's weight fragments (per wave)
-    // PAIR (ABLK = 90; MIXQ_ACT_SILU_PAIR): gate_proj and up_proj of an MLP block as ONE GEMM.  The weight rows are interleaved in groups of
+    // PAIR (template parameter ABL = 90; MIXQ_ACT_SILU_PAIR): gate_proj and up_proj of an MLP block as ONE GEMM.  The weight rows are interleaved in groups of
     // four - up[2g], up[2g+1], gate[2g], gate[2g+1] (scale_col, bias and weight_cache rows likewise) - so the four consecutive channels a
     // lane holds of a 16 x 16 accumulator block ARE the two (up, gate) pairs of output channels 2g, 2g+1: the product
     // (silu(gate) + bias_gate) * fp16(up + bias_up) is lane-local, leaves the epilogue as ONE packed fp16 pair, and the tile stages and
