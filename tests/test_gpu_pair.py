@@ -394,3 +394,51 @@ def test_moving_a_block_captured_on_the_joint_route_raises():
     assert not inner._joint["wpk"].is_cuda
     sd = inner.state_dict()                                            # the layers' rows come back out of the (host) joint image
     assert sd["up_proj_.q_weight"].shape == (F, H) and sd["gate_proj_.q_weight"].dtype == torch.int8
+
+
+def test_random_shapes_one_launch_equals_two_launches():
+    """Forty seeded random problems (ragged token counts, tiles hanging over N by every number of 16-column blocks, 1 .. 40 k-steps, 0 .. 200
+    outlier columns, with and without bias, automatic and forced tilings): the joint launch against the two launches, bit for bit.  Random
+    int8 operands straight from the generator - no oracle in the loop, so it runs in seconds."""
+    rng = np.random.default_rng(2026)
+    lib, names = _capi.load(), _capi.gemm_config_names()
+    forms = [-1] + [names.index(nm) for nm in ("wr128x192_s16_d4_l2", "wr128x256_s16_d3_l2", "wr64x192_s16_d4_l2", "wr64x256_s16_d4_l2", "wr32x64_s8_d6_l1")]
+    try:
+        for case in range(40):
+            M = int(rng.integers(1, 700))
+            N = int(rng.integers(1, 160)) * 8                               # per layer; 2N % 16 == 0
+            K = int(rng.integers(1, 41)) * 64
+            n_out = int(rng.choice([0, 0, 1, 15, 16, 17, 33, 64, 65, 129, 200]))
+            n_out = min(n_out, K)
+            bias = bool(rng.integers(0, 2))
+            g = torch.Generator().manual_seed(case)
+            qx = mixlib.PackOperand(torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV), 1)
+            sx = (torch.rand((M, 1), generator=g) * 0.02 + 0.001).half().to(DEV)
+            pad = (n_out + 15) // 16 * 16
+            xo = (torch.randn((M, max(pad, 16)), generator=g) * 3).half().to(DEV)[:, :n_out] if n_out else None
+            lay = []
+            for _ in range(2):
+                qw = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+                sw = (torch.rand((1, N), generator=g) * 0.002 + 0.0001).half().to(DEV)
+                wo = (torch.randn((N, max(pad, 16)), generator=g) * 0.05).half().to(DEV)[:, :n_out] if n_out else None
+                b = torch.randn(N, generator=g).half().to(DEV) if bias else None
+                lay.append((qw, sw, wo, b))
+            (qu, su, wu, bu), (qg, sg, wg, bg) = lay
+            up = mixlib.FusedLinear(qx, mixlib.PackOperand(qu, 2), sx, su, xo, wu, n_out, bu, M, N, K)
+            ref = mixlib.FusedLinear(qx, mixlib.PackOperand(qg, 2), sx, sg, xo, wg, n_out, bg, M, N, K, act=_capi.ACT_SILU_MUL, addend=up)
+            jw = mixlib.PackOperand(interleave_pair_rows(qu, qg), 2)
+            jsw = interleave_pair_rows(su.reshape(-1), sg.reshape(-1)).reshape(1, -1)
+            jwo = None
+            if n_out:
+                jwo = torch.zeros((2 * N, pad), dtype=torch.float16, device=DEV)
+                jwo[:, :n_out] = interleave_pair_rows(wu, wg)
+                jwo = jwo[:, :n_out]
+            jb = interleave_pair_rows(bu, bg) if bias else None
+            cfg = forms[case % len(forms)]
+            assert lib.mixq_gemm_set_config(cfg) == 0
+            y = mixlib.FusedLinear(qx, jw, sx, jsw, xo, jwo, n_out, jb, M, 2 * N, K, act=_capi.ACT_SILU_PAIR)
+            lib.mixq_gemm_set_config(-1)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all() and torch.equal(y, ref), (case, M, N, K, n_out, bias, names[cfg] if cfg >= 0 else "auto", int((y != ref).sum()))
+    finally:
+        lib.mixq_gemm_set_config(-1)
