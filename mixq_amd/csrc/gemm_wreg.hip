@@ -86,6 +86,9 @@ template <int I, int N, class F> __device__ __forceinline__ void wr_static_for(F
 // 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only, 4 weight loads issued but never waited for, 5 the loader
 // never waits for its DMA, 6 no k-loop barriers (4-6: timing probes, results are garbage), 7 no stores of Y, 8 ordinary instead of
 // nt stores, 9 return at entry, 12 no prologue ramp in the loader.
+#ifndef MIXQ_PAIR_ST
+#define MIXQ_PAIR_ST 2                      // cache policy of the joint gate / up form's stores of Y: 2 = nt (streaming), 0 = ordinary (A/B build switch)
+#endif
 template <int MB, int WNB, int NSTAGE, int D, int Q, int LOADERS, int ABL>
 __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const WrArgs a)
 {
@@ -275,7 +278,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         for (int it = 0; it < IT; ++it) v[it] = *reinterpret_cast<const u32x4*>(lds + p * PROWS * OPITCH + loff[it]);
         if (ABLK != 7 || a.act == 12345) {
 #pragma unroll
-            for (int it = 0; it < IT; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs, voff[it], 0, ABLK == 8 ? 0 : 2 /* nt */);
+            for (int it = 0; it < IT; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs, voff[it], 0, ABLK == 8 ? 0 : (PAIR ? MIXQ_PAIR_ST : 2 /* nt */));
         }
     };
     uint32_t voffA[IT_A];                                                        // this thread's chunks when all NT threads copy a panel
