@@ -8,13 +8,16 @@ step    : ONE full forward of MixLinear_GEMM over one 512-token batch already re
           (i)+(ii) fused extract/zero/absmax/quantise kernel  +  (iii)+(iv) int8 MFMA GEMM with fused dequant,
           fp16 outlier tail and (absent for Llama) bias.  Each step gets its own pristine activation buffer (the
           operator zeroes outlier columns in place, as the reference does), so no restore copy sits in the timed region.
-timing  : the K steps are ONE hipGraph; barrier + synchronize on both sides of the timed region; the clock is a pair of HIP
-          events on the launch stream (the host wall time around the same region is reported beside it); MAX over ranks.
+timing  : the K steps are ONE hipGraph; barrier + synchronize on both sides of the timed region; the clock is HIP events on the launch
+          stream (the host wall time around the same region is reported beside it); MAX over ranks.
           The metric is SUSTAINED throughput, and an MI355X needs 15-25 ms of continuous work to reach the clock it sustains
           (measured: the same graph replayed from idle runs 33-34 us per step for its first 2-3 ms, 30.9 us from ~12 ms on), so
           after the W warm-up steps and before the timed region the captured graph is replayed, untimed, for ~40 ms
-          (CLOCK_SETTLE_MS; the inputs are restored afterwards).  The timed region is still exactly the K steps; the figure of the
-          FIRST replay after idle is reported beside it (timing.first_replay_ms_per_step).
+          (CLOCK_SETTLE_MS; the inputs are restored afterwards).  One replay of a 20-step graph is a 0.6 ms sample that also carries
+          the graph-launch latency (~45 us per replay from an idle stream: BENCH_r04's eager loop beat its own graph figure), so the
+          timed region is --replays (31) back-to-back replays of the K-step graph, each between its own pair of events with the device
+          never idle between them, and ms_per_step = MEDIAN replay / K (timing.replay_ms_min / median / max carry the spread; the
+          single-replay figure of rounds 1-4 and the first replay after idle are reported beside it).  A step computes what it always did.
 N GPUs  : one process per GPU, no data-path collective, one all_gather of {elapsed, flops} at the end.
           --scaling weak (default): every rank runs the same K steps on its own 512-token batches;
           --scaling strong: the 512 rows are split over the ranks (bench.shard_rows), weights replicated.
@@ -44,12 +47,36 @@ SIGMA = 6
 CLOCK_SETTLE_MS = 40.0       # untimed graph replays in front of the timed region: the chip's clock needs this long to settle under load
 
 
-def conditioned_replay(graph, stream, restore=None, settle_ms=None):
+def timed_replays(graph, stream, replays, restore=None):
+    """`replays` back-to-back replays of a captured hipGraph, every one between its own pair of HIP events on the launch stream, all
+    queued before the host waits once: the device goes from one replay straight into the next (`restore()`, when given, puts the inputs
+    back between two replays, OUTSIDE every event pair - the forward zeroes outlier columns in place).  Returns the list of per-replay
+    milliseconds.  A single replay of a 20-step graph is a 0.6 ms sample with >= 7 % run-internal scatter; the median of
+    >= 31 such samples is what bench.py reports."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(replays)]
+    with torch.cuda.stream(stream):                                 # restore, events and replays all ordered on the launch stream
+        for a, b in ev:
+            if restore is not None:
+                restore()
+            a.record(stream)
+            graph.replay()
+            b.record(stream)
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in ev]
+
+
+def median(vals):
+    v = sorted(vals)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def conditioned_replay(graph, stream, restore=None, settle_ms=None, replays=9):
     """THE measurement protocol of this repository for a captured hipGraph (bench.py and every tools/ script that quotes microseconds):
     (1) the first replay after idle is timed and reported, never used; (2) the graph is replayed untimed for ~CLOCK_SETTLE_MS so the
-    chip sits at the clock it sustains under this load (15-25 ms on MI355X; a 100-step graph is over in 3 ms); (3) `restore()` puts the
-    inputs back (the forward zeroes outlier columns in place); (4) ONE replay between two events on the launch stream is the figure.
-    Returns (timed_ms, first_replay_ms, untimed_replays)."""
+    chip sits at the clock it sustains under this load (15-25 ms on MI355X; a 100-step graph is over in 3 ms); (3) `replays` replays
+    back to back, each between its own event pair on the launch stream, the inputs restored between them (timed_replays); the MEDIAN
+    is the figure.  Returns (median_ms, first_replay_ms, untimed_replays)."""
     settle_ms = CLOCK_SETTLE_MS if settle_ms is None else settle_ms
     f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     f0.record(stream)
@@ -61,22 +88,15 @@ def conditioned_replay(graph, stream, restore=None, settle_ms=None):
     for _ in range(reps):
         graph.replay()
     torch.cuda.synchronize()
-    if restore is not None:
-        restore()
-        torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    graph.replay()
-    e1.record(stream)
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1), first_ms, reps
+    return median(timed_replays(graph, stream, replays, restore)), first_ms, reps
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20, help="forwards per timed region = per hipGraph (the driver runs --steps 20 --warmup 5)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--replays", type=int, default=31, help="back-to-back timed replays of the K-step graph; the median is reported")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--shape", default=None, help="K,N of the Linear (default 4096,11008); e.g. 8192,28672 for BASELINE config 3")
     ap.add_argument("--batch", type=int, default=None, help="token rows M (default 512)")
@@ -368,22 +388,38 @@ def main(argv=None):
                 graph.replay()
             torch.cuda.synchronize()
             pristine.copy_(base.unsqueeze(0).expand_as(pristine))
+        restore_inputs = lambda: pristine.copy_(base.unsqueeze(0).expand_as(pristine))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         barrier(world, device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        e0.record(side)
+        replay_ms = None
         if graph is not None:
-            graph.replay()
+            # the K-step graph replayed `--replays` times back to back, each replay between its own pair of events (the device never
+            # idles between them; the inputs are restored between replays, outside the event pairs): the MEDIAN replay is the figure
+            replay_ms = timed_replays(graph, side, args.replays, restore_inputs)
+            host_elapsed = (time.perf_counter() - t0) / args.replays
+            elapsed = median(replay_ms) * 1e-3
         else:
+            e0.record(side)
             for i in range(steps):
                 one_step(i)
-        e1.record(side)
-        torch.cuda.synchronize()
-        host_elapsed = time.perf_counter() - t0
+            e1.record(side)
+            torch.cuda.synchronize()
+            host_elapsed = time.perf_counter() - t0
+            elapsed = e0.elapsed_time(e1) * 1e-3                # seconds between the two events on the launch stream
         barrier(world, device)
-        elapsed = e0.elapsed_time(e1) * 1e-3                    # seconds between the two events on the launch stream
+        # the previous rounds' figure, kept beside the median: ONE replay between two events, from a synchronised (idle) stream
+        single_ms = None
+        if graph is not None:
+            restore_inputs()
+            torch.cuda.synchronize()
+            e0.record(side)
+            graph.replay()
+            e1.record(side)
+            torch.cuda.synchronize()
+            single_ms = e0.elapsed_time(e1)
 
         # ---- dominant kernel (the int8 MFMA GEMM + fused epilogue) alone, HIP events on the launch stream ------------
         ind_buf, n_dev = layer._ind_dev()
@@ -518,7 +554,16 @@ def main(argv=None):
                        "operand_format": {"activations": {0: "plain", 1: "P16x64", 4: "R6x128 (int4 as FP6 E3M2 codes, row-contiguous)"}[fmt],
                                "weights": {0: "plain", 1: "P16x64", 2: "F16x64", 3: "F6x128 (int4 as FP6 E3M2 codes)"}[mixlib.fmt_of(layer._wpk)]},
                        "weight_bytes_resident": int(layer._wpk.numel() + (0 if layer._buffers['q_weight'] is None else layer._buffers['q_weight'].numel()))},
-            "timing": {"clock": "HIP events on the launch stream around the K steps", "host_wall_ms_per_step": round(max_host * 1e3 / steps, 5),
+            "timing": {"clock": "HIP events on the launch stream around the K steps" if graph is None else
+                                f"HIP events on the launch stream around each of {args.replays} back-to-back replays of the K-step graph (inputs restored "
+                                f"between replays, outside the event pairs); ms_per_step = MEDIAN replay / K",
+                       "replays": None if replay_ms is None else len(replay_ms),
+                       "replay_ms_min": None if replay_ms is None else round(min(replay_ms), 5),
+                       "replay_ms_median": None if replay_ms is None else round(median(replay_ms), 5),
+                       "replay_ms_max": None if replay_ms is None else round(max(replay_ms), 5),
+                       "single_replay_ms_per_step": None if single_ms is None else round(single_ms / steps, 5),
+                       "single_replay_protocol": "ONE replay between two events from a synchronised stream (rounds 1-4's figure; carries the graph-launch latency)",
+                       "host_wall_ms_per_step": round(max_host * 1e3 / steps, 5),
                        "per_rank_ms_per_step": [round(v * 1e3 / steps, 5) for v in per_rank],
                        "clock_settle": None if graph is None else f"{settle_reps} untimed replays of the captured graph (~{CLOCK_SETTLE_MS:.0f} ms) between the warm-up and the timed region",
                        "first_replay_ms_per_step": None if first_replay_ms is None else round(first_replay_ms / steps, 5),

@@ -134,12 +134,20 @@ int mixq_extract_outliers_zero(uint16_t* x, const int32_t* ind, int n, uint16_t*
 int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev,
                      uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                      int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
-/* The same pass for a caller that KEEPS the bit-per-column mask of its outlier columns in device memory (a layer whose prediction is
- * frozen: `ind` never changes again): col_mask = ceil(K / 32) little-endian words, bit c set <=> column c is one of ind[0 .. live count),
- * FOLLOWED BY ONE WORD holding the number of columns the mask marks (required when n > 0).  Same bytes out; the row maximum no longer waits for the device-resident count, `ind` and the
- * two barriers around building that mask inside the kernel.  A mask built for another count than the live one (n, or *n_dev when given -
- * device code may lower it without the host knowing) is ignored: the kernel then builds its own, as mixq_quant_fused does.
- * mixq_linear_forward takes this route when args->col_mask is set. */
+/* The same pass for a caller that KEEPS an OUTLIER MAP of its columns in device memory (a layer whose prediction is frozen: `ind` never
+ * changes again).  col_mask = int32 words:
+ *     [W = ceil(K / 32) little-endian words : bit c set <=> column c is one of ind[0 .. live count)]
+ *     [1 word                               : the number of columns the map marks]
+ *     [pad to a multiple of 4 words]
+ *     [K uint16, two per word, low half first : pos[c] = j with ind[j] == c, 0xffff for every other column]   (K, n < 65535)
+ * (required when n > 0).  Same bytes out.  With the map every byte the pass needs arrives in ONE memory round trip: the eight positions of
+ * a 16-byte chunk are requested beside the chunk, the outlier values are taken out of the registers that hold the row (an LDS copy of the
+ * x_out row, stored as a whole), the marked halves are zeroed in the chunk, which goes back to x - the row maximum waits for neither the
+ * device-resident count, nor `ind`, nor a mask build in LDS, and there is no dependent gather ind[j] -> x[row][ind[j]] behind the row
+ * load (5.2 -> see profiles/r05_quant_kept_map.txt us at 512 x 4096, 41 columns).  A map built for another count than the live one (n, or
+ * *n_dev when given - device code may lower it without the host knowing) is ignored: the kernel then builds its own mask, as
+ * mixq_quant_fused does; so is a map for more than 4096 (padded) outlier columns.  A producing GEMM reads only the bit words
+ * (mixq_gemm_i8_fused_amax).  mixq_linear_forward takes this route when args->col_mask is set. */
 int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
                             uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                             int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
@@ -280,7 +288,7 @@ int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weight, uint16_t
                              const int32_t* n_dev, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                              int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma, int qfmt,
                              mixq_stream_t stream);
-/* ... with the next layer's kept bit-per-column mask of its outlier columns (see mixq_quant_fused_masked): same bytes out */
+/* ... with the next layer's kept outlier map (layout: mixq_quant_fused_masked): same bytes out */
 int mixq_rmsnorm_quant_fused_masked(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
                                     const int32_t* n_dev, const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out,
                                     int32_t* flag, int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma,

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     void* __restrict__ q, uint16_t* __restrict__ x_out, int ldxo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt,
     const uint32_t* __restrict__ col_mask)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];     // column bitmask, then 8 floats
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];     // column bitmask, 8 floats, [ldxo] fp16: the x_out row (kept route)
     const int row = blockIdx.x, tid = threadIdx.x;
     const int mask_words = (K + 31) >> 5;
     float* red = reinterpret_cast<float*>(smem + mask_words);
@@ -67,21 +67,21 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
             wk[i] = reinterpret_cast<const uint4*>(w)[c];
         }
     }
-    // col_mask (mixq_rmsnorm_quant_fused_masked): the caller's kept bit-per-column mask of `ind`.  A chunk's eight bits are one byte of
-    // it, requested here with the row, and so are the live count and this thread's `ind` entry: behind the sum of squares the row maximum
-    // starts at once - unmasked it waits for three dependent round trips (count, ind[j], x[ind[j]]) and two barriers around the LDS mask
-    const uint8_t* cm = QUANT ? reinterpret_cast<const uint8_t*>(col_mask) : nullptr;
-    uint32_t m8g[NCH];
-    int nd0 = n_cap, c0 = 0, mcount = 0;
-    if (cm) {
+    // col_mask (mixq_rmsnorm_quant_fused_masked): the next layer's KEPT OUTLIER MAP (bits, count, per-column positions: quant.hip).  A
+    // chunk's eight positions are 16 bytes of it, requested here with the row and the live count: the normalised outlier values are then
+    // taken out of the registers that hold the row - unmasked they cost three dependent round trips (count, ind[j], x[ind[j]]) and two
+    // barriers around the LDS mask in front of the row maximum.
+    const uint4* pv = (QUANT && col_mask) ? reinterpret_cast<const uint4*>(col_mask + ((mask_words + 1 + 3) & ~3)) : nullptr;
+    uint4 pg[NCH];
+    int nd0 = n_cap, mcount = 0;
+    if (pv) {
         mcount = static_cast<int>(col_mask[mask_words]);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * NT;
-            m8g[i] = c < nchunk ? cm[c] : 0u;
+            pg[i] = c < nchunk ? pv[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
         }
         if (n_dev) nd0 = *n_dev;
-        if (tid < n_cap) c0 = ind[tid];                                 // (inside the capacity-padded buffer; used only below the live count)
     }
     float ss = 0.f;
 #pragma unroll
@@ -103,21 +103,16 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
     const float inv = 1.0f / sqrtf(total / static_cast<float>(K) + eps);
 
     int n = 0;
-    bool have_out = false;
+    bool have_out = false, kept = false;
+    uint16_t* stage = reinterpret_cast<uint16_t*>(red + 8);              // kept route: this row of x_out, assembled in LDS
     if constexpr (QUANT) {
         n = n_cap;
-        if (cm) n = nd0 < n_cap ? nd0 : n_cap;
+        if (pv) n = nd0 < n_cap ? nd0 : n_cap;
         else if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
         have_out = (n > 0) && ind != nullptr;
-        // (a kept mask built for another count than the live one - lowered in device memory behind the host's back - is not used: quant.hip)
-        if (cm && mcount != (have_out ? n : 0)) cm = nullptr;
-        if (have_out && cm) {
-            for (int j = tid; j < n; j += NT) {                          // (the gather only: nothing below waits for it)
-                const int c = j == tid ? c0 : ind[j];
-                const uint16_t yv = norm1(xr[c], inv, w[c]);
-                if (x_out) x_out[static_cast<size_t>(row) * ldxo + j] = yv;
-            }
-        } else if (have_out) {
+        // (a kept map built for another count than the live one - lowered in device memory behind the host's back - is not used: quant.hip)
+        kept = pv != nullptr && have_out && mcount == n;
+        if (have_out && !kept) {
             for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
             __syncthreads();
             for (int j = tid; j < n; j += NT) {
@@ -127,8 +122,8 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
                 atomicOr(&smem[c >> 5], 1u << (c & 31));
             }
         }
-        if (x_out) for (int j = (have_out ? n : 0) + tid; j < ldxo; j += NT) x_out[static_cast<size_t>(row) * ldxo + j] = 0;
-        if (have_out && !cm) __syncthreads();
+        if (x_out && !kept) for (int j = (have_out ? n : 0) + tid; j < ldxo; j += NT) x_out[static_cast<size_t>(row) * ldxo + j] = 0;
+        if (have_out && !kept) __syncthreads();
     }
 
     float amax = 0.f;
@@ -138,7 +133,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
         if (c < nchunk) {
             const uint32_t d[4] = {keep[i].x, keep[i].y, keep[i].z, keep[i].w};
             const uint32_t g[4] = {wk[i].x, wk[i].y, wk[i].z, wk[i].w};
-            const uint32_t m8 = cm ? m8g[i] : (have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u);
+            const uint32_t m8 = (!kept && have_out) ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
             uint32_t y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -147,15 +142,20 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(
                 if (m8 & (1u << (2 * e)))     lo = 0;
                 if (m8 & (1u << (2 * e + 1))) hi = 0;
                 y[e] = lo | (hi << 16);
-                amax = fmaxf(amax, fmaxf(fabsf(h2f(static_cast<uint16_t>(lo))), fabsf(h2f(static_cast<uint16_t>(hi)))));
             }
             keep[i] = make_uint4(y[0], y[1], y[2], y[3]);
+            if (kept) (void)kept_extract8(keep[i], pg[i], stage, ldxo);    // normalised outlier values -> the LDS copy of the x_out row; zeroed in the chunk
+            const uint32_t z[4] = {keep[i].x, keep[i].y, keep[i].z, keep[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                amax = fmaxf(amax, fmaxf(fabsf(h2f(static_cast<uint16_t>(z[e] & 0xffffu))), fabsf(h2f(static_cast<uint16_t>(z[e] >> 16)))));
             reinterpret_cast<uint4*>(out + static_cast<size_t>(row) * ldout)[c] = keep[i];
         }
     }
     if constexpr (!QUANT) return;
 
-    amax = block_max(amax, red + 4);
+    amax = block_max(amax, red + 4);                                      // (its barrier also orders the LDS copy of the x_out row)
+    if (kept && x_out) for (int j = tid; j < ldxo; j += NT) x_out[static_cast<size_t>(row) * ldxo + j] = j < n ? stage[j] : static_cast<uint16_t>(0);
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
     const float s = h2f(sh);
@@ -227,7 +227,7 @@ int launch_norm(const uint16_t* x, int ldx, const uint16_t* w, float eps, uint16
                 const int32_t* n_dev, uint16_t* x_scale, void* q, uint16_t* x_out, int ldxo, int32_t* flag, int M, int K,
                 float thr, int qfmt, hipStream_t st, const uint32_t* col_mask = nullptr)
 {
-    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + 8) * sizeof(uint32_t);
+    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + 8) * sizeof(uint32_t) + (col_mask ? static_cast<size_t>(ldxo) * 2 + 4 : 0);
     const int nchunk = K >> 3;
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g(M), b(NT);
@@ -270,6 +270,7 @@ static int rmsnorm_quant_common(const uint16_t* x, const uint16_t* weight, uint1
     const float qmax = static_cast<float>((1 << (bit - 1)) - 1);
     const float thr = fp16_round(fp16_round(sigma) / qmax);
     uint16_t* xo = (n > 0) ? x_out : nullptr;
+    if (ldxo > 4096 || K > 65528) col_mask = nullptr;   // (as mixq_quant_fused_masked: the kept route assembles the x_out row in LDS, 16-bit columns)
     if (bit == 8)
         return launch_norm<8, true>(x, ldx, weight, eps, out, ldout, ind, n, n_dev, x_scale, q, xo, ldxo, flag, M, K, thr, qfmt,
                                     mixq_stream(stream), col_mask);
@@ -284,7 +285,7 @@ extern "C" int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weigh
 {
     return rmsnorm_quant_common(x, weight, out, ind, n, n_dev, nullptr, x_scale, q, x_out, flag, M, K, ldx, ldout, ldxo, eps, bit, sigma, qfmt, stream);
 }
-// ... for a next layer whose prediction is frozen: its kept bit-per-column mask of the live `ind` entries (as mixq_quant_fused_masked)
+// ... for a next layer whose prediction is frozen: its kept outlier map (as mixq_quant_fused_masked)
 extern "C" int mixq_rmsnorm_quant_fused_masked(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
                                                const int32_t* n_dev, const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out,
                                                int32_t* flag, int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma,

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     int32_t* __restrict__ flag, int M, int K, float thr_scale, int rows16, int fmt, int dbg, const uint32_t* __restrict__ col_mask)
 {
     constexpr int NT = TPR * RPB, WPR = TPR / 64;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32] column bitmask, RPB * WPR floats
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32] column bitmask, RPB * WPR floats, [RPB][ldo] fp16: the x_out rows (kept route)
     const int tid = threadIdx.x, rw = tid / TPR, t = tid - rw * TPR;
     const int row = blockIdx.x * RPB + rw;
     const bool valid = row < M;
@@ -220,48 +220,47 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         const int c = chunk(i);
         keep[i] = (valid && c < nchunk) ? xv[c] : make_uint4(0, 0, 0, 0);
     }
-    // col_mask (mixq_quant_fused_masked): the caller keeps the bit-per-column mask of `ind` in device memory (a frozen layer's never
-    // changes).  A chunk's eight mask bits are ONE byte of it, requested here beside the row: the maximum then waits for neither the
-    // device-resident count, nor `ind`, nor the two barriers around building the same mask in LDS - `ind` is only needed for the gather,
-    // which is consumed behind the quantised stores.
-    const uint8_t* cm = reinterpret_cast<const uint8_t*>(col_mask);
+    // col_mask (mixq_quant_fused_masked): the caller's KEPT OUTLIER MAP (a frozen layer's never changes; layout above).  A chunk's eight
+    // positions are 16 bytes of it, requested here beside the row: everything the pass needs then arrives in ONE memory round trip - the
+    // row maximum waits for neither the device-resident count, nor `ind`, nor the two barriers around building a mask in LDS, and the
+    // outlier values are taken from the registers that hold the row (no second, dependent round trip for x[row][ind[j]]).
+    const uint4* pv = col_mask ? kept_pos_table(col_mask, K) : nullptr;
     const int mcount = col_mask ? static_cast<int>(col_mask[mask_words]) : 0;
-    uint32_t m8g[NCH];
+    uint4 pg[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = chunk(i);
-        m8g[i] = (cm && c < nchunk) ? cm[c] : 0u;
+        pg[i] = (pv && c < nchunk) ? pv[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
     }
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
     const bool have_out = (n > 0) && ind != nullptr && !(dbg & 4);
-    // (the kept mask must describe the LIVE count, which device code may have lowered behind the host's back: the word behind the mask
-    // says how many columns it marks - requested with the row - and a mask built for another count is not used: the kernel builds its own)
-    if (cm && mcount != (have_out ? n : 0)) cm = nullptr;
-    // The gather of the outlier values (ind[j] -> x[row][ind[j]]) is a second, dependent memory round trip.  Only the column
-    // bitmask has to exist before the row can be processed; the gathered values are REQUESTED here (up to GQ per thread, the rest
+    // (the kept map must describe the LIVE count, which device code may have lowered behind the host's back: the word behind the bits
+    // says how many columns it marks - requested with the row - and a map built for another count is not used: the kernel builds its own mask)
+    const bool kept = pv != nullptr && have_out && mcount == n;
+    uint16_t* stage = reinterpret_cast<uint16_t*>(red + RPB * WPR) + rw * ldo;   // kept route: this row's x_out, assembled in LDS
+    // Without a kept map the gather of the outlier values (ind[j] -> x[row][ind[j]]) is a second, dependent memory round trip.  Only the
+    // column bitmask has to exist before the row can be processed; the gathered values are REQUESTED here (up to GQ per thread, the rest
     // in the tail loop) and only consumed - stored to x_out, their column zeroed in x - after the quantised row has been written,
     // so that round trip runs beside the absmax / quantise work instead of in front of it.
     constexpr int GQ = 2;
     int gcol[GQ] = {-1, -1};
     uint16_t gval[GQ] = {0, 0};
-    if (have_out) {
-        if (!cm) for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
+    if (have_out && !kept) {
+        for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
 #pragma unroll
         for (int g = 0; g < GQ; ++g) { const int j = t + g * TPR; if (j < n) gcol[g] = ind[j]; }
-        if (!cm) {
-            __syncthreads();
-            if (rw == 0) {                                     // one row's threads build the mask for the whole workgroup
+        __syncthreads();
+        if (rw == 0) {                                     // one row's threads build the mask for the whole workgroup
 #pragma unroll
-                for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0) atomicOr(&smem[gcol[g] >> 5], 1u << (gcol[g] & 31));
-                for (int j = t + GQ * TPR; j < n; j += TPR) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
-            }
+            for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0) atomicOr(&smem[gcol[g] >> 5], 1u << (gcol[g] & 31));
+            for (int j = t + GQ * TPR; j < n; j += TPR) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
         }
         if (valid) {
 #pragma unroll
             for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0 && !(dbg & 2)) gval[g] = xr[gcol[g]];
         }
-        if (!cm) __syncthreads();
+        __syncthreads();
     }
 
     uint32_t amax_acc = 0u;
@@ -269,8 +268,15 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     for (int i = 0; i < NCH; ++i) {
         const int c = chunk(i);
         if (c < nchunk) {
-            const uint32_t m8 = cm ? m8g[i] : (have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u);
-            amax_acc = amax8_masked(keep[i], m8, amax_acc);
+            if (kept) {
+                // marked elements -> the LDS copy of the x_out row, zeroed in the registers; the chunk goes back to x with its outlier
+                // columns zeroed (the reference zeroes the caller's tensor in place; the other six or seven halves are rewritten unchanged)
+                if (kept_extract8(keep[i], pg[i], stage, ldo) && valid && !(dbg & 1)) reinterpret_cast<uint4*>(xr)[c] = keep[i];
+                amax_acc = amax8_masked(keep[i], 0u, amax_acc);
+            } else {
+                const uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
+                amax_acc = amax8_masked(keep[i], m8, amax_acc);
+            }
         }
     }
     float amax = wave_max(amax_finish(amax_acc));
@@ -280,6 +286,8 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         amax = red[rw * WPR];
 #pragma unroll
         for (int w = 1; w < WPR; ++w) amax = fmaxf(amax, red[rw * WPR + w]);
+    } else {
+        if (kept) __syncthreads();                         // (the row lives in one wave: only its LDS copy of x_out needs the order)
     }
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
@@ -338,6 +346,10 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
             if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
         }
     }
+    if (kept) {                                                     // the whole x_out row (zeros behind the live columns) from its LDS copy
+        if (x_out && !(dbg & 8)) for (int j = t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = j < n ? stage[j] : static_cast<uint16_t>(0);
+        return;
+    }
     if (have_out) {
 #pragma unroll
         for (int g = 0; g < GQ; ++g) {
@@ -358,8 +370,8 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
 
 
 // One-pass form for a row whose masked |x| maximum is already KNOWN (the GEMM that produced x left it in row_amax, as fp16 bit
-// patterns maximised with atomics - mixq_gemm_i8_fused_amax): no reduction, no column-mask build (col_mask is the bit-per-column mask
-// the producer used), one barrier that only orders "everybody has read the maximum" before it is cleared for the next forward.
+// patterns maximised with atomics - mixq_gemm_i8_fused_amax): no reduction, no column-mask build (col_mask is the layer's kept outlier
+// map, whose bit words the producer used), one barrier that only orders "everybody has read the maximum" before it is cleared for the next forward.
 // Same bytes out as quant_rows2_kernel on the same row: the scale is fp16(amax / qmax) either way.
 template <int BIT, int TPR, int NCH>
 __global__ __launch_bounds__(TPR) void quant_known_kernel(
@@ -367,32 +379,44 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(
     uint32_t* __restrict__ row_amax, const uint32_t* __restrict__ col_mask, uint16_t* __restrict__ x_scale, void* __restrict__ q,
     uint16_t* __restrict__ x_out, int ldo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt)
 {
+    extern __shared__ __attribute__((aligned(16))) uint16_t kstage[];       // [ldo]: this row of x_out (kept-map route)
     const int row = blockIdx.x, t = threadIdx.x;
     uint16_t* xr = x + static_cast<size_t>(row) * ldx;
-    const int nchunk = K >> 3;
+    const int nchunk = K >> 3, mask_words = (K + 31) >> 5;
     const uint4* xv = reinterpret_cast<const uint4*>(xr);
-    uint4 keep[NCH];
+    const uint4* pv = col_mask ? kept_pos_table(col_mask, K) : nullptr;     // (col_mask is the layer's kept outlier map: bits, count, positions)
+    const int mcount = col_mask ? static_cast<int>(col_mask[mask_words]) : 0;
+    uint4 keep[NCH], pg[NCH];
     uint32_t m8[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = t + i * TPR;
         const bool in = c < nchunk;
         keep[i] = in ? xv[c] : make_uint4(0, 0, 0, 0);
+        pg[i] = (in && pv) ? pv[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
         m8[i] = (in && col_mask) ? ((col_mask[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
     }
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
     const bool have_out = (n > 0) && ind != nullptr;
-    // the outlier values of this row are requested now and consumed (x_out, in-place zero) after the quantised row has been written
+    const bool kept = have_out && pv != nullptr && mcount == n && ldo <= 16384;   // (a map built for another live count: the dependent gather below)
+    // without a usable map the outlier values of this row are requested now and consumed (x_out, in-place zero) after the quantised row has been written
     constexpr int GQ = 2;
     int gcol[GQ] = {-1, -1};
     uint16_t gval[GQ] = {0, 0};
-    if (have_out) {
+    if (have_out && !kept) {
 #pragma unroll
         for (int g = 0; g < GQ; ++g) { const int j = t + g * TPR; if (j < n) { gcol[g] = ind[j]; gval[g] = xr[gcol[g]]; } }
     }
     const uint32_t abits = row_amax[row] & 0x7fffu;
-    __syncthreads();                                                      // every thread of the row has read the maximum ...
+    if (kept) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = t + i * TPR;
+            if (c < nchunk && kept_extract8(keep[i], pg[i], kstage, ldo)) reinterpret_cast<uint4*>(xr)[c] = keep[i];   // (in-place zeroing of the marked columns)
+        }
+    }
+    __syncthreads();                                                      // every thread of the row has read the maximum (and dropped its outlier values into LDS) ...
     if (t == 0) row_amax[row] = 0u;                                       // ... before it is cleared for the producer's next run
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const uint16_t sh = f2h(__fdiv_rn(h2f(static_cast<uint16_t>(abits)), QMAX));
@@ -407,9 +431,13 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(
     for (int i = 0; i < NCH; ++i) {
         const int c = t + i * TPR;
         if (c < nchunk) {
-            (void)amax8_masked(keep[i], m8[i], 0u);                        // zero the outlier columns of the chunk (whatever the load saw there)
+            if (!kept) (void)amax8_masked(keep[i], m8[i], 0u);            // zero the outlier columns of the chunk (whatever the load saw there)
             quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
         }
+    }
+    if (kept) {
+        if (x_out) for (int j = t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = j < n ? kstage[j] : static_cast<uint16_t>(0);
+        return;
     }
     if (have_out) {
 #pragma unroll
@@ -603,7 +631,7 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
                        const uint32_t* col_mask)
 {
     const int nchunk = K >> 3;
-    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + RPB * (TPR / 64)) * sizeof(uint32_t);
+    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + RPB * (TPR / 64)) * sizeof(uint32_t) + (col_mask ? static_cast<size_t>(RPB) * ldo * 2 + 4 : 0);
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g((M + RPB - 1) / RPB), b(TPR * RPB);
 #define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt, g_quant_dbg, col_mask)
@@ -620,7 +648,7 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
 template <int BIT>
 int launch_quant_rows(uint16_t* x, int ldx, const int32_t* ind, int n, const int32_t* n_dev, uint16_t* x_scale, void* q,
                       uint16_t* x_out, int ldo, int32_t* flag, int M, int K, float thr_scale, int qfmt, hipStream_t st,
-                      const uint32_t* col_mask = nullptr)      // (optional: the kept bit-per-column mask of `ind`; the round-1 kernel builds its own)
+                      const uint32_t* col_mask = nullptr)      // (optional: the kept outlier map of `ind`; the round-1 kernel builds its own mask)
 {
     const int nchunk = K >> 3;
     int cfg = g_quant_cfg.get();
@@ -728,6 +756,7 @@ static int quant_fused_common(uint16_t* x, const int32_t* ind, int n, const int3
     // reference: `x_scale.max() > self.sigma / qmax` with sigma an fp16 [1,1] tensor -> fp16(fp16(sigma)/qmax)
     const float thr = fp16_round(fp16_round(sigma) / qmax);
     uint16_t* xo = (n > 0) ? x_out : nullptr;
+    if (ldo > 4096 || K > 65528) col_mask = nullptr;   // (the kept route assembles x_out rows in LDS and addresses columns with 16 bits: beyond that, the in-kernel mask)
     if (bit == 8) return launch_quant_rows<8>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream), col_mask);
     return launch_quant_rows<4>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream), col_mask);
 }
@@ -738,8 +767,8 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
 {
     return quant_fused_common(x, ind, n, n_dev, nullptr, x_scale, q, x_out, flag, M, K, ldx, ldo, bit, sigma, qfmt, stream);
 }
-// ... with the bit-per-column mask of the live `ind` entries kept by the caller (bit c of the little-endian word array = column c is an
-// outlier column; at least K / 32 words): same bytes out, without the in-kernel mask build in front of the row maximum
+// ... with the caller's kept outlier map of the live `ind` entries (include/mixq_hip.h: bit words, count word, per-column positions): same
+// bytes out from ONE memory round trip - no in-kernel mask build in front of the row maximum, no dependent gather behind the row load
 extern "C" int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
                                        uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo,
                                        int bit, float sigma, int qfmt, mixq_stream_t stream)
@@ -765,7 +794,7 @@ extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, con
     uint16_t* xo = (n > 0) ? x_out : nullptr;
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0, nchunk = K >> 3;
     hipStream_t st = mixq_stream(stream);
-#define MIXQ_QK(BITv, TPRv, NCHv) hipLaunchKernelGGL((quant_known_kernel<BITv, TPRv, NCHv>), dim3(M), dim3(TPRv), 0, st, x, ldx, ind, n, n_dev, \
+#define MIXQ_QK(BITv, TPRv, NCHv) hipLaunchKernelGGL((quant_known_kernel<BITv, TPRv, NCHv>), dim3(M), dim3(TPRv), static_cast<size_t>(ldo <= 16384 ? ldo : 0) * 2 + 4, st, x, ldx, ind, n, n_dev, \
                                                      row_amax, col_mask, x_scale, q, xo, ldo, flag, K, thr, rows16, qfmt)
 #define MIXQ_QK_BY_SIZE(BITv)                                             \
     if      (nchunk <= 256)      MIXQ_QK(BITv, 256, 1);                   \

@@ -187,6 +187,27 @@ def _derived_attr(name):
     return property(lambda self: getattr(self._d, name), lambda self, v: setattr(self._d, name, v))
 
 
+def kept_outlier_map(ind, K):
+    """The kept outlier map of `ind` over K input columns as int32 words on ind's device (layout: MixLinear_GEMM._col_mask)."""
+    dev = ind.device
+    n = int(ind.shape[0])
+    words = (K + 31) // 32
+    bits = torch.zeros(words * 32, dtype=torch.int64, device=dev)
+    bits[ind.long()] = 1
+    w = (bits.view(words, 32) << torch.arange(32, device=dev, dtype=torch.int64)).sum(dim=1)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)           # the same 32 bits as a signed word
+    head = torch.zeros(((words + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
+    head[:words] = w
+    head[words] = n
+    kp = ((K + 7) // 8) * 8
+    pos = torch.full((kp,), 0xffff, dtype=torch.int64, device=dev)
+    pos[ind.long()] = torch.arange(n, device=dev, dtype=torch.int64)
+    pw = pos.view(kp // 2, 2)
+    pw = pw[:, 0] | (pw[:, 1] << 16)
+    pw = torch.where(pw >= 2 ** 31, pw - 2 ** 32, pw).to(torch.int32)
+    return torch.cat([head, pw])
+
+
 class MixLinear_GEMM(nn.Module):
     _wpk, _wpk_key = _derived_attr("wpk"), _derived_attr("wpk_key")
     _wpk_small, _wpk_small_key = _derived_attr("wpk_small"), _derived_attr("wpk_small_key")
@@ -484,21 +505,17 @@ class MixLinear_GEMM(nn.Module):
 
     # ---- this layer's pre-pass maximum as a side output of the GEMM that produces its input (fused/mlp.py:57-70) --------
     def _col_mask(self):
-        """int32 words, bit k set <=> input column k is one of this layer's outlier columns, followed by ONE word holding the number of
-        columns marked (what the quantise passes check a kept mask against: include/mixq_hip.h); None without outliers."""
+        """This layer's KEPT OUTLIER MAP (include/mixq_hip.h, mixq_quant_fused_masked), int32 words: [ceil(K / 32) words: bit k set <=> input
+        column k is one of this layer's outlier columns][ONE word: the number of columns marked - what the quantise passes check a kept map
+        against][pad to a multiple of 4 words][K uint16, two per word: pos[k] = j with ind[j] == k, 0xffff elsewhere].  None without outliers.
+        A producing GEMM reads only the bits (its row-maximum side output skips the marked columns)."""
         n = int(self.ind.shape[0])
         if n == 0:
             return None
         ind = self.ind
         key = (id(ind), ind.data_ptr(), ind._version, n)
         if self._cmask is None or self._cmask_key != key:
-            words = (self.in_features + 31) // 32
-            bits = torch.zeros(words * 32, dtype=torch.int64, device=ind.device)
-            bits[ind.long()] = 1
-            w = (bits.view(words, 32) << torch.arange(32, device=ind.device, dtype=torch.int64)).sum(dim=1)
-            w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)       # the same 32 bits as a signed word
-            w = torch.cat([w, torch.tensor([n], dtype=torch.int32, device=w.device)])
-            self._cmask, self._cmask_key = w, key
+            self._cmask, self._cmask_key = kept_outlier_map(ind, self.in_features), key
         return self._cmask
 
     def amax_target(self, M, device):

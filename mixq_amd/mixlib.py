@@ -621,13 +621,18 @@ def _want_fmt(packed, fmt):
     return FMT_P16X64 if packed else FMT_PLAIN
 
 
+def kept_map_words(K):
+    """int32 words of the kept outlier map of K columns (include/mixq_hip.h: bits, count, pad to 4 words, K 16-bit positions)."""
+    return (((K + 31) // 32 + 1 + 3) // 4) * 4 + ((K + 7) // 8) * 4
+
+
 def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, packed=False, fmt=None, col_mask=None):
     """(i)+(ii) in one pass over X: extract/zero the known outlier columns `ind`, per-row scale into x_scale[0:M],
     quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n]).  With fmt = FMT_P16X64 /
     FMT_F16X64 (or packed=True: P16x64) q_x is emitted directly in that layout ([roundup(M,16), KB] bytes) and tagged.
     `n_dev` (device int32[1]) overrides the count: `ind` then is a buffer of capacity ind.numel().
-    `col_mask` (device int32 words, bit c <=> column c is one of the live `ind` entries): the caller's kept mask - the pass skips its
-    own mask build (mixq_quant_fused_masked; same bytes out)."""
+    `col_mask`: the caller's kept outlier map of the live `ind` entries (device int32 words - bit words, count word, per-column positions:
+    include/mixq_hip.h, linear.kept_outlier_map) - the pass then needs ONE memory round trip (mixq_quant_fused_masked; same bytes out)."""
     _dev_check(x, x_scale, ind, col_mask)
     fmt = _want_fmt(packed, fmt)
     xp, ldx = _rows(x, "x")
@@ -649,8 +654,8 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
     else:
         op, ldo, ip = None, 0, None
     if col_mask is not None and n:
-        if col_mask.element_size() != 4 or col_mask.numel() < (K + 31) // 32 + 1 or not col_mask.is_contiguous():
-            raise RuntimeError("QuantFused: col_mask must be contiguous 4-byte words covering all K columns + the count word behind them")
+        if col_mask.element_size() != 4 or col_mask.numel() < kept_map_words(K) or not col_mask.is_contiguous():
+            raise RuntimeError("QuantFused: col_mask must be the kept outlier map of K columns (bit words, count word, pad, K 16-bit positions)")
         _capi.call("mixq_quant_fused_masked", xp, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K,
                    ldx, ldo, bit, float(sigma), fmt, _stream())
     else:
@@ -801,7 +806,7 @@ class ForwardPlan:
             a.w_out, a.ldwo = wop, ldwo
         a.ldy = N
         self.args, self.ref, self.fn = a, C.byref(a), _capi.load().mixq_linear_forward
-        # kept_mask: the layer's bit-per-column mask of `ind` (int32 words, >= K / 32): the quantise pass then skips its own mask build
+        # kept_mask: the layer's kept outlier map of `ind` (include/mixq_hip.h: bits, count, positions): the quantise pass then needs one memory round trip
         if kept_mask is not None:
             _dev_check(kept_mask)
             if kept_mask.element_size() != 4 or kept_mask.numel() < (K + 31) // 32 + 1 or not kept_mask.is_contiguous():
@@ -861,7 +866,7 @@ def layernorm_forward_cuda(x, weight, out, eps):
 
 def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=None, packed=False, fmt=None, n_dev=None, col_mask=None):
     """RMSNorm fused with the next linear's extract + zero + scale + quantise.  Returns (q_x, x_out_view[M,n]); q_x carries
-    its format tag.  `col_mask`: the next layer's kept bit-per-column mask of `ind` (as QuantFused)."""
+    its format tag.  `col_mask`: the next layer's kept outlier map of `ind` (as QuantFused)."""
     _dev_check(x, weight, out, x_scale, ind, col_mask)
     fmt = _want_fmt(packed, fmt)
     K = x.shape[-1]
@@ -881,8 +886,8 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
     else:
         x_out, xop, ldxo, ip = None, None, 0, None
     if col_mask is not None and n:
-        if col_mask.element_size() != 4 or col_mask.numel() < (K + 31) // 32 + 1 or not col_mask.is_contiguous():
-            raise RuntimeError("RMSNormQuantFused: col_mask must be contiguous 4-byte words covering all K columns + the count word behind them")
+        if col_mask.element_size() != 4 or col_mask.numel() < kept_map_words(K) or not col_mask.is_contiguous():
+            raise RuntimeError("RMSNormQuantFused: col_mask must be the kept outlier map of K columns (bit words, count word, pad, K 16-bit positions)")
         _capi.call("mixq_rmsnorm_quant_fused_masked", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(),
                    q.data_ptr(), xop, _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), fmt, _stream())
     else:

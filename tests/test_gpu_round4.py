@@ -268,16 +268,12 @@ def test_quantise_pass_with_the_kept_column_mask_writes_the_same_bytes(bit, fmt,
     flag, with the live count in device memory below the capacity of `ind` (poison behind it)."""
     g = torch.Generator().manual_seed(bit * 1000 + K + ncols)
     x = torch.randn(M, K, generator=g).half()
-    cols = torch.sort(torch.randperm(K, generator=g)[:ncols])[0].to(torch.int32)
+    cols = torch.randperm(K, generator=g)[:ncols].to(torch.int32)      # (unsorted, as `ind` is after an append: linear.py:214)
     x[:, cols.long()] *= 30
     ind = torch.full((cap,), K - 1, dtype=torch.int32)                   # (entries behind the live count: never read as columns)
     ind[:ncols] = cols
     ind, n_dev = ind.to(DEV), torch.tensor([ncols], dtype=torch.int32, device=DEV)
-    words = (K + 31) // 32
-    bits = torch.zeros(words * 32, dtype=torch.int64)
-    bits[cols.long()] = 1
-    w = (bits.view(words, 32) << torch.arange(32, dtype=torch.int64)).sum(dim=1)
-    mask = torch.cat([torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32), torch.tensor([ncols], dtype=torch.int32)]).to(DEV)   # (+ the count word)
+    mask = L.kept_outlier_map(ind[:ncols], K)                            # bits, count word, per-column positions (include/mixq_hip.h)
     outs = []
     for cm in (None, mask):
         xd = x.clone().to(DEV)
@@ -315,17 +311,13 @@ def test_fused_norm_with_the_kept_column_mask_writes_the_same_bytes(bit, fmt, M,
     columns than the workgroup has threads' first entries (300) and the live count below the capacity of `ind`."""
     g = torch.Generator().manual_seed(bit * 1000 + K + ncols)
     x = torch.randn(M, K, generator=g).half()
-    cols = torch.sort(torch.randperm(K, generator=g)[:ncols])[0].to(torch.int32)
+    cols = torch.randperm(K, generator=g)[:ncols].to(torch.int32)      # (unsorted, as `ind` is after an append: linear.py:214)
     x[:, cols.long()] *= 30
     wgt = (torch.rand(K, generator=g) + 0.5).half().to(DEV)
     ind = torch.full((cap,), K - 1, dtype=torch.int32)
     ind[:ncols] = cols
     ind, n_dev = ind.to(DEV), torch.tensor([ncols], dtype=torch.int32, device=DEV)
-    words = (K + 31) // 32
-    bits = torch.zeros(words * 32, dtype=torch.int64)
-    bits[cols.long()] = 1
-    w = (bits.view(words, 32) << torch.arange(32, dtype=torch.int64)).sum(dim=1)
-    mask = torch.cat([torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32), torch.tensor([ncols], dtype=torch.int32)]).to(DEV)   # (+ the count word)
+    mask = L.kept_outlier_map(ind[:ncols], K)                            # bits, count word, per-column positions (include/mixq_hip.h)
     outs = []
     for cm in (None, mask):
         xd = x.clone().to(DEV)

@@ -1,0 +1,112 @@
+"""Round 5: the kept OUTLIER MAP of a frozen layer (bits, count, per-column positions) - the quantise passes take the outlier values out
+of the registers that hold the row instead of gathering x[row][ind[j]] through two dependent memory round trips.  Everything here
+compares the kept route with the in-kernel-mask route through the C ABI, byte for byte."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mixq_amd import mixlib  # noqa: E402
+from mixq_amd import linear as L  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _case(M, K, ncols, cap, seed, scale=30.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g).half()
+    cols = torch.randperm(K, generator=g)[:ncols].to(torch.int32)          # unsorted, as `ind` is after an append
+    x[:, cols.long()] *= scale
+    ind = torch.full((cap,), K - 1, dtype=torch.int32)
+    ind[:ncols] = cols
+    return x, cols, ind.to(DEV)
+
+
+def test_kept_outlier_map_layout():
+    """Restates include/mixq_hip.h: W bit words, the count word, pad to 4 words, K 16-bit positions (two per word)."""
+    K = 200
+    ind = torch.tensor([7, 199, 0, 64, 33], dtype=torch.int32, device=DEV)
+    m = L.kept_outlier_map(ind, K).cpu()
+    W = (K + 31) // 32
+    assert m.numel() == mixlib.kept_map_words(K) == ((W + 1 + 3) // 4) * 4 + K // 2
+    bits = m[:W].numpy().view("uint32")
+    for c in range(K):
+        assert bool((int(bits[c // 32]) >> (c % 32)) & 1) == (c in ind.tolist())
+    assert int(m[W]) == 5
+    pos = m[((W + 1 + 3) // 4) * 4:].numpy().view("uint16")
+    want = {int(c): j for j, c in enumerate(ind.tolist())}
+    for c in range(K):
+        assert int(pos[c]) == want.get(c, 0xffff)
+
+
+@pytest.mark.parametrize("bit,fmt,M,K,ncols,cap", [(8, 1, 512, 4096, 41, 48), (8, 1, 130, 11008, 110, 112), (8, 0, 33, 1024, 600, 608),
+                                                   (4, 4, 64, 2048, 128, 128), (8, 1, 48, 28672, 287, 288), (8, 0, 5, 64, 64, 64)])
+def test_quantise_kept_map_route_is_byte_identical(bit, fmt, M, K, ncols, cap):
+    """Also: more outlier columns than a row has threads (600 of 1024), EVERY column an outlier (64 of 64), the widest BASELINE layer."""
+    x, cols, ind = _case(M, K, ncols, cap, seed=K + ncols)
+    n_dev = torch.tensor([ncols], dtype=torch.int32, device=DEV)
+    kept = L.kept_outlier_map(ind[:ncols], K)
+    outs = []
+    for cm in (None, kept):
+        xd = x.clone().to(DEV)
+        sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        q, xo = mixlib.QuantFused(xd, ind, sx, bit, 6.0, flag=flag, n_dev=n_dev if cap > ncols else None, fmt=fmt, col_mask=cm)
+        torch.cuda.synchronize()
+        if fmt:
+            q = mixlib.UnpackOperand(q, M)
+        outs.append((q.clone(), sx, xo[:, :ncols].clone(), xd, flag))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int((outs[1][3][:, cols.long().to(DEV)] != 0).sum()) == 0
+    keep = torch.ones(K, dtype=torch.bool)
+    keep[cols.long()] = False
+    assert torch.equal(outs[1][3].cpu()[:, keep], x[:, keep])                # every other column of x is untouched
+
+
+@pytest.mark.parametrize("what", ["quant", "norm"])
+def test_a_kept_map_built_for_another_live_count_is_ignored(what):
+    """Device code may lower the live count behind the host's back: the map's count word then disagrees and the pass builds its own mask
+    from ind[0 .. live) - same bytes as the route that never saw a map."""
+    M, K, ncols, cap = 70, 2048, 37, 48
+    x, cols, ind = _case(M, K, ncols, cap, seed=5)
+    kept = L.kept_outlier_map(ind[:ncols], K)                              # describes 37 columns ...
+    n_dev = torch.tensor([ncols - 5], dtype=torch.int32, device=DEV)       # ... the device says 32
+    wgt = (torch.rand(K, generator=torch.Generator().manual_seed(1)) + 0.5).half().to(DEV)
+    outs = []
+    for cm in (None, kept):
+        xd = x.clone().to(DEV)
+        sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        if what == "quant":
+            q, xo = mixlib.QuantFused(xd, ind, sx, 8, 6.0, n_dev=n_dev, fmt=1, col_mask=cm)
+            extra = xd
+        else:
+            extra = torch.empty_like(xd)
+            q, xo = mixlib.RMSNormQuantFused(xd, wgt, extra, 1e-5, ind, sx, 8, n_dev=n_dev, fmt=1, col_mask=cm)
+        torch.cuda.synchronize()
+        outs.append((mixlib.UnpackOperand(q, M).clone(), sx, xo[:, :ncols - 5].clone(), extra))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("bit,fmt,M,K,ncols,cap", [(8, 1, 512, 4096, 41, 48), (8, 1, 60, 11008, 300, 304), (4, 4, 96, 1024, 128, 128)])
+def test_fused_norm_kept_map_route_is_byte_identical(bit, fmt, M, K, ncols, cap):
+    x, cols, ind = _case(M, K, ncols, cap, seed=K + ncols + 1)
+    n_dev = torch.tensor([ncols], dtype=torch.int32, device=DEV)
+    wgt = (torch.rand(K, generator=torch.Generator().manual_seed(2)) + 0.5).half().to(DEV)
+    kept = L.kept_outlier_map(ind[:ncols], K)
+    outs = []
+    for cm in (None, kept):
+        xd = x.clone().to(DEV)
+        out = torch.empty_like(xd)
+        sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        q, xo = mixlib.RMSNormQuantFused(xd, wgt, out, 1e-5, ind, sx, bit, n_dev=n_dev if cap > ncols else None, fmt=fmt, col_mask=cm)
+        torch.cuda.synchronize()
+        if fmt:
+            q = mixlib.UnpackOperand(q, M)
+        outs.append((q.clone(), sx, xo[:, :ncols].clone(), out))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
