@@ -495,7 +495,7 @@ def main(argv=None):
             # (c) the MLP block this layer sits in (mixquant/modules/fused/mlp.py:57-70: fused norm -> up_proj, gate_proj -> down_proj) at the
             # same batch: gate_proj + up_proj as ONE launch over their interleaved rows (MIXQ_ACT_SILU_PAIR) against the two launches
             try:
-                from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP, fused
+                from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP
                 bcache = MixLibCache(rows, sigma=SIGMA, bit=bit, device=device)
                 _, _, up_l = build_layer(device, rows, seed=21, bit=bit, cache=bcache)
                 _, _, gate_l = build_layer(device, rows, seed=22, bit=bit, cache=bcache)
@@ -506,9 +506,8 @@ def main(argv=None):
                 block = MixLlamaMLP(gate_l, down_l, up_l, bcache)
                 bsteps = 20
                 bx = base.unsqueeze(0).repeat(bsteps, 1, 1).contiguous()
-                prev_joint = fused.JOINT_GATE_UP
                 for joint in (False, True):
-                    fused.JOINT_GATE_UP = joint
+                    block.config.joint_gate_up = joint                  # (bcache's MixqConfig: this block's switches only)
                     for _ in range(4):
                         block(norm(base.clone()))                   # freezes the predictions; the joint image is built on the first frozen forward
                     torch.cuda.synchronize()
@@ -520,7 +519,6 @@ def main(argv=None):
                     bms, _, _ = conditioned_replay(bg, side, restore=lambda: bx.copy_(base.unsqueeze(0).expand_as(bx)))
                     mlp_ms[joint] = bms / bsteps
                     del bg
-                fused.JOINT_GATE_UP = prev_joint
                 del block, up_l, gate_l, down_l, bx
             except Exception as exc:                                # (a secondary figure must not take the bench line down)
                 print(f"bench.py: MLP-block secondary timing skipped: {exc!r}", file=sys.stderr)

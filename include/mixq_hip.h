@@ -205,7 +205,9 @@ int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x
  * (bit n of a uint32 array, NULL = no column excluded) is clear, into row_amax[m] with integer atomic max: order-independent, so the
  * value is exactly the maximum the quantiser would have found.  row_amax must be zero when the GEMM starts.
  * mixq_quant_known_amax is mixq_quant_fused for rows whose maximum is known: one pass, no reduction; it reads row_amax[m], CLEARS it
- * (ready for the producer's next run), and writes exactly the bytes mixq_quant_fused writes.  col_mask must mark the columns `ind`.
+ * (ready for the producer's next run), and writes exactly the bytes mixq_quant_fused writes.  Its col_mask is the layer's KEPT OUTLIER MAP
+ * of `ind` (the full layout of mixq_quant_fused_masked: bit words, count word, pad, positions - required when n > 0; the GEMM reads only
+ * the bit words of the same buffer).
  * mixq_gemm_amax_supported: 1 when the side output is available for (M, N, K, layout) - int8, MIXQ_X_PACKED | MIXQ_W_F16X64, the
  * batches the weights-in-registers kernels serve - else 0 (mixq_gemm_i8_fused_amax then returns MIXQ_ESHAPE). */
 int mixq_gemm_i8_fused_amax(const int8_t* q_x, const int8_t* q_w, const uint16_t* x_scale,
@@ -230,8 +232,8 @@ int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, const int32_t*
  *   x [M,K] fp16 ldx (outlier columns zeroed in place), ind / n_cap / n_dev, x_scale [M] (written), q_x (written, format qfmt),
  *   x_out [M,ldxo] (written; NULL when n_cap = 0), flag (optional), q_w in format wfmt (MIXQ_FMT_*), scale_col [N],
  *   w_out [N,ldwo], addend / lda, bias, y [M,ldy], act (MIXQ_ACT_*), row_amax / col_mask (optional: a producer left the row maxima,
- *   see mixq_gemm_i8_fused_amax - the quantise pass is then mixq_quant_known_amax; col_mask alone: the caller's kept mask of `ind`,
- *   the pass is mixq_quant_fused_masked).  qfmt must be what the GEMM takes for wfmt:
+ *   see mixq_gemm_i8_fused_amax - the quantise pass is then mixq_quant_known_amax; col_mask alone: the caller's kept outlier map of
+ *   `ind`, the pass is mixq_quant_fused_masked).  qfmt must be what the GEMM takes for wfmt:
  *   PLAIN / P16X64 with wfmt PLAIN / P16X64 in any combination, P16X64 with wfmt F16X64. */
 typedef struct mixq_linear_args {
     uint16_t* x; int ldx;
@@ -244,14 +246,6 @@ typedef struct mixq_linear_args {
     uint32_t* row_amax; const uint32_t* col_mask;   /* row_amax non-NULL: the rows' maxima are known (mixq_quant_known_amax runs instead) */
 } mixq_linear_args;
 int mixq_linear_forward(const mixq_linear_args* args, mixq_stream_t stream);
-
-/* ---- weight prefetch into the memory-side cache --------------------------------------------------------------
- * Touch `bytes` of a device buffer (one dword per 128-byte line) from a handful of light workgroups: enqueued on a SIDE stream while
- * another kernel computes, it pulls a layer's weight image into the MI355X's 256 MB memory-side cache ahead of the GEMM that streams it
- * (a GEMM with cache-resident weights runs its k loop 20 % faster than one fed from HBM).  Nothing is written.  A model runner calls it
- * for the NEXT GEMM's image when it enqueues the current one; the images are k-major, so the walk stays ahead of that GEMM's own reads.
- * No reference counterpart (the reference's GPUs have no such cache level). */
-int mixq_prefetch(const void* ptr, long long bytes, mixq_stream_t stream);
 
 /* ---- operand re-tiling ------------------------------------------------------------------------------------
  * Copy a plain [R,KB] byte matrix (int8 weights, or nibble-packed int4) into MIXQ_FMT_P16X64.

@@ -88,7 +88,6 @@ SIGNATURES = {
     "mixq_gemm_w8a16_set_config": [_I],
     "mixq_gemm_w8a16_num_configs": [],
     "mixq_gemm_w8a16_config_name": [_I, C.c_char_p, _I],
-    "mixq_prefetch": [_P, C.c_longlong, _P],
     "mixq_gemm_workspace_bytes": [],
     "mixq_gemm_set_workspace": [_P, C.c_longlong],
     "mixq_linear_forward": [_P, _P],

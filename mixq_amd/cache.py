@@ -10,6 +10,8 @@ MI355X differences, all behind the same names:
     `x_scale.max() > sigma/qmax` (linear.py:201) is evaluated on device inside the quantise kernel.
   * `n_dev`: the device-resident outlier count of the layer that filled the cache (kernel.py:108-111 reads its K the same
     way): the quantise kernel and the GEMM tail take the count from there, `ind` / `activation_outliers` are capacities.
+  * `config`: the model's MixqConfig (config.py) - packed formats, one-call forward, joint gate / up launch ... - instead of
+    process-global switches: two models in one process do not change each other's kernels.
   * the storage format of `q_xcache` (plain / P16x64 / F16x64) is a tag on the tensor itself (mixlib.fmt_of), not a flag
     here: a flag on this shared object would describe whichever layer wrote last.
 """
@@ -17,10 +19,13 @@ from __future__ import annotations
 
 import torch
 
+from .config import MixqConfig
+
 
 class MixLibCache:
-    def __init__(self, inputdim=1024, sigma=6, bit=8, eval_ppl=False, locality=False, device="cuda"):
+    def __init__(self, inputdim=1024, sigma=6, bit=8, eval_ppl=False, locality=False, device="cuda", config=None):
         self.device = device
+        self.config = config if config is not None else MixqConfig()    # this model's switches (config.py); every layer built with this cache shares it
         self.inputdim = inputdim
         self.x_scale = torch.zeros((inputdim, 1), dtype=torch.float16, device=device)
         self.sigma = torch.zeros((1, 1), dtype=torch.float16, device=device)
@@ -53,6 +58,20 @@ class MixLibCache:
                  torch.zeros(1, dtype=torch.int32, device=self.device))
             self._scratch[K] = s
         return s
+
+    def do_bench_cudagraph(self, fn):
+        """Mirror of Cache.py:26-38: ten warm-up calls of `fn`, then `fn` captured into a graph (a hipGraph here) on the CURRENT stream,
+        which must not be the default one; returns the graph (`g.replay()`).  The warm-up calls also let outlier prediction freeze
+        (Cache.py:21, `stop = 2`): a layer that is still searching synchronises with the host and cannot be captured."""
+        if torch.cuda.current_stream() == torch.cuda.default_stream():
+            raise RuntimeError("Cannot capture graph in default stream. Please use side stream in benchmark code.")
+        for _ in range(10):
+            fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        torch.cuda.synchronize()
+        return g
 
     @property
     def q_xcache_packed(self):

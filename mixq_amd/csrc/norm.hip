@@ -45,11 +45,11 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 template <int BIT, int NCH, bool QUANT>
-__global__ __launch_bounds__(NT) void rmsnorm_kernel(
-    const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ w, float eps, uint16_t* __restrict__ out, int ldout,
-    const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev, uint16_t* __restrict__ x_scale,
-    void* __restrict__ q, uint16_t* __restrict__ x_out, int ldxo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt,
-    const uint32_t* __restrict__ col_mask)
+__global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter order: the 14 dwords in front of the first requests first - quant.hip)
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint32_t* __restrict__ col_mask, const int32_t* __restrict__ n_dev,
+    const int32_t* __restrict__ ind, int ldx, int K, int n_cap, float eps,
+    uint16_t* __restrict__ out, int ldout, uint16_t* __restrict__ x_scale,
+    void* __restrict__ q, uint16_t* __restrict__ x_out, int ldxo, int32_t* __restrict__ flag, float thr_scale, int rows16, int fmt)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];     // column bitmask, 8 floats, [ldxo] fp16: the x_out row (kept route)
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -231,7 +231,7 @@ int launch_norm(const uint16_t* x, int ldx, const uint16_t* w, float eps, uint16
     const int nchunk = K >> 3;
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g(M), b(NT);
-#define MIXQ_NLAUNCH(NCH) hipLaunchKernelGGL((rmsnorm_kernel<BIT, NCH, QUANT>), g, b, shm, st, x, ldx, w, eps, out, ldout, ind, n, n_dev, x_scale, q, x_out, ldxo, flag, K, thr, rows16, qfmt, col_mask)
+#define MIXQ_NLAUNCH(NCH) hipLaunchKernelGGL((rmsnorm_kernel<BIT, NCH, QUANT>), g, b, shm, st, x, w, col_mask, n_dev, ind, ldx, K, n, eps, out, ldout, x_scale, q, x_out, ldxo, flag, thr, rows16, qfmt)
     if      (nchunk <= 2 * NT)  MIXQ_NLAUNCH(2);
     else if (nchunk <= 4 * NT)  MIXQ_NLAUNCH(4);
     else if (nchunk <= 8 * NT)  MIXQ_NLAUNCH(8);

@@ -193,10 +193,13 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
 // once per workgroup and shared by its RPB rows, and with TPR == 64 a row lives in ONE wave, so the absmax needs no LDS
 // round trip and no barrier at all when the layer has no outlier columns.  Results are bit-identical to the first form.
 template <int BIT, int TPR, int RPB, int NCH>
+// (parameter order: what a thread needs before it can request its row - 12 dwords - comes FIRST: built with -amdgpu-kernarg-preload-count
+// those arrive in SGPRs with the wave, and no scalar load stands in front of the row request; the rest is waited for behind it)
 __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
-    uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
+    uint16_t* __restrict__ x, const uint32_t* __restrict__ col_mask, const int32_t* __restrict__ n_dev, const int32_t* __restrict__ ind,
+    int ldx, int M, int K, int n_cap,
     uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int ldo,
-    int32_t* __restrict__ flag, int M, int K, float thr_scale, int rows16, int fmt, int dbg, const uint32_t* __restrict__ col_mask)
+    int32_t* __restrict__ flag, float thr_scale, int rows16, int fmt, int dbg)
 {
     constexpr int NT = TPR * RPB, WPR = TPR / 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32] column bitmask, RPB * WPR floats, [RPB][ldo] fp16: the x_out rows (kept route)
@@ -374,10 +377,10 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
 // map, whose bit words the producer used), one barrier that only orders "everybody has read the maximum" before it is cleared for the next forward.
 // Same bytes out as quant_rows2_kernel on the same row: the scale is fp16(amax / qmax) either way.
 template <int BIT, int TPR, int NCH>
-__global__ __launch_bounds__(TPR) void quant_known_kernel(
-    uint16_t* __restrict__ x, int ldx, const int32_t* __restrict__ ind, int n_cap, const int32_t* __restrict__ n_dev,
-    uint32_t* __restrict__ row_amax, const uint32_t* __restrict__ col_mask, uint16_t* __restrict__ x_scale, void* __restrict__ q,
-    uint16_t* __restrict__ x_out, int ldo, int32_t* __restrict__ flag, int K, float thr_scale, int rows16, int fmt)
+__global__ __launch_bounds__(TPR) void quant_known_kernel(       // (parameter order: see quant_rows2_kernel)
+    uint16_t* __restrict__ x, const uint32_t* __restrict__ col_mask, uint32_t* __restrict__ row_amax, const int32_t* __restrict__ n_dev,
+    const int32_t* __restrict__ ind, int ldx, int K, int n_cap, int ldo,
+    uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int32_t* __restrict__ flag, float thr_scale, int rows16, int fmt)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t kstage[];       // [ldo]: this row of x_out (kept-map route)
     const int row = blockIdx.x, t = threadIdx.x;
@@ -634,7 +637,7 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
     const size_t shm = (static_cast<size_t>((K + 31) >> 5) + RPB * (TPR / 64)) * sizeof(uint32_t) + (col_mask ? static_cast<size_t>(RPB) * ldo * 2 + 4 : 0);
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g((M + RPB - 1) / RPB), b(TPR * RPB);
-#define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, ldx, ind, n, n_dev, x_scale, q, x_out, ldo, flag, M, K, thr_scale, rows16, qfmt, g_quant_dbg, col_mask)
+#define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, col_mask, n_dev, ind, ldx, M, K, n, x_scale, q, x_out, ldo, flag, thr_scale, rows16, qfmt, g_quant_dbg)
     if      (nchunk <= 1 * TPR)  MIXQ_QLAUNCH2(1);
     else if (nchunk <= 2 * TPR)  MIXQ_QLAUNCH2(2);
     else if (nchunk <= 4 * TPR)  MIXQ_QLAUNCH2(4);
@@ -794,8 +797,8 @@ extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, con
     uint16_t* xo = (n > 0) ? x_out : nullptr;
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0, nchunk = K >> 3;
     hipStream_t st = mixq_stream(stream);
-#define MIXQ_QK(BITv, TPRv, NCHv) hipLaunchKernelGGL((quant_known_kernel<BITv, TPRv, NCHv>), dim3(M), dim3(TPRv), static_cast<size_t>(ldo <= 16384 ? ldo : 0) * 2 + 4, st, x, ldx, ind, n, n_dev, \
-                                                     row_amax, col_mask, x_scale, q, xo, ldo, flag, K, thr, rows16, qfmt)
+#define MIXQ_QK(BITv, TPRv, NCHv) hipLaunchKernelGGL((quant_known_kernel<BITv, TPRv, NCHv>), dim3(M), dim3(TPRv), static_cast<size_t>(ldo <= 16384 ? ldo : 0) * 2 + 4, st, x, col_mask, row_amax, n_dev, ind, \
+                                                     ldx, K, n, ldo, x_scale, q, xo, flag, thr, rows16, qfmt)
 #define MIXQ_QK_BY_SIZE(BITv)                                             \
     if      (nchunk <= 256)      MIXQ_QK(BITv, 256, 1);                   \
     else if (nchunk <= 512)      MIXQ_QK(BITv, 512, 1);                   \

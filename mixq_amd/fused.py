@@ -15,14 +15,7 @@ from . import linear as _L
 from . import mixlib as _hip_mixlib
 
 _backend = _hip_mixlib
-# gate_proj's GEMM also emits down_proj's per-row |x| maxima (include/mixq_hip.h: mixq_gemm_i8_fused_amax); False = the two-pass quantiser
-FUSE_DOWN_AMAX = True
-# gate_proj + up_proj of MixLlamaMLP as one launch over an interleaved weight image once both predictions are frozen (int8 layers);
-# False = up_proj's launch, then gate_proj's with the SiLU-and-multiply epilogue
-JOINT_GATE_UP = True
-# the fused norm hands the next (frozen) layer's kept column mask to its quantise step (mixq_rmsnorm_quant_fused_masked); False = the mask
-# is built inside the kernel on every launch
-NORM_KEPT_MASK = True
+# (the switches of rounds 1-4 - FUSE_DOWN_AMAX, JOINT_GATE_UP, NORM_KEPT_MASK - are fields of the model's MixqConfig now: config.py)
 
 
 def set_backend(mod):
@@ -76,7 +69,7 @@ class FasterTransformerRMSNorm(nn.Module):
             ind, n_dev = (nl.ind if n else None), None
         if hasattr(_backend, "PackOperand"):
             # (a next layer whose prediction is frozen hands over its kept column mask: no mask build in front of the row maximum)
-            cm = nl._col_mask() if (NORM_KEPT_MASK and n and hasattr(nl, "_col_mask") and not nl.add_outliers) else None
+            cm = nl._col_mask() if (getattr(getattr(nl, "config", None), "norm_kept_map", True) and n and hasattr(nl, "_col_mask") and not nl.add_outliers) else None
             q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
                                                sigma=getattr(cache, "sigma_value", 6.0), fmt=fmt, n_dev=n_dev, col_mask=cm)
         else:                                                # host stand-in of the CPU tests
@@ -113,6 +106,8 @@ class MixLlamaMLP(nn.Module):
         self.up_proj_ = up_proj
         self.out_features = down_proj.out_features
         self.MLPCache = MixGemmCache
+        # the model's switches: the cache's MixqConfig when there is one, else up_proj's (config.py)
+        object.__setattr__(self, "config", getattr(MixGemmCache, "config", None) or getattr(up_proj, "config", None) or _L.MixqConfig())
         # gate_proj and up_proj as ONE launch (MIXQ_ACT_SILU_PAIR): the interleaved operands, built at the first forward after both
         # layers' outlier predictions froze.  A plain attribute, not a buffer: the state_dict stays the reference's (two q_weight tensors)
         object.__setattr__(self, "_joint", None)
@@ -125,24 +120,28 @@ class MixLlamaMLP(nn.Module):
         def ident(t):
             return None if t is None else (id(t), t._version, tuple(t.shape))
         return tuple((ident(l._buffers.get("q_weight")), ident(l.scale_col), ident(l.bias), ident(l.weight_cache), ident(l.ind))
-                     for l in (up, gate)) + (str(up.scale_col.device), _L.PACK_FMT, _L.PACK_FMT4)
+                     for l in (up, gate)) + (str(up.scale_col.device),) + self.config.key()
 
     def _joint_applies(self, cache):
         up, gate = self.up_proj_, self.gate_proj_
-        if not JOINT_GATE_UP or not getattr(_backend, "PAIR_LAUNCH", False):
+        if not self.config.joint_gate_up or not getattr(_backend, "PAIR_LAUNCH", False):
             return False
         if up.bit != gate.bit or up.weight_only or gate.weight_only or up.add_outliers:
             return False
         # the kernels with the paired epilogue: int8 on fragment-order weights, int4 as FP6 codes (the default image of either width)
-        if (_L.PACK_FMT != _L.FMT_F16X64) if up.bit == 8 else (_L.PACK_FMT4 != _L.FMT_F6X128):
+        if (self.config.pack_fmt != _L.FMT_F16X64) if up.bit == 8 else (self.config.pack_fmt4 != _L.FMT_F6X128):
             return False
         if up.in_features % (64 if up.bit == 8 else 128) or up.out_features % 8 or \
                 (up.in_features, up.out_features) != (gate.in_features, gate.out_features):
             return False
         n = int(up.ind.shape[0])
+        if up.bit == 4 and n == 0:
+            return False                                     # (the two-launch route raises "int4 mod should have outliers", linear.py:255)
         if n and (gate.forward_without_precondition_len != n or gate.weight_cache is None or gate.weight_cache.shape[1] != n
                   or up.weight_cache is None or up.weight_cache.shape[1] != n):
             return False                                     # (gate_proj has not taken over the latest outlier columns yet: its own route does that)
+        if int(gate.ind.shape[0]) != n:
+            return False
         if _L._fmt_of(cache.q_xcache) != (_L.FMT_P16X64 if up.bit == 8 else _L.FMT_R6X128):
             return False
         j = self._joint
@@ -152,6 +151,11 @@ class MixLlamaMLP(nn.Module):
             # the joint image is never BUILT under capture (its packing kernels would be replayed with the graph, and the layers' own
             # images - which that graph is about to address through the two-launch route - would be freed by the build)
             object.__setattr__(self, "_two_launch_captured", True)
+            return False
+        if (j is None or j["key"] != key) and n and gate.ind is not up.ind and not torch.equal(gate.ind, up.ind):
+            # the joint launch multiplies up_proj's activation outliers (extracted in `up.ind` order) with BOTH layers' weight_cache columns:
+            # a gate_proj holding another column set or order (a per-layer load_state_dict of `ind` / `weight_cache`) keeps the two launches
+            # (checked when the image is (re)built, not per forward: it is a host sync; `ind`'s identity and version are part of the key)
             return False
         return True
 
@@ -179,7 +183,9 @@ class MixLlamaMLP(nn.Module):
         j = {"wpk": wpk, "rows": 2 * N, "scale": scale, "bias": bias, "wo": wo,
              # a superseded joint image may still be addressed by a graph captured on this route: kept alive (rebuilds are rare: new weights
              # loaded, new outlier columns, a device move)
-             "retired": ([] if old is None else old["retired"] + [old["wpk"], old["wo"], old["scale"], old["bias"]])}
+             # - only when such a graph exists; otherwise every load_state_dict / outlier change of a frozen block would pin one more full
+             # image (90 MB per Llama-2-7b block)
+             "retired": ([] if old is None else old["retired"] + ([old["wpk"], old["wo"], old["scale"], old["bias"]] if old.get("captured") else []))}
         object.__setattr__(self, "_joint", j)
         for which, l in enumerate((up, gate)):
             d = l._d
@@ -188,7 +194,7 @@ class MixLlamaMLP(nn.Module):
             d.invalidate()                                   # (kept argument blocks carry the old image's address)
             d.wpk = d.wpk_key = None
             d.joint = _JointRows(self, which)
-            if _L.COMPACT_WEIGHTS:
+            if self.config.compact_weights:
                 l._buffers["q_weight"] = None
         j["key"] = self._joint_key()
         return j
@@ -206,9 +212,12 @@ class MixLlamaMLP(nn.Module):
         j = self._joint
         if j is not None:                                    # the joint image is the only copy of gate_proj's / up_proj's weights: it follows the module
             w = fn(j["wpk"])
-            if w is not j["wpk"] and hasattr(_backend, "set_fmt"):
-                _backend.set_fmt(w, _L._fmt_of(j["wpk"]))
-            j["wpk"], j["key"], j["retired"] = w, None, []   # (the per-channel operands are re-made from the moved layers)
+            if w is not j["wpk"]:
+                if hasattr(_backend, "set_fmt"):
+                    _backend.set_fmt(w, _L._fmt_of(j["wpk"]))
+                j["wpk"], j["key"], j["retired"] = w, None, []   # (the per-channel operands are re-made from the moved layers)
+            # (an _apply that moves nothing - model.half() on an fp16 block - leaves the image, its key and the buffers a captured graph
+            # addresses alone; changed per-channel tensors show up in the key on the next forward)
         return out
 
     def _forward_joint(self, x, cache):
@@ -220,6 +229,15 @@ class MixLlamaMLP(nn.Module):
             cache.n_dev = None
         cache.ind = up.ind
         j = self._joint_operands()
+        for l in (up, gate):
+            # a direct call of up_proj / gate_proj since the last joint forward re-packed a private image from the joint one: released
+            # here (the block keeps ONE copy of these weights) unless a captured graph addresses it
+            d = l._d
+            if d.joint is not None and (d.wpk is not None or d.wpk_small is not None) and not torch.cuda.is_current_stream_capturing() \
+                    and not any(getattr(pl, "captured", False) for pl in d.plans.values()):
+                d.invalidate()
+                d.wpk = d.wpk_key = None
+                d.wpk_small = d.wpk_small_key = None
         if not j.get("captured") and torch.cuda.is_current_stream_capturing():
             j["captured"] = True                             # a graph out there replays the joint image's address (see _apply)
         n = int(up.ind.shape[0])
@@ -238,7 +256,7 @@ class MixLlamaMLP(nn.Module):
             xo, wo = _L._wide(xo, n_cap), _L._wide(wo, n_cap)
         extra = {}
         target = None
-        if FUSE_DOWN_AMAX and up.bit == 8 and down.bit == 8 and down.in_features == N and hasattr(_backend, "amax_supported") and \
+        if self.config.fuse_down_amax and up.bit == 8 and down.bit == 8 and down.in_features == N and hasattr(_backend, "amax_supported") and \
                 _backend.amax_supported(M, 2 * N, K, _L.FMT_P16X64, _L.FMT_F16X64):
             target = down.amax_target(M, x.device)
             if target is not None:
@@ -259,6 +277,6 @@ class MixLlamaMLP(nn.Module):
         up_output = self.up_proj_(x, self.MLPCache)
         # silu(gate(x)) * up(x) in gate_proj's epilogue (the reference multiplies in a separate pass, mlp.py:61-63)
         # ... and down_proj's pre-pass row maxima leave the same epilogue (its quantiser then needs one pass over the activation)
-        extra = {"amax_for": self.down_proj_} if FUSE_DOWN_AMAX else {}
+        extra = {"amax_for": self.down_proj_} if self.config.fuse_down_amax else {}
         gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache, mul=up_output, **extra)
         return self.down_proj_(gate_output, None, True)

@@ -22,6 +22,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import mixlib as _hip_mixlib
+from .config import MixqConfig
 from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, FMT_R6X128
 
 # The kernel backend.  Always the HIP module in the product; tests that exercise the host-side state machine on a
@@ -33,34 +34,6 @@ def set_backend(mod):
     global _backend
     prev = _backend
     _backend = mod
-    return prev
-
-
-# Packed layout new layers keep their weights in (and ask their activations in): MIXQ_FMT_F16X64 feeds the
-# weights-in-registers GEMM of gemm_wreg.hip, MIXQ_FMT_P16X64 the LDS-staged one of gemm.hip (include/mixq_hip.h).
-PACK_FMT = FMT_F16X64
-# ... and 4-bit layers: MIXQ_FMT_F6X128 - both operands as FP6 E3M2 codes, the W4A4 GEMM on the FP6 matrix pipe (gfx950 has no int4
-# MFMA; every integer of [-8, 8] is an E3M2 value and the fp32 accumulator is exact, so the result is the int4 contraction bit for
-# bit at 1.6x the int8 MFMA rate: 22.9 vs 27.6 us at 512 x 4096 -> 11008, 24.9 vs 32.3 us at 11008 -> 4096).  FMT_P16X64 selects the
-# int8-expansion kernel instead (nibbles, two thirds of the FP6 image's weight bytes: the better trade for weight-stream-bound decode).
-PACK_FMT4 = FMT_F6X128
-# ONE resident weight image per 4-bit layer (round 4): the FP6 one, 0.75 byte per weight (33.8 MB at 4096 -> 11008; nibbles would be 22.5 MB,
-# int8 45.1 MB).  Small batches (M <= 32) run the FP6 form of the 32 x 64 weight-stream tiling on it: 11.9-13.5 us at 4096 -> 11008 (nibble
-# image: 13.6-15.8), 10.9-12.3 us at 4096 -> 4096 (9.1-10.2), 19-22 us at 11008 -> 4096 (14-16) - tools/time_w4_small_batch.py,
-# profiles/r04_w4a4_small_batch.txt.  A decode-heavy deployment of NARROW layers may opt into a SECOND, nibble image for batches of at most
-# SMALL_BATCH_M4 rows (32 is the useful value; + 2/3 of the FP6 image's bytes, built when the first such batch arrives).  0 = off, the default.
-SMALL_BATCH_M4 = 0
-# After a layer's outlier search has frozen, keep ONLY the packed weight image in HBM (the plain [N,K] `q_weight` is
-# re-created on demand for state_dict / attribute reads).  False keeps both copies (2x the reference's weight memory).
-COMPACT_WEIGHTS = True
-# Frozen layers run their forward (extract + quantise, GEMM) through ONE C-ABI call on a kept argument block
-# (mixq_linear_forward).  False keeps the two-call route (same kernels, same results; the parity test compares the two).
-ONE_CALL_FORWARD = True
-
-
-def set_pack_fmt(fmt):
-    global PACK_FMT
-    prev, PACK_FMT = PACK_FMT, fmt
     return prev
 
 
@@ -256,6 +229,9 @@ class MixLinear_GEMM(nn.Module):
             self.forward_without_precondition_len = fp_features_num
 
         self.cache = cache
+        # the switches of the model this layer belongs to (config.py): the cache's, shared by every layer built with it; a layer without a
+        # cache gets its own.  A plain attribute (not a buffer, not in the state_dict).
+        object.__setattr__(self, "config", getattr(cache, "config", None) or MixqConfig())
         self.weight_only = weight_only
         self.add_outliers = True
         if cache is not None:
@@ -412,7 +388,17 @@ class MixLinear_GEMM(nn.Module):
                 raise RuntimeError("MixLinear_GEMM: this layer ran under hipGraph capture; moving it to another device would leave that graph "
                                    "with dangling addresses.  Drop the graph first, then set layer.allow_move_after_capture = True (re-capture "
                                    "after the move).")
+        def idents():
+            own = [self.__dict__.get("weight_cache"), self.__dict__.get("ind"), d.wpk]
+            return [id(t) for t in list(self._buffers.values()) + own]
+        before = idents()
         out = super()._apply(fn, *args, **kwargs)
+        if fn(d.wpk) is d.wpk if d.wpk is not None else True:
+            wc, ind = self.__dict__.get("weight_cache"), self.__dict__.get("ind")
+            if (not isinstance(wc, Tensor) or fn(wc) is wc) and (not isinstance(ind, Tensor) or fn(ind) is ind) and idents() == before:
+                # an _apply that changes nothing (model.half() on an fp16 layer): the derived buffers - among them the row-maximum
+                # hand-over buffer and the retired images a captured graph still writes to and reads - stay as they are
+                return out
         if d.wpk is not None:
             moved = fn(d.wpk)
             if moved is not d.wpk:
@@ -442,7 +428,7 @@ class MixLinear_GEMM(nn.Module):
         return FMT_R6X128 if _fmt_of(wpk) == FMT_F6X128 else FMT_P16X64
 
     def _small_batch_image(self, M):
-        return self.bit == 4 and M is not None and 0 < M <= SMALL_BATCH_M4 and PACK_FMT4 == FMT_F6X128 and not self.weight_only
+        return self.bit == 4 and M is not None and 0 < M <= self.config.small_batch_m4 and self.config.pack_fmt4 == FMT_F6X128 and not self.weight_only
 
     def _packed_small(self):
         """The nibble (P16X64) image of a 4-bit layer, for small batches; made from the plain matrix while it exists, from the FP6 image after."""
@@ -469,13 +455,13 @@ class MixLinear_GEMM(nn.Module):
         if qw is None:
             if self._wpk is None and self._d.joint is not None:
                 # the layer is used on its own again (its MLP block took the joint route before): its own image, from the joint one
-                self._wpk = _backend.PackOperand(self._plain_weight(), PACK_FMT if self.bit == 8 else PACK_FMT4)
+                self._wpk = _backend.PackOperand(self._plain_weight(), self.config.pack_fmt if self.bit == 8 else self.config.pack_fmt4)
             return self._wpk                                             # compacted: the packed image is all there is
         if qw.shape[1] % 64 or not hasattr(_backend, "PackOperand"):
             return None
-        # W4A4: FP6 codes for the FP6 matrix pipe (PACK_FMT4); as nibbles it stays with the LDS-staged kernel (P16X64 weights), whose
+        # W4A4: FP6 codes for the FP6 matrix pipe (config.pack_fmt4); as nibbles it stays with the LDS-staged kernel (P16X64 weights), whose
         # nibble expansion hides behind 32-cycle MFMAs, not behind the 16-cycle ones of the weights-in-registers kernel (28.0 vs 32.4 us)
-        fmt = PACK_FMT if self.bit == 8 else PACK_FMT4
+        fmt = self.config.pack_fmt if self.bit == 8 else self.config.pack_fmt4
         key = (id(qw), qw.data_ptr(), qw._version, fmt)
         if self._wpk is None or self._wpk_key != key:
             self._wpk = _backend.PackOperand(qw, fmt)
@@ -521,7 +507,7 @@ class MixLinear_GEMM(nn.Module):
     def amax_target(self, M, device):
         """(row_amax buffer, column mask) a producing GEMM should fill for this layer's next forward of M rows, or None when this
         layer cannot use it (outlier search still running, weight-only).  The buffer is zero when handed out."""
-        if self.weight_only or self.add_outliers or not ONE_CALL_FORWARD or not hasattr(_backend, "amax_supported"):
+        if self.weight_only or self.add_outliers or not self.config.one_call_forward or not hasattr(_backend, "amax_supported"):
             return None
         d = self._d
         # ONE buffer for the layer's lifetime on a device, sized for the largest batch the cache admits (x_scale has one row per
@@ -591,7 +577,7 @@ class MixLinear_GEMM(nn.Module):
         d.plan, d.plan_key, d.plans, d.retired = None, None, {}, []
         if d.joint is not None:                              # (the copy stands alone: its own image instead of a reference into the MLP block's)
             if d.wpk is None and self._buffers.get("q_weight") is None:
-                d.wpk = _backend.PackOperand(self._plain_weight(), PACK_FMT if self.bit == 8 else PACK_FMT4)
+                d.wpk = _backend.PackOperand(self._plain_weight(), self.config.pack_fmt if self.bit == 8 else self.config.pack_fmt4)
             d.joint = None
         state["_d"] = d
         return state
@@ -612,7 +598,7 @@ class MixLinear_GEMM(nn.Module):
         dd = d["_d"]
         return (M, inputs.stride(0), inputs.device, id(cache), id(cache.x_scale), id(ind), ind._version, id(dd.wpk), id(dd.wpk_small), id(qw),
                 -1 if qw is None else qw._version, id(wc), -1 if wc is None else wc._version, id(b.get("bias", d.get("bias"))),
-                id(b.get("scale_col")), PACK_FMT, PACK_FMT4, SMALL_BATCH_M4)
+                id(b.get("scale_col"))) + d["config"].key()
 
     def _build_plan(self, cache, inputs, M):
         if not hasattr(_backend, "ForwardPlan") or M == 0 or inputs.dtype != torch.float16 or inputs.stride(1) != 1 \
@@ -645,7 +631,7 @@ class MixLinear_GEMM(nn.Module):
         cache.shape = x.shape[:-1] + (self.out_features,)
         inputs = x.reshape(-1, x.shape[-1])
         M = inputs.shape[0]
-        if unfused and not self.add_outliers and self.weight_only is False and ONE_CALL_FORWARD:
+        if unfused and not self.add_outliers and self.weight_only is False and self.config.one_call_forward:
             # prediction frozen: extract + quantise + GEMM enqueued by one C call on a kept argument block; bit-identical to the
             # route below (tests/test_gpu_round3.py::test_one_call_forward_is_bit_identical)
             # The argument block takes x by ADDRESS: what the two-call route checked in QuantFused is checked here on every call - a
@@ -663,7 +649,7 @@ class MixLinear_GEMM(nn.Module):
                 self._plan, self._plan_key = self._plans[key], key       # (a batch size seen before, nothing else changed)
             if self._plan_key != key:
                 self._plan = self._build_plan(cache, inputs, M)
-                if COMPACT_WEIGHTS and self._plan is not None:
+                if self.config.compact_weights and self._plan is not None:
                     self.compact_weights_()                  # (e.g. after a load_state_dict into a frozen layer re-created q_weight)
                 self._plan_key = self._frozen_key(cache, inputs, M)
                 if self._plan is not None:
@@ -735,7 +721,7 @@ class MixLinear_GEMM(nn.Module):
                 self.add_outliers = False
 
         y1 = self._gemm(cache, M, ACT_NONE)
-        if COMPACT_WEIGHTS and not self.add_outliers:
+        if self.config.compact_weights and not self.add_outliers:
             self.compact_weights_()
         return y1.reshape(cache.shape)
 
@@ -777,7 +763,7 @@ class MixLinear_GEMM(nn.Module):
         else:
             y1 = self._gemm(cache, M, ACT_SILU, **extra)
         self._silu_calls += 1
-        if COMPACT_WEIGHTS and self._silu_calls >= self.cache.stop:
+        if self.config.compact_weights and self._silu_calls >= self.cache.stop:
             self.compact_weights_()
         out = y1.reshape(cache.shape)
         if target is not None:

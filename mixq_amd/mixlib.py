@@ -708,16 +708,6 @@ def DequantWeightCols(q_w, scale_col, ind, bit, out=None):
     return out
 
 
-def Prefetch(t, stream=None):
-    """Pull a device tensor's bytes (a layer's weight image) into the MI355X's memory-side cache from `stream` (default: the current one)
-    - meant for a SIDE stream, while another kernel computes (mixq_prefetch, include/mixq_hip.h).  Nothing is written."""
-    _dev_check(t)
-    if not t.is_contiguous():
-        raise RuntimeError("Prefetch: a contiguous tensor (a packed weight image)")
-    st = _stream() if stream is None else stream.cuda_stream
-    _capi.call("mixq_prefetch", t.data_ptr(), t.numel() * t.element_size(), st)
-
-
 PAIR_LAUNCH = True                       # FusedLinear serves ACT_SILU_PAIR (fused.MixLlamaMLP asks before taking its joint gate / up route)
 
 

@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from mixq_amd import MixLibCache, MixLinear_GEMM, _capi, mixlib  # noqa: E402
+from mixq_amd import MixLibCache, MixLinear_GEMM, MixqConfig, _capi, mixlib  # noqa: E402
 from mixq_amd import linear as L  # noqa: E402
 from mixq_amd._capi import FMT_F6X128, FMT_R6X128, FMT_P16X64, FMT_PLAIN  # noqa: E402
 from oracle import oracle as O  # noqa: E402
@@ -30,7 +30,6 @@ def _device():
     _capi.load().mixq_gemm_set_config(-1)
     yield
     _capi.load().mixq_gemm_set_config(-1)
-    L.PACK_FMT4 = FMT_F6X128
 
 
 def nibble_matrix(R, K, seed, lo=-8):
@@ -184,11 +183,12 @@ def test_fp6_gemm_extreme_operands_stay_exact():
         assert np.array_equal(n(y).view(np.uint16), ref.view(np.uint16))
 
 
-def _layer(M, K, N, ncols, bias, seed=0):
+def _layer(M, K, N, ncols, bias, seed=0, **cfg):
+    """(cfg: fields of the model's MixqConfig, e.g. pack_fmt4 = FMT_P16X64 for the nibble / int8-expansion path)"""
     torch.manual_seed(seed)
     lin = torch.nn.Linear(K, N, bias=bias).half()
     cols = torch.randperm(K, generator=torch.Generator().manual_seed(1))[:ncols]
-    cache = MixLibCache(M, bit=4, device=DEV)
+    cache = MixLibCache(M, bit=4, device=DEV, config=MixqConfig(**cfg))
     scales = torch.ones(K) + torch.arange(K) * 1e-6
     scales[cols] = 20.0 + torch.arange(cols.numel()) * 1e-3
     layer = MixLinear_GEMM.from_linear(lin, 4, cache=cache, layer_scales=scales, dev=DEV)
@@ -201,8 +201,7 @@ def test_four_bit_layer_runs_on_the_fp6_pipe_and_equals_the_int8_expansion():
     M, K, N, ncols = 96, 1024, 320, 10
     outs = {}
     for fmt in (FMT_F6X128, FMT_P16X64):
-        L.PACK_FMT4 = fmt
-        layer, cache, cols = _layer(M, K, N, ncols, True)
+        layer, cache, cols = _layer(M, K, N, ncols, True, pack_fmt4=fmt)
         ys = []
         for call in range(4):
             x = torch.randn(M, K, generator=torch.Generator().manual_seed(10 + call)).half()
@@ -212,7 +211,6 @@ def test_four_bit_layer_runs_on_the_fp6_pipe_and_equals_the_int8_expansion():
         xf = FMT_R6X128 if fmt == FMT_F6X128 else fmt
         assert mixlib.fmt_of(layer._packed_weight()) == fmt and layer.x_fmt() == xf and mixlib.fmt_of(cache.q_xcache) == xf
         outs[fmt] = (ys, layer, cache)
-    L.PACK_FMT4 = FMT_F6X128
     for a, b in zip(outs[FMT_F6X128][0], outs[FMT_P16X64][0]):
         assert torch.equal(a, b)
     l6, l8 = outs[FMT_F6X128][1], outs[FMT_P16X64][1]
@@ -250,9 +248,8 @@ def test_mlp_block_w4a4_shares_the_fp6_activation():
     M, H, F = 64, 512, 1024
     res = {}
     for fmt in (FMT_F6X128, FMT_P16X64):
-        L.PACK_FMT4 = fmt
         torch.manual_seed(0)
-        cache = MixLibCache(M, sigma=6, bit=4, device=DEV)
+        cache = MixLibCache(M, sigma=6, bit=4, device=DEV, config=MixqConfig(pack_fmt4=fmt))
         cols = torch.randperm(H, generator=torch.Generator().manual_seed(1))[:8]
         ls = torch.ones(H); ls[cols] = 20.0
         mk = lambda k, nn_, sc: MixLinear_GEMM.from_linear(torch.nn.Linear(k, nn_, bias=False).half(), 4, cache=cache, layer_scales=sc, dev=DEV)
@@ -266,7 +263,6 @@ def test_mlp_block_w4a4_shares_the_fp6_activation():
         ys = [mlp(norm(x.clone().to(DEV))).clone() for _ in range(4)]
         assert mixlib.fmt_of(up._packed_weight()) == fmt
         res[fmt] = ys
-    L.PACK_FMT4 = FMT_F6X128
     for a, b in zip(res[FMT_F6X128], res[FMT_P16X64]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
@@ -274,12 +270,11 @@ def test_mlp_block_w4a4_shares_the_fp6_activation():
 def test_a_four_bit_layer_keeps_one_weight_image_by_default():
     """Round 4 (VERDICT r03 #5b): a 4-bit layer holds ONE resident weight image - the FP6 one, 0.75 byte per weight - whatever batch sizes
     it sees: small batches run the FP6 form of the 32 x 64 weight-stream tiling on it.  Same bits as the nibble-only layer."""
-    assert L.SMALL_BATCH_M4 == 0, "the second (nibble) image is opt-in"
+    assert MixqConfig().small_batch_m4 == 0, "the second (nibble) image is opt-in"
     K, N, ncols = 1024, 320, 10
     outs = {}
     for fmt in (FMT_F6X128, FMT_P16X64):
-        L.PACK_FMT4 = fmt
-        layer, cache, cols = _layer(96, K, N, ncols, True)
+        layer, cache, cols = _layer(96, K, N, ncols, True, pack_fmt4=fmt)
         ys = []
         for call, M in enumerate((96, 96, 96, 16, 96, 1, 32, 33)):
             x = torch.randn(M, K, generator=torch.Generator().manual_seed(40 + call)).half()
@@ -291,21 +286,18 @@ def test_a_four_bit_layer_keeps_one_weight_image_by_default():
             assert layer._buffers["q_weight"] is None and mixlib.fmt_of(layer._wpk) == FMT_F6X128
             assert layer._wpk.numel() == N * K * 3 // 4, "resident bytes of the layer: 0.75 per weight"
         outs[fmt] = ys
-    L.PACK_FMT4 = FMT_F6X128
     for a, b in zip(outs[FMT_F6X128], outs[FMT_P16X64]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 def test_small_batches_of_a_four_bit_layer_stream_a_nibble_image():
-    """Opt-in (SMALL_BATCH_M4 = 32; narrow layers at decode: 9-10 vs 11-12 us at 4096 -> 4096, tools/time_w4_small_batch.py): M <= 32 is a
+    """Opt-in (MixqConfig.small_batch_m4 = 32; narrow layers at decode: 9-10 vs 11-12 us at 4096 -> 4096, tools/time_w4_small_batch.py): M <= 32 is a
     weight stream - the layer serves it from a second, nibble image (built when the first small batch arrives, also after the plain matrix
     was dropped) with P16X64 activations; larger batches keep the FP6 pair.  Same bits either way."""
     K, N, ncols = 1024, 320, 10
     outs = {}
-    prev_small, L.SMALL_BATCH_M4 = L.SMALL_BATCH_M4, 32
     for fmt in (FMT_F6X128, FMT_P16X64):
-        L.PACK_FMT4 = fmt
-        layer, cache, cols = _layer(96, K, N, ncols, True)
+        layer, cache, cols = _layer(96, K, N, ncols, True, pack_fmt4=fmt, small_batch_m4=32)
         ys = []
         for call, M in enumerate((96, 96, 96, 16, 96, 1, 32, 33)):
             x = torch.randn(M, K, generator=torch.Generator().manual_seed(40 + call)).half()
@@ -314,12 +306,11 @@ def test_small_batches_of_a_four_bit_layer_stream_a_nibble_image():
                 assert layer._wpk_small is None and layer._buffers["q_weight"] is None       # frozen, compacted, no small batch seen yet
             ys.append(layer(x.to(DEV), None, True).clone())
             if fmt == FMT_F6X128:
-                small = M <= L.SMALL_BATCH_M4
+                small = M <= 32
                 assert mixlib.fmt_of(cache.q_xcache) == (FMT_P16X64 if small else FMT_R6X128), (M, mixlib.fmt_of(cache.q_xcache))
         if fmt == FMT_F6X128:
             assert layer._wpk_small is not None and mixlib.fmt_of(layer._wpk_small) == FMT_P16X64 and mixlib.fmt_of(layer._wpk) == FMT_F6X128
         outs[fmt] = ys
-    L.PACK_FMT4, L.SMALL_BATCH_M4 = FMT_F6X128, prev_small
     for a, b in zip(outs[FMT_F6X128], outs[FMT_P16X64]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
@@ -330,8 +321,7 @@ def test_four_bit_layer_with_ragged_k_and_n(M, K, N, ncols):
     zero-padded FP6 pair gives the nibble path's bits, warm-up and frozen calls alike."""
     outs = {}
     for fmt in (FMT_F6X128, FMT_P16X64):
-        L.PACK_FMT4 = fmt
-        layer, cache, cols = _layer(M, K, N, ncols, True, seed=3)
+        layer, cache, cols = _layer(M, K, N, ncols, True, seed=3, pack_fmt4=fmt)
         ys = []
         for call in range(4):
             x = torch.randn(M, K, generator=torch.Generator().manual_seed(70 + call)).half()
@@ -339,7 +329,6 @@ def test_four_bit_layer_with_ragged_k_and_n(M, K, N, ncols):
             ys.append(layer(x.to(DEV), None, True).clone())
         assert mixlib.fmt_of(layer._packed_weight()) == fmt
         outs[fmt] = (ys, layer)
-    L.PACK_FMT4 = FMT_F6X128
     for a, b in zip(outs[FMT_F6X128][0], outs[FMT_P16X64][0]):
         assert a.shape == (M, N) and torch.isfinite(a).all() and torch.equal(a, b)
     assert torch.equal(outs[FMT_F6X128][1].state_dict()["q_weight"], outs[FMT_P16X64][1].state_dict()["q_weight"])

@@ -201,9 +201,9 @@ def test_mlp_block_on_the_joint_route_is_bit_identical_and_keeps_one_weight_imag
     inner, norm, cache, xs = _block(M, H, F, bias)
     up, gate, down = inner.up_proj_, inner.gate_proj_, inner.down_proj_
     mlp = lambda x: inner(norm(x))
-    prev = fused.JOINT_GATE_UP
+    prev = inner.config.joint_gate_up
     try:
-        fused.JOINT_GATE_UP = False
+        inner.config.joint_gate_up = False
         for x in xs[:3]:
             mlp(x.clone().to(DEV))                                    # freeze every layer's outlier search
         assert not up.add_outliers and not down.add_outliers
@@ -211,7 +211,7 @@ def test_mlp_block_on_the_joint_route_is_bit_identical_and_keeps_one_weight_imag
         y_ref = [mlp(x.clone().to(DEV)) for x in xs[3:]]
         sx_ref = cache.x_scale[:M].clone()
         assert inner._joint is None and up._wpk is not None
-        fused.JOINT_GATE_UP = True
+        inner.config.joint_gate_up = True
         y = [mlp(x.clone().to(DEV)) for x in xs[3:]]
         assert inner._joint is not None, "the joint route did not run"
         assert all(torch.equal(a, b) for a, b in zip(y, y_ref)) and torch.equal(cache.x_scale[:M], sx_ref)
@@ -233,11 +233,11 @@ def test_mlp_block_on_the_joint_route_is_bit_identical_and_keeps_one_weight_imag
                 torch.cuda.synchronize()
                 assert torch.equal(yg, y_ref[1])
         # a layer used on its own again gets its own image back (from the joint one) and computes what it always did
-        fused.JOINT_GATE_UP = False
+        inner.config.joint_gate_up = False
         y2 = mlp(xs[3].clone().to(DEV))
         assert torch.equal(y2, y_ref[0]) and up._wpk is not None
     finally:
-        fused.JOINT_GATE_UP = prev
+        inner.config.joint_gate_up = prev
 
 
 def test_new_weights_loaded_into_a_block_on_the_joint_route_reach_the_joint_image():
@@ -294,32 +294,28 @@ def test_w4a4_one_launch_for_gate_and_up(M, N, K, n_out, bias):
 def test_w4a4_mlp_block_on_the_joint_route_is_bit_identical():
     from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP, fused
     from mixq_amd import linear as L
-    assert L.PACK_FMT4 == _capi.FMT_F6X128
+    from mixq_amd import MixqConfig
+    assert MixqConfig().pack_fmt4 == _capi.FMT_F6X128
     M, H, F = 64, 512, 1024
     outs = {}
-    prev = fused.JOINT_GATE_UP
-    try:
-        for joint in (False, True):
-            fused.JOINT_GATE_UP = joint
-            torch.manual_seed(0)
-            cache = MixLibCache(M, sigma=6, bit=4, device=DEV)
-            cols = torch.randperm(H, generator=torch.Generator().manual_seed(1))[:8]
-            ls = torch.ones(H); ls[cols] = 20.0
-            mk = lambda k, nn_, sc: MixLinear_GEMM.from_linear(torch.nn.Linear(k, nn_, bias=False).half(), 4, cache=cache, layer_scales=sc, dev=DEV)
-            lsd = torch.ones(F); lsd[:12] = 20.0
-            gate, up, down = mk(H, F, ls), mk(H, F, ls), mk(F, H, lsd)
-            norm = FasterTransformerRMSNorm((torch.rand(H) + 0.5).half().to(DEV), 1e-5, cache)
-            norm.next_layer = up
-            mlp = MixLlamaMLP(gate, down, up, cache)
-            x = torch.randn(M, H, generator=torch.Generator().manual_seed(2)).half()
-            x[:, cols] *= 20
-            outs[joint] = [mlp(norm(x.clone().to(DEV))).clone() for _ in range(6)]
-            if joint:
-                assert mlp._joint is not None, "the joint route did not run"
-                assert mixlib.fmt_of(mlp._joint["wpk"]) == _capi.FMT_F6X128 and up._wpk is None and gate._wpk is None
-                assert mlp._joint["wpk"].numel() == 2 * F * H * 3 // 4          # 0.75 byte per weight, once
-    finally:
-        fused.JOINT_GATE_UP = prev
+    for joint in (False, True):
+        torch.manual_seed(0)
+        cache = MixLibCache(M, sigma=6, bit=4, device=DEV, config=MixqConfig(joint_gate_up=joint))
+        cols = torch.randperm(H, generator=torch.Generator().manual_seed(1))[:8]
+        ls = torch.ones(H); ls[cols] = 20.0
+        mk = lambda k, nn_, sc: MixLinear_GEMM.from_linear(torch.nn.Linear(k, nn_, bias=False).half(), 4, cache=cache, layer_scales=sc, dev=DEV)
+        lsd = torch.ones(F); lsd[:12] = 20.0
+        gate, up, down = mk(H, F, ls), mk(H, F, ls), mk(F, H, lsd)
+        norm = FasterTransformerRMSNorm((torch.rand(H) + 0.5).half().to(DEV), 1e-5, cache)
+        norm.next_layer = up
+        mlp = MixLlamaMLP(gate, down, up, cache)
+        x = torch.randn(M, H, generator=torch.Generator().manual_seed(2)).half()
+        x[:, cols] *= 20
+        outs[joint] = [mlp(norm(x.clone().to(DEV))).clone() for _ in range(6)]
+        if joint:
+            assert mlp._joint is not None, "the joint route did not run"
+            assert mixlib.fmt_of(mlp._joint["wpk"]) == _capi.FMT_F6X128 and up._wpk is None and gate._wpk is None
+            assert mlp._joint["wpk"].numel() == 2 * F * H * 3 // 4          # 0.75 byte per weight, once
     for a, b in zip(outs[True], outs[False]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
@@ -333,13 +329,13 @@ def test_joint_image_is_never_built_under_capture_and_a_graph_of_the_two_launch_
     inner, norm, cache, xs = _block(M, H, F, False)
     up, gate = inner.up_proj_, inner.gate_proj_
     mlp = lambda x: inner(norm(x))
-    prev = fused.JOINT_GATE_UP
+    prev = inner.config.joint_gate_up
     try:
-        fused.JOINT_GATE_UP = False
+        inner.config.joint_gate_up = False
         for x in xs[:3]:
             mlp(x.clone().to(DEV))
         y_ref = mlp(xs[3].clone().to(DEV))
-        fused.JOINT_GATE_UP = True
+        inner.config.joint_gate_up = True
         side = torch.cuda.Stream()
         xg = xs[3].clone().to(DEV)
         keep = xg.clone()
@@ -365,7 +361,7 @@ def test_joint_image_is_never_built_under_capture_and_a_graph_of_the_two_launch_
             inner2(norm2(x.clone().to(DEV)))
         assert inner2._joint is not None and not inner2.up_proj_._d.retired and not inner2.gate_proj_._d.retired
     finally:
-        fused.JOINT_GATE_UP = prev
+        inner.config.joint_gate_up = prev
 
 
 def test_moving_a_block_captured_on_the_joint_route_raises():

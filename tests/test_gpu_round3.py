@@ -38,7 +38,6 @@ def _device():
     _capi.load().mixq_gemm_set_config(-1)
     yield
     _capi.load().mixq_gemm_set_config(-1)
-    L.ONE_CALL_FORWARD = True
 
 
 def frozen_layer(M, K, N, bit, ncols, bias, seed=0):
@@ -70,7 +69,7 @@ def test_one_call_forward_is_bit_identical(M, K, N, bit, ncols, bias):
     x[:, cols] *= 20
     res = {}
     for one in (False, True, True):                                  # the third run re-uses the kept plan
-        L.ONE_CALL_FORWARD = one
+        layer.config.one_call_forward = one
         xd = x.to(DEV)
         cache.x_scale.zero_()
         y = layer(xd, None, True)
@@ -87,7 +86,7 @@ def test_one_call_forward_is_bit_identical(M, K, N, bit, ncols, bias):
             assert np.array_equal(a.view(np.uint8) if a.dtype != np.uint8 else a, b.view(np.uint8) if b.dtype != np.uint8 else b)
         assert (res[4] is None) == (got[4] is None) and (res[4] is None or np.array_equal(res[4].view(np.uint16), got[4].view(np.uint16)))
         assert res[5] == got[5]
-    L.ONE_CALL_FORWARD = True
+    layer.config.one_call_forward = True
     # and the route is the operator's real arithmetic: sampled rows against the oracle
     rows = sorted({0, M // 2, M - 1})
     xh = x.numpy()[rows].copy()
@@ -119,9 +118,9 @@ def test_one_call_plan_follows_the_layer_state():
     sd["bias"] = sd["bias"] + 1
     layer.load_state_dict(sd)
     y4 = layer(x.to(DEV), None, True)
-    L.ONE_CALL_FORWARD = False
+    layer.config.one_call_forward = False
     y4b = layer(x.to(DEV), None, True)
-    L.ONE_CALL_FORWARD = True
+    layer.config.one_call_forward = True
     assert torch.equal(y4, y4b) and not torch.equal(y4, y1)
 
 
@@ -266,7 +265,7 @@ def test_known_maximum_quantiser_writes_the_same_bytes(M, K, ncols, bit, fmt):
     if ncols:
         xm[:, cols] = 0
     amax = torch.from_numpy(xm.max(axis=1).astype(np.float16).view(np.uint16).astype(np.int32)).to(DEV)
-    mask = _mask_words(K, cols.tolist()) if ncols else None
+    mask = L.kept_outlier_map(ind, K) if ncols else None               # the layer's kept outlier map: bits, count, positions (include/mixq_hip.h)
     qb = torch.empty_like(qa)
     ldo = (ncols + 15) // 16 * 16
     xob = torch.empty((M, ldo), dtype=torch.float16, device=DEV) if ncols else None
@@ -302,15 +301,15 @@ def test_mlp_block_with_the_fused_row_maximum_is_bit_identical():
         x = torch.randn(M, H, generator=g).half()
         x[:, cols] *= 20
         xs.append(x)
-    prev = fused.FUSE_DOWN_AMAX
+    prev = inner.config.fuse_down_amax
     try:
-        fused.FUSE_DOWN_AMAX = False
+        inner.config.fuse_down_amax = False
         for x in xs[:3]:
             mlp(x.clone().to(DEV))                                    # freeze every layer's outlier search
         assert not down.add_outliers and not up.add_outliers
         y_ref = mlp(xs[3].clone().to(DEV))
         sx_ref = cache.x_scale[:M].clone()
-        fused.FUSE_DOWN_AMAX = True
+        inner.config.fuse_down_amax = True
         y = mlp(xs[3].clone().to(DEV))
         assert down._amax_buf is not None and not down._amax_dirty, "down_proj did not take the hand-over"
         assert torch.equal(y, y_ref) and torch.equal(cache.x_scale[:M], sx_ref)
@@ -328,7 +327,7 @@ def test_mlp_block_with_the_fused_row_maximum_is_bit_identical():
                 torch.cuda.synchronize()
                 assert torch.equal(yg, y_ref)
     finally:
-        fused.FUSE_DOWN_AMAX = prev
+        inner.config.fuse_down_amax = prev
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -429,10 +428,10 @@ def test_one_call_plans_are_kept_per_batch_size():
     layer, cache, cols = frozen_layer(96, 1024, 320, 8, 5, True)
     xs = {M: torch.randn(M, 1024, generator=torch.Generator().manual_seed(M)).half() for M in (96, 16, 40)}
     want = {}
-    L.ONE_CALL_FORWARD = False
+    layer.config.one_call_forward = False
     for M, x in xs.items():
         want[M] = layer(x.clone().to(DEV), None, True).clone()
-    L.ONE_CALL_FORWARD = True
+    layer.config.one_call_forward = True
     plans = {}
     for rnd in range(3):
         for M, x in xs.items():
@@ -443,7 +442,9 @@ def test_one_call_plans_are_kept_per_batch_size():
             else:
                 assert layer._plan is plans[M], "the plan of a batch size seen before was rebuilt"
     assert len(layer._plans) == 3
-    moved = layer.to(DEV)                                             # a device move drops them (they pin the old tensors)
+    same = layer.to(DEV)                                              # nothing moves: the kept blocks (and whatever a captured graph addresses) stay
+    assert len(same._plans) == 3 and same._plan is not None
+    moved = layer.cpu()                                               # a device move drops them (they pin the old tensors)
     assert moved._plans == {} and moved._plan is None
 
 

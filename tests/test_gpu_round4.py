@@ -24,7 +24,6 @@ def _device():
     _capi.load().mixq_gemm_set_config(-1)
     yield
     _capi.load().mixq_gemm_set_config(-1)
-    L.ONE_CALL_FORWARD = True
 
 
 def test_row_maximum_buffer_survives_a_larger_batch_under_graph_replay():
@@ -48,9 +47,9 @@ def test_row_maximum_buffer_survives_a_larger_batch_under_graph_replay():
         x = torch.randn(M, H, generator=g).half()
         x[:, cols] *= 20
         return x.to(DEV)
-    prev = fused.FUSE_DOWN_AMAX
+    prev = inner.config.fuse_down_amax
     try:
-        fused.FUSE_DOWN_AMAX = True
+        inner.config.fuse_down_amax = True
         for _ in range(3):
             mlp(batch(CAP))                                            # freeze the outlier search of every layer
         assert not down.add_outliers
@@ -77,7 +76,7 @@ def test_row_maximum_buffer_survives_a_larger_batch_under_graph_replay():
         assert int(buf.abs().sum()) == 0 and all(int(j[0]) == 0x7fffffff for j in junk)
         del y_big
     finally:
-        fused.FUSE_DOWN_AMAX = prev
+        inner.config.fuse_down_amax = prev
 
 
 def test_one_call_route_validates_its_input_on_every_call():
@@ -297,11 +296,11 @@ def test_frozen_layer_hands_its_kept_mask_to_the_one_call_forward():
     x[:, cols] *= 20
     y1 = layer(x.clone().to(DEV), None, True)
     assert layer._plan is not None and layer._plan.kept_mask is not None and layer._plan.kept_mask is layer._col_mask()
-    L.ONE_CALL_FORWARD = False
+    layer.config.one_call_forward = False
     try:
         y2 = layer(x.clone().to(DEV), None, True)
     finally:
-        L.ONE_CALL_FORWARD = True
+        layer.config.one_call_forward = True
     assert torch.equal(y1, y2)
 
 

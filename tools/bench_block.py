@@ -44,38 +44,12 @@ class Layer:
         self.norm1.next_layer, self.norm2.next_layer = self.W_pack, up
         self.H = H
 
-    def __call__(self, x, pf=None, nxt=None):
-        """pf: a side stream for weight prefetches (mixq_prefetch), nxt: the layer that runs after this one.  When a GEMM is enqueued, the
-        NEXT GEMM's image starts streaming into the memory-side cache from `pf` - ordered behind this point of the main stream by an event,
-        so at most the current and the next images are in flight through the cache."""
-        def ahead(*fns):
-            if pf is None:
-                return
-            main = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            pf.wait_event(ev)
-            for f in fns:
-                if PROBE != "empty":
-                    f(pf)
-                else:
-                    with torch.cuda.stream(pf):
-                        _sink.add_(1)                                            # (a trivial kernel in the branch's place)
-        def img(layer):                                                         # a layer's resident weight image
-            return lambda s: (mixlib.Prefetch(layer._wpk, s) if layer._wpk is not None else None)
-
-        def mlp_img(s):
-            j = self.mlp._joint
-            if j is not None:
-                mixlib.Prefetch(j["wpk"], s)
+    def __call__(self, x):
         h = self.norm1(x)
-        ahead(img(self.o_proj))                                                 # while W_pack computes
         qkv = self.W_pack(h)                                                    # (cache filled by the norm: unfused=False)
         attn = qkv[:, :self.H].contiguous()                                     # stand-in for the attention output (out of scope)
-        ahead(mlp_img)                                                          # while o_proj computes
         o = self.o_proj(attn, None, True)
         h2 = self.norm2(o)
-        ahead(img(self.mlp.down_proj_), *([img(nxt.W_pack)] if nxt is not None else []))   # while gate / up and down_proj compute
         return self.mlp(h2)
 
 
@@ -85,12 +59,8 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--bit", type=int, default=8)
     ap.add_argument("--passes", type=int, default=2, help="passes over all layers per graph")
-    ap.add_argument("--prefetch", action="store_true", help="third arm: mixq_prefetch of the next GEMM's weight image from a side stream (fork / join inside the graph)")
-    ap.add_argument("--probe", default="", help="diagnostics of the prefetch arm: 'empty' = the fork / join structure with no bytes touched")
     args = ap.parse_args()
     dev = "cuda"
-    global PROBE, _sink
-    PROBE, _sink = args.probe, torch.zeros(1, device=dev)
     M, H, F, QKV = args.M, 4096, 11008, 12288
     cache = MixLibCache(M, sigma=6, bit=args.bit, device=dev)
     g = torch.Generator().manual_seed(1)
@@ -98,18 +68,15 @@ def main():
     base = torch.randn(M, H, generator=g).half()
     base[:, cols] *= 20
     base = base.to(dev)
-    fused.FUSE_DOWN_AMAX = True
     flops = 2.0 * M * (H * QKV + H * H + 2 * H * F + F * H)
     wbytes = (H * QKV + H * H + 2 * H * F + F * H) * (1 if args.bit == 8 else 0.75)
     print(f"Llama-2-7b decoder layer, Linear path only (norm, W_pack, o_proj, norm, MLP), {M} tokens, W{args.bit}A{args.bit}; {flops / 1e9:.1f} GFLOP and "
           f"~{wbytes / 1e6:.0f} MB of weights per layer; protocol: bench.conditioned_replay")
-    arms = [(1, "ONE layer copy (weights resident in the memory-side cache: a benchmark loop)", False),
-            (args.layers, f"{args.layers} layer copies in rotation (weights from HBM: a model)", False)]
-    if args.prefetch or args.probe:
-        # measured negative (profiles/r04_prefetch_side_stream.txt): a cross-stream edge in a captured graph costs ~14 us on this stack
-        arms.append((args.layers, f"{args.layers} layer copies in rotation, each GEMM's weights prefetched into the memory-side cache from a side stream "
-                                  f"while the previous one computes{' [probe: ' + args.probe + ']' if args.probe else ''}", True))
-    for nl, label, prefetch in arms:
+    # (a third arm - the next GEMM's weight image prefetched into the memory-side cache from a side stream - was measured in round 4 and
+    # removed with mixq_prefetch in round 5: profiles/r04_prefetch_side_stream.txt, a cross-stream edge in a captured graph costs ~14 us)
+    arms = [(1, "ONE layer copy (weights resident in the memory-side cache: a benchmark loop)"),
+            (args.layers, f"{args.layers} layer copies in rotation (weights from HBM: a model)")]
+    for nl, label in arms:
         layers = [Layer(H, F, QKV, cache, dev, args.bit, s) for s in range(nl)]
         for ly in layers:
             for _ in range(3):                                                  # outlier prediction warm-up (host syncs allowed here)
@@ -118,14 +85,11 @@ def main():
         steps = max(nl * args.passes, 16)
         xs = base.unsqueeze(0).repeat(steps, 1, 1).contiguous()
         side = torch.cuda.Stream()
-        pf = torch.cuda.Stream() if prefetch else None
         with torch.cuda.stream(side):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=side):
                 for i in range(steps):
-                    layers[i % nl](xs[i], pf, layers[(i + 1) % nl] if prefetch else None)
-                if pf is not None:
-                    side.wait_stream(pf)                                        # (join: the prefetch branch is part of the graph)
+                    layers[i % nl](xs[i])
             torch.cuda.synchronize()
             ms, first_ms, reps = bench.conditioned_replay(gr, side, restore=lambda: xs.copy_(base.unsqueeze(0).expand_as(xs)))
         us = ms * 1e3 / steps

@@ -37,19 +37,18 @@ def block(x, fused_mul):
     return down(go, None, True)
 
 
-fused.FUSE_DOWN_AMAX = False
-fused.JOINT_GATE_UP = False
+cfg = mlp.config                         # the model's switches (mixq_amd/config.py); shared with the layers through the cache
+cfg.fuse_down_amax = False
+cfg.joint_gate_up = False
 for _ in range(3):                       # outlier prediction warm-up (host syncs allowed here)
     block(base.clone(), True)
 torch.cuda.synchronize()
 ya, yb = block(base.clone(), True), block(base.clone(), False)
 print("max |fused - two-step| =", float((ya.float() - yb.float()).abs().max()))
 steps = 50
-fused.NORM_KEPT_MASK = False
+cfg.norm_kept_map = False
 for fused_mul, amax, joint, kept in ((False, False, False, False), (True, False, False, False), (True, True, False, False), (True, True, True, False), (True, True, True, True)):
-    fused.FUSE_DOWN_AMAX = amax
-    fused.JOINT_GATE_UP = joint
-    fused.NORM_KEPT_MASK = kept
+    cfg.fuse_down_amax, cfg.joint_gate_up, cfg.norm_kept_map = amax, joint, kept
     if joint:
         yj = block(base.clone(), True)
         print("joint gate / up launch: max |joint - two launches| =", float((yj.float() - ya.float()).abs().max()), "(bit-identical)" if torch.equal(yj, ya) else "(DIFFERENT)")
@@ -64,5 +63,5 @@ for fused_mul, amax, joint, kept in ((False, False, False, False), (True, False,
         ms, first_ms, _ = bench.conditioned_replay(gr, side, restore=lambda: xs.copy_(base.unsqueeze(0).expand_as(xs)))
         us = ms * 1e3 / steps
     flops = 2.0 * M * (2 * H * F + F * H)
-    print(f"norm + MLP block, gate*up {('in ONE joint gate / up launch' if joint else 'in the gate epilogue') if fused_mul else 'as a separate pass'}{', down_proj row maxima from the same epilogue' if amax else ''}{', norm with the kept column mask' if kept else ''}: {us:7.1f} us  "
+    print(f"norm + MLP block, gate*up {('in ONE joint gate / up launch' if joint else 'in the gate epilogue') if fused_mul else 'as a separate pass'}{', down_proj row maxima from the same epilogue' if amax else ''}{', norm with the kept outlier map' if kept else ''}: {us:7.1f} us  "
           f"({flops / us / 1e6:6.0f} effective TFLOPS; first replay {first_ms * 1e3 / steps:7.1f} us)")

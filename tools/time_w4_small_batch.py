@@ -1,12 +1,11 @@
 #!/usr/bin/env python3
 """4-bit layer forward at small batches: FP6-coded weights ALONE (the default: one resident image), FP6 + the opt-in nibble image for batches
-<= 32 rows (SMALL_BATCH_M4 = 32), and nibble weights only (PACK_FMT4 = FMT_P16X64: skinny / LDS-staged kernels); us per forward in a graph of
+<= 32 rows (MixqConfig.small_batch_m4 = 32), and nibble weights only (MixqConfig.pack_fmt4 = FMT_P16X64: skinny / LDS-staged kernels); us per forward in a graph of
 50 forwards, frozen layer."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mixq_amd import MixLibCache, MixLinear_GEMM, _capi
-from mixq_amd import linear as L
+from mixq_amd import MixLibCache, MixLinear_GEMM, MixqConfig, _capi
 from mixq_amd._capi import FMT_F6X128, FMT_P16X64
 dev = "cuda"
 names = _capi.gemm_config_names()
@@ -14,9 +13,8 @@ for (K, N) in [(4096, 11008), (4096, 4096), (11008, 4096)]:
     for M in (1, 16, 32, 64, 128, 256):
         row = []
         for fmt, small in ((FMT_F6X128, 0), (FMT_F6X128, 32), (FMT_P16X64, 0)):
-            L.PACK_FMT4, L.SMALL_BATCH_M4 = fmt, small
             torch.manual_seed(0)
-            cache = MixLibCache(M, bit=4, device=dev)
+            cache = MixLibCache(M, bit=4, device=dev, config=MixqConfig(pack_fmt4=fmt, small_batch_m4=small))
             ls = torch.ones(K); ls[torch.randperm(K)[:128]] = 20.0
             layer = MixLinear_GEMM.from_linear(torch.nn.Linear(K, N, bias=False).half(), 4, cache=cache, layer_scales=ls, dev=dev)
             x = torch.randn(8, M, K).half().to(dev)
@@ -37,4 +35,3 @@ for (K, N) in [(4096, 11008), (4096, 4096), (11008, 4096)]:
             cfg = names[_capi.load().mixq_gemm_pick_config_fmt(M, N, K, 4, used)] + (" on its nibble image" if used != fmt else "")
             row.append(f"{('fp6+nibble' if small else 'fp6 only') if fmt == FMT_F6X128 else 'nibble only'} {us:6.1f} us ({cfg})")
         print(f"{K:6d}->{N:6d} M={M:4d}: " + "   ".join(row), flush=True)
-L.PACK_FMT4, L.SMALL_BATCH_M4 = FMT_F6X128, 0
