@@ -86,6 +86,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// x_scale = fp16(amax / qmax) (include/mixq_hip.h: fp32 divide, RNE to fp16) WITHOUT the division: for every finite fp16 maximum and both
+// qmax (127, 7), fp16(RN(amax * RN(1 / qmax))) is the same fp16 value (checked exhaustively: tests/test_oracle_golden.py) - one multiply
+// instead of a ~10-instruction IEEE division on every row's critical path (maximum -> scale -> quantise).
+__device__ __forceinline__ uint16_t mixq_row_scale(float amax, float qmax) { return f2h(amax * (1.0f / qmax)); }
+// 1 / s for the per-value products of quant_exact / quant8_exact below.  MIXQ_RCP_APPROX: v_rcp_f32 (1 ulp) instead of the IEEE division -
+// the exactness argument below has the slack (t within 3.5e-5 of x / s, needed < 6e-5) and the exhaustive self-test is the judge.
+__device__ __forceinline__ float mixq_rcp_scale(float s) {
+#ifdef MIXQ_RCP_APPROX
+    return s > 0.f ? __builtin_amdgcn_rcpf(s) : 0.f;
+#else
+    return s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;
+#endif
+}
+
 // q = clamp(rint(x / s), +-QMAX) with the fp32 IEEE quotient rounded half-to-even (the convention of the oracle's
 // find_row_scale), WITHOUT a division per element.  x is an fp16 value, s an fp16 scale (both exact in fp32), rs = 1/s.
 // Why it is exact: where it matters |x/s| <= 128, and x/s = (a/b) 2^E with 11-bit a, b lies either exactly on a half-integer or at
@@ -103,6 +117,46 @@ __device__ __forceinline__ int quant_exact(float x, float s, float rs) {
     if (fabsf(e) * 2.f == s && (static_cast<int>(q0) & 1)) q0 += copysignf(1.f, e);
     q0 = fminf(fmaxf(q0, -QMAX), QMAX);
     return (s > 0.f) ? static_cast<int>(q0) : 0;
+}
+// The same quotient for the EIGHT values of a 16-byte chunk, at a third of the instructions (the quantise passes spend 0.7 us of a 5 us
+// launch at K = 4096, 2.2 us at K = 11008, on this arithmetic: profiles/r05_quant_probe.txt).  Per value: t = x rs clamped to +-QMAX FIRST
+// (the bounds are integers: clamp and round commute, and the tie rule below cannot carry a clamped value past them), u = t + 1.5 2^23 - the
+// add IS the round-half-even to an integer, and u's low mantissa bits are the two's-complement result: no rint, no float -> int
+// conversion, no "& 0xff" - q0 = u - 1.5 2^23 (exact), e = x - q0 s (exact, as above), and the exact-tie test |e| == s / 2.  Ties are rare
+// (x / s must be a half-integer exactly: ~1e-5 per value on real activations), so their fix-up - move an ODD q0 to its even neighbour on
+// e's side, never past +-QMAX - sits behind ONE wave-uniform branch for the chunk.  Returns the bit patterns of u: byte 0 is the int8
+// value (low nibble: the int4 value), quant8_int() the integer.  Equal to quant_exact bit for bit: mixq_selftest_quant_exact checks both
+// against the division form over every finite fp16 pair.
+constexpr float MIXQ_RMAGIC = 12582912.f;                                     // 1.5 * 2^23 = 0x4B400000
+__device__ __forceinline__ int quant8_int(uint32_t ubits) { return static_cast<int>(ubits & 0x7fffffu) - 0x400000; }
+template <int BIT>
+__device__ __forceinline__ void quant8_exact(const uint4& v, float s, float rs, uint32_t (&ub)[8]) {
+    constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const float hs = 0.5f * s;
+    float u[8], e[8];
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = h2f(static_cast<uint16_t>((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu)));
+        const float t = __builtin_amdgcn_fmed3f(x * rs, -QMAX, QMAX);
+        u[j] = t + MIXQ_RMAGIC;
+        e[j] = fmaf(-(u[j] - MIXQ_RMAGIC), s, x);
+        tie |= fabsf(e[j]) == hs;
+    }
+    if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {                            // (wave-uniform; s == 0: x == 0 here, u is even, nothing moves)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (fabsf(e[j]) == hs && (__float_as_uint(u[j]) & 1u))
+                u[j] = __builtin_amdgcn_fmed3f(u[j] + copysignf(1.f, e[j]), MIXQ_RMAGIC - QMAX, MIXQ_RMAGIC + QMAX);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ub[j] = __float_as_uint(u[j]);
+}
+// bytes 0 of four such patterns as one dword (v_perm_b32: two selects and an or instead of masks and shifts)
+__device__ __forceinline__ uint32_t quant8_pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return __builtin_amdgcn_perm(b, a, 0x0c0c0400u) | __builtin_amdgcn_perm(d, c, 0x04000c0cu);
 }
 // Byte address of byte `kb` of row `row` in a packed operand ([KB/64][rows16/16] blocks of 16 rows x 64 bytes = 1 KiB):
 //   MIXQ_FMT_P16X64: row r of a block stores its four 16-byte chunks c at r*64 + (c ^ (-(r>>2) & 3))*16: a row's 64 bytes stay

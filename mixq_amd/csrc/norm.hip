@@ -157,9 +157,9 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
     amax = block_max(amax, red + 4);                                      // (its barrier also orders the LDS copy of the x_out row)
     if (kept && x_out) for (int j = tid; j < ldxo; j += NT) x_out[static_cast<size_t>(row) * ldxo + j] = j < n ? stage[j] : static_cast<uint16_t>(0);
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
-    const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
+    const uint16_t sh = mixq_row_scale(amax, QMAX);
     const float s = h2f(sh);
-    const float rs = s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;
+    const float rs = mixq_rcp_scale(s);
     if (tid == 0) {
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
@@ -175,13 +175,10 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
                 const bool in = c < nchunk;                          // (K % 128 == 0: both chunks of a pair are in, or neither)
                 uint32_t lo = 0, hi = 0;
                 if (in) {
-                    const uint32_t d[4] = {keep[i].x, keep[i].y, keep[i].z, keep[i].w};
-                    uint32_t code[8];
+                    uint32_t ub[8], code[8];
+                    quant8_exact<4>(keep[i], s, rs, ub);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        code[2 * e]     = f6_code_of_int(quant_exact<4>(h2f(static_cast<uint16_t>(d[e] & 0xffffu)), s, rs));
-                        code[2 * e + 1] = f6_code_of_int(quant_exact<4>(h2f(static_cast<uint16_t>(d[e] >> 16)), s, rs));
-                    }
+                    for (int e = 0; e < 8; ++e) code[e] = f6_code_of_int(quant8_int(ub[e]));
                     f6_pack8(code, lo, hi);
                 }
                 const uint32_t plo = __shfl_xor(lo, 1), phi = __shfl_xor(hi, 1);
@@ -198,23 +195,18 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + i * NT;
         if (c < nchunk) {
-            const uint32_t d[4] = {keep[i].x, keep[i].y, keep[i].z, keep[i].w};
-            int qv[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                qv[2 * e]     = quant_exact<BIT>(h2f(static_cast<uint16_t>(d[e] & 0xffffu)), s, rs);
-                qv[2 * e + 1] = quant_exact<BIT>(h2f(static_cast<uint16_t>(d[e] >> 16)), s, rs);
-            }
+            uint32_t ub[8];
+            quant8_exact<BIT>(keep[i], s, rs, ub);
             if constexpr (BIT == 8) {
                 uint2 o;
-                o.x = (qv[0] & 0xff) | ((qv[1] & 0xff) << 8) | ((qv[2] & 0xff) << 16) | (static_cast<uint32_t>(qv[3] & 0xff) << 24);
-                o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
+                o.x = quant8_pack4(ub[0], ub[1], ub[2], ub[3]);
+                o.y = quant8_pack4(ub[4], ub[5], ub[6], ub[7]);
                 const size_t off = fmt ? packed_offset(fmt, row, c * 8, rows16) : static_cast<size_t>(row) * K + c * 8;
                 *reinterpret_cast<uint2*>(qb + off) = o;
             } else {
                 uint32_t o = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o |= static_cast<uint32_t>((qv[2 * e] & 0xf) | ((qv[2 * e + 1] & 0xf) << 4)) << (8 * e);
+                for (int e = 0; e < 4; ++e) o |= static_cast<uint32_t>((ub[2 * e] & 0xfu) | ((ub[2 * e + 1] & 0xfu) << 4)) << (8 * e);
                 const size_t off = fmt ? packed_offset(fmt, row, c * 4, rows16) : static_cast<size_t>(row) * (K >> 1) + c * 4;
                 *reinterpret_cast<uint32_t*>(qb + off) = o;
             }

@@ -9,6 +9,12 @@
 // the conventions fixed in include/mixq_hip.h.
 #include "common.h"
 
+#ifdef MIXQ_PAD                                       // (placement experiment: shifts every kernel of this code object by 4 MIXQ_PAD bytes)
+#define MIXQ_STR2(x) #x
+#define MIXQ_STR(x) MIXQ_STR2(x)
+extern "C" __global__ void mixq_pad_kernel(int* p) { asm volatile(".rept " MIXQ_STR(MIXQ_PAD) "\n s_nop 0\n .endr"); if (p) *p = 1; }
+#endif
+
 namespace {
 
 constexpr int QT = 256;                 // threads per row workgroup
@@ -46,41 +52,50 @@ __device__ __forceinline__ float amax_finish(uint32_t acc) {
 
 // FP6 codes of a chunk's 8 quantised values (MIXQ_FMT_F6X128)
 __device__ __forceinline__ void quant_codes8(const uint4& v, float s, float rs, uint32_t* code) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t ub[8];
+    quant8_exact<4>(v, s, rs, ub);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        code[2 * i]     = f6_code_of_int(quant_exact<4>(h2f(static_cast<uint16_t>(w[i] & 0xffffu)), s, rs));
-        code[2 * i + 1] = f6_code_of_int(quant_exact<4>(h2f(static_cast<uint16_t>(w[i] >> 16)), s, rs));
-    }
+    for (int i = 0; i < 8; ++i) code[i] = f6_code_of_int(quant8_int(ub[i]));
 }
 
 // q: plain -> row base pointer, packed (fmt != 0) -> matrix base pointer
 template <int BIT>
 __device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, void* q, int chunk, int row, int rows16, int fmt) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    int qv[8];
+    uint32_t ub[8];
+#ifdef MIXQ_OLD_QUANT_ARITH                          // (A/B build switch: round 4's per-value quant_exact)
+    {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        qv[2 * i]     = quant_exact<BIT>(h2f(static_cast<uint16_t>(w[i] & 0xffffu)), s, rs);
-        qv[2 * i + 1] = quant_exact<BIT>(h2f(static_cast<uint16_t>(w[i] >> 16)), s, rs);
+        for (int i = 0; i < 4; ++i) {
+            ub[2 * i]     = static_cast<uint32_t>(quant_exact<BIT>(h2f(static_cast<uint16_t>(w[i] & 0xffffu)), s, rs) + 0x400000) | 0x4b000000u;
+            ub[2 * i + 1] = static_cast<uint32_t>(quant_exact<BIT>(h2f(static_cast<uint16_t>(w[i] >> 16)), s, rs) + 0x400000) | 0x4b000000u;
+        }
     }
+#else
+    quant8_exact<BIT>(v, s, rs, ub);
+#endif
     if constexpr (BIT == 8) {
         uint2 o;
-        o.x = (qv[0] & 0xff) | ((qv[1] & 0xff) << 8) | ((qv[2] & 0xff) << 16) | (static_cast<uint32_t>(qv[3] & 0xff) << 24);
-        o.y = (qv[4] & 0xff) | ((qv[5] & 0xff) << 8) | ((qv[6] & 0xff) << 16) | (static_cast<uint32_t>(qv[7] & 0xff) << 24);
+#ifdef MIXQ_OLD_QUANT_ARITH
+        o.x = (ub[0] & 0xff) | ((ub[1] & 0xff) << 8) | ((ub[2] & 0xff) << 16) | ((ub[3] & 0xff) << 24);
+        o.y = (ub[4] & 0xff) | ((ub[5] & 0xff) << 8) | ((ub[6] & 0xff) << 16) | ((ub[7] & 0xff) << 24);
+#else
+        o.x = quant8_pack4(ub[0], ub[1], ub[2], ub[3]);
+        o.y = quant8_pack4(ub[4], ub[5], ub[6], ub[7]);
+#endif
         if (fmt) *reinterpret_cast<uint2*>(static_cast<char*>(q) + packed_offset(fmt, row, chunk * 8, rows16)) = o;
         else     reinterpret_cast<uint2*>(q)[chunk] = o;
     } else if (fmt == MIXQ_FMT_F6X128 || fmt == MIXQ_FMT_R6X128) {   // FP6 codes (include/mixq_hip.h): chunk = elements 8 chunk .. + 7 of the row
         uint32_t code[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) code[i] = f6_code_of_int(qv[i]);
+        for (int i = 0; i < 8; ++i) code[i] = f6_code_of_int(quant8_int(ub[i]));
         const int k = chunk * 8;
         f6_store8(fmt, static_cast<uint8_t*>(q) + f6_block_offset(row, k, rows16), row, f6_group(k), (k & 31) >> 3, code);
     } else {   // nibble pack: low nibble = even column (linear.py:14-18)
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            o |= static_cast<uint32_t>((qv[2 * i] & 0xf) | ((qv[2 * i + 1] & 0xf) << 4)) << (8 * i);
+            o |= static_cast<uint32_t>((ub[2 * i] & 0xfu) | ((ub[2 * i + 1] & 0xfu) << 4)) << (8 * i);
         if (fmt) *reinterpret_cast<uint32_t*>(static_cast<char*>(q) + packed_offset(fmt, row, chunk * 4, rows16)) = o;
         else     reinterpret_cast<uint32_t*>(q)[chunk] = o;
     }
@@ -163,9 +178,9 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
     }
     const float amax = block_max_256(amax_finish(amax_acc), red);
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
-    const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
+    const uint16_t sh = mixq_row_scale(amax, QMAX);
     const float s = h2f(sh);
-    const float rs = s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;      // one division per row; quant_exact needs none per element
+    const float rs = mixq_rcp_scale(s);      // one division per row; quant_exact needs none per element
     if (tid == 0) {
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
@@ -234,6 +249,9 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     for (int i = 0; i < NCH; ++i) {
         const int c = chunk(i);
         pg[i] = (pv && c < nchunk) ? pv[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
+#ifdef MIXQ_TUNING
+        if (dbg & 64) pg[i] = make_uint4(~0u, ~0u, ~0u, ~0u);          // timing probe: positions loaded, nothing extracted
+#endif
     }
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
@@ -293,9 +311,9 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         if (kept) __syncthreads();                         // (the row lives in one wave: only its LDS copy of x_out needs the order)
     }
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
-    const uint16_t sh = f2h(__fdiv_rn(amax, QMAX));
+    const uint16_t sh = mixq_row_scale(amax, QMAX);
     const float s = h2f(sh);
-    const float rs = s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;
+    const float rs = mixq_rcp_scale(s);
     if (!valid) return;
     if (t == 0) {
         x_scale[row] = sh;
@@ -346,6 +364,16 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = t + i * TPR;
+#ifdef MIXQ_TUNING
+            if (BIT == 8 && (dbg & 32)) {                               // timing probe (tools build): no quantise arithmetic - garbage bytes to the same place
+                if (c < nchunk) {
+                    const uint2 o = make_uint2(keep[i].x ^ keep[i].y ^ __float_as_uint(rs), keep[i].z ^ keep[i].w);
+                    if (fmt) *reinterpret_cast<uint2*>(static_cast<char*>(qrow) + packed_offset(fmt, row, c * 8, rows16)) = o;
+                    else     reinterpret_cast<uint2*>(qrow)[c] = o;
+                }
+                continue;
+            }
+#endif
             if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
         }
     }
@@ -422,9 +450,9 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(       // (parameter o
     __syncthreads();                                                      // every thread of the row has read the maximum (and dropped its outlier values into LDS) ...
     if (t == 0) row_amax[row] = 0u;                                       // ... before it is cleared for the producer's next run
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
-    const uint16_t sh = f2h(__fdiv_rn(h2f(static_cast<uint16_t>(abits)), QMAX));
+    const uint16_t sh = mixq_row_scale(h2f(static_cast<uint16_t>(abits)), QMAX);
     const float s = h2f(sh);
-    const float rs = s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;
+    const float rs = mixq_rcp_scale(s);
     if (t == 0) {
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
@@ -622,7 +650,7 @@ __global__ __launch_bounds__(QT) void repack_f6_kernel(const uint8_t* __restrict
 // quant_rows2_kernel as (threads per row, rows per workgroup); -1 = choose by shape.  Tuning / test knob: mixq_quant_set_config.
 MixqDevInt g_quant_cfg(-1);             // per device (common.h)
 #ifdef MIXQ_TUNING
-int g_quant_dbg = 0;                    // timing probes (bits: 1 no in-place zeroing, 2 no gather loads, 4 no outlier handling, 8 no x_out stores): tools build only
+int g_quant_dbg = 0;                    // timing probes (bits: 1 no in-place zeroing, 2 no gather loads, 4 no outlier handling, 8 no x_out stores, 32 no quantise arithmetic, 64 positions loaded but nothing extracted): tools build only
 #else
 constexpr int g_quant_dbg = 0;
 #endif
@@ -710,7 +738,7 @@ __global__ __launch_bounds__(256) void selftest_quant_exact_kernel(unsigned long
 {
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const float s = h2f(static_cast<uint16_t>(blockIdx.x + 1));          // bits 0x0001 .. 0x7bff
-    const float rs = __fdiv_rn(1.0f, s);
+    const float rs = mixq_rcp_scale(s);
     unsigned long long bad = 0;
     for (unsigned xb = threadIdx.x; xb < 65536u; xb += 256) {
         if ((xb & 0x7c00u) == 0x7c00u) continue;                          // inf / nan
@@ -718,6 +746,19 @@ __global__ __launch_bounds__(256) void selftest_quant_exact_kernel(unsigned long
         float q = rintf(__fdiv_rn(x, s));
         q = fminf(fmaxf(q, -QMAX), QMAX);
         bad += quant_exact<BIT>(x, s, rs) != static_cast<int>(q);
+        // the chunk form (quant8_exact): this value in slot xb % 8 of a chunk whose other slots hold its neighbours' bit patterns (finite ones)
+        uint32_t hw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const unsigned o = (xb + 8191u * (j + 1)) & 0xffffu; hw[j] = (o & 0x7c00u) == 0x7c00u ? 0u : o; }
+        hw[xb & 7u] = xb;
+        const uint4 v = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+        uint32_t ub[8];
+        quant8_exact<BIT>(v, s, rs, ub);
+        uint32_t got = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if ((xb & 7u) == static_cast<unsigned>(j)) got = ub[j];
+        bad += quant8_int(got) != static_cast<int>(q);
+        bad += BIT == 8 && (got & 0xffu) != (static_cast<uint32_t>(static_cast<int>(q)) & 0xffu);
     }
     if (bad) atomicAdd(mismatches, bad);
 }

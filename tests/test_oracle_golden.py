@@ -118,3 +118,14 @@ def test_oracle_fused_vs_dequant_reference(oracle):
     y = oracle.linear_fused(qx, qw, sx, sw, xo=xo, wo=wo, bias=bias).astype(np.float64)
     ref = oracle.linear_dequant_ref(qx, qw, sx, sw, xo=xo, ind=ind, bias=bias, wo=wo)
     assert np.abs(y - ref).max() <= 1e-2
+
+
+def test_row_scale_multiplication_equals_the_division_for_every_fp16_maximum():
+    """The kernels compute x_scale = fp16(amax * fp32(1 / qmax)) (mixq_amd/csrc/common.h: mixq_row_scale); the convention (include/mixq_hip.h,
+    oracle find_row_scale) is fp16(amax / qmax) with an fp32 IEEE division.  The two agree for every finite fp16 maximum and both widths."""
+    import numpy as np
+    a = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float32)
+    for qmax in (127.0, 7.0):
+        div = (a / np.float32(qmax)).astype(np.float16)
+        mul = (a * (np.float32(1.0) / np.float32(qmax))).astype(np.float16)
+        assert np.array_equal(div.view(np.uint16), mul.view(np.uint16))
