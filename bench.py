@@ -269,7 +269,7 @@ def cpu_baseline(rows):
 
 def hbm_traffic_from_profile(tag=""):
     """(HBM bytes per GEMM launch, source file) from the committed rocprofv3 PMC passes - the newest profiles/rNN_hbm_traffic<tag>.json -
-    or (None, None).  The counters need their own rocprofv3 --pmc passes (tools/r04_profile.sh), so the bench line carries the committed
+    or (None, None).  The counters need their own rocprofv3 --pmc passes (tools/r05_profile.sh), so the bench line carries the committed
     figure of the same configuration (tag "" = the metric shape W8A8, "_w4a4", "_8192x28672")."""
     try:
         best = src = None

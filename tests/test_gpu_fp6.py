@@ -291,7 +291,7 @@ def test_a_four_bit_layer_keeps_one_weight_image_by_default():
 
 
 def test_small_batches_of_a_four_bit_layer_stream_a_nibble_image():
-    """Opt-in (MixqConfig.small_batch_m4 = 32; narrow layers at decode: 9-10 vs 11-12 us at 4096 -> 4096, tools/time_w4_small_batch.py): M <= 32 is a
+    """Opt-in (MixqConfig.small_batch_m4 = 32; narrow layers at decode: 9-10 vs 11-12 us at 4096 -> 4096, profiles/r04_w4a4_small_batch.txt): M <= 32 is a
     weight stream - the layer serves it from a second, nibble image (built when the first small batch arrives, also after the plain matrix
     was dropped) with P16X64 activations; larger batches keep the FP6 pair.  Same bits either way."""
     K, N, ncols = 1024, 320, 10

@@ -9,7 +9,7 @@ modules/fused/attn.py:219,263, modules/fused/mlp.py:57-70), at 512 tokens:
 over `--layers` independent copies of the weights (32 x 202 MB = 6.5 GB for the 7b shapes): launch i of the graph runs layer i % layers, so
 every layer's weights come from HBM, as in a model - and, for comparison, over ONE copy (everything resident in the 256 MB memory-side cache
 after the first pass, as in a single-layer benchmark loop).  Measurement protocol: bench.conditioned_replay.  A per-kernel breakdown comes
-from running this script under `rocprofv3 --kernel-trace --stats` (tools/r04_profile.sh does, into profiles/r04_block_kernels.txt)."""
+from running this script under `rocprofv3 --kernel-trace --stats` (round 4's evidence script did, into profiles/r04_block_kernels.txt)."""
 import argparse
 import os
 import sys
