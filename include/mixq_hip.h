@@ -139,14 +139,14 @@ int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_de
  *     [W = ceil(K / 32) little-endian words : bit c set <=> column c is one of ind[0 .. live count)]
  *     [1 word                               : the number of columns the map marks]
  *     [pad to a multiple of 4 words]
- *     [K uint16, two per word, low half first : pos[c] = j with ind[j] == c, 0xffff for every other column]   (K, n < 65535)
- * (required when n > 0).  Same bytes out.  With the map every byte the pass needs arrives in ONE memory round trip: the eight positions of
- * a 16-byte chunk are requested beside the chunk, the outlier values are taken out of the registers that hold the row (an LDS copy of the
- * x_out row, stored as a whole), the marked halves are zeroed in the chunk, which goes back to x - the row maximum waits for neither the
- * device-resident count, nor `ind`, nor a mask build in LDS, and there is no dependent gather ind[j] -> x[row][ind[j]] behind the row
- * load (5.2 -> see profiles/r05_quant_kept_map.txt us at 512 x 4096, 41 columns).  A map built for another count than the live one (n, or
+ *     [K uint16, two per word, low half first : keep[c] = 0x0000 for an outlier column, 0xffff for every other column]
+ * (required when n > 0).  Same bytes out.  With the map every byte the pass needs arrives in ONE memory round trip: the eight AND-masks of
+ * a 16-byte chunk are requested beside the chunk; a chunk that holds a marked column goes to an LDS image of the row as a whole and is
+ * zeroed by four ANDs (it goes back to x), and lane j reads element ind[j] of that image for x_out[row][j] behind the barrier of the row
+ * maximum - the row maximum waits for neither the device-resident count, nor `ind`, nor a mask build in LDS, there is no dependent
+ * gather ind[j] -> x[row][ind[j]] behind the row load, and no per-element branch in an issue-bound pass (profiles/r05_quant_pmc.txt).  A map built for another count than the live one (n, or
  * *n_dev when given - device code may lower it without the host knowing) is ignored: the kernel then builds its own mask, as
- * mixq_quant_fused does; so is a map for more than 4096 (padded) outlier columns.  A producing GEMM reads only the bit words
+ * mixq_quant_fused does; so is a map when the row's fp16 image does not fit the default 64 KB of LDS (K > 30000).  A producing GEMM reads only the bit words
  * (mixq_gemm_i8_fused_amax).  mixq_linear_forward takes this route when args->col_mask is set. */
 int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
                             uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,

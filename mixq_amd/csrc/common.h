@@ -236,26 +236,22 @@ __device__ __forceinline__ void f6_store16(int fmt, uint8_t* blk, int row, int g
     f6_store_words(fmt, blk, row, g, h, lo0, hi0 | (lo1 << 16), (lo1 >> 16) | (hi1 << 16));
 }
 // The KEPT OUTLIER MAP of a frozen layer (include/mixq_hip.h, mixq_quant_fused_masked): [W = ceil(K / 32) words: bit c set <=> column c is
-// an outlier column][1 word: the number of columns marked][pad to a multiple of 4 words][K uint16: pos[c] = j with ind[j] == c, 0xffff
-// for every other column].  The positions are what lets a quantise pass take its outlier values OUT OF THE ROW IT HOLDS IN REGISTERS:
-// a thread reads the eight positions of each of its 16-byte chunks beside the chunk (the table is a few KB and cache-resident, the same
-// for every row), drops the marked elements into an LDS copy of the x_out row and zeroes them - no `ind[j]` -> `x[row][ind[j]]` chain of
-// two dependent memory round trips behind the row load, no scattered 2-byte stores.
-__device__ __forceinline__ const uint4* kept_pos_table(const uint32_t* map, int K) {
+// an outlier column][1 word: the number of columns marked][pad to a multiple of 4 words][K uint16 AND-masks: keep[c] = 0x0000 for an
+// outlier column, 0xffff for every other column].  The AND-masks are what lets a quantise pass take its outlier values OUT OF THE ROW IT
+// HOLDS IN REGISTERS at almost no instruction cost (the passes are issue-bound: profiles/r05_quant_pmc.txt): a thread reads the 16 bytes of
+// masks of each of its 16-byte chunks beside the chunk (the table is a few KB and cache-resident, the same for every row); a chunk that
+// holds a marked column - a handful per wave - goes to an LDS image of the row AS A WHOLE (one ds_write_b128) and is zeroed by four
+// v_and; behind the barrier of the row maximum lane j reads element ind[j] of that image for x_out[row][j].  No `ind[j]` ->
+// `x[row][ind[j]]` chain of two dependent memory round trips behind the row load, no scattered 2-byte stores, no per-element branches.
+__device__ __forceinline__ const uint4* kept_mask_table(const uint32_t* map, int K) {
     return reinterpret_cast<const uint4*>(map + ((((K + 31) >> 5) + 1 + 3) & ~3));
 }
-// One chunk against its eight positions: marked elements go to stage[pos] and are zeroed in v.  Returns true when the chunk held any.
-__device__ __forceinline__ bool kept_extract8(uint4& v, const uint4& pos, uint16_t* stage, int ldo) {
-    if ((pos.x & pos.y & pos.z & pos.w) == 0xffffffffu) return false;
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    const uint32_t p[4] = {pos.x, pos.y, pos.z, pos.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t plo = p[i] & 0xffffu, phi = p[i] >> 16;
-        if (plo != 0xffffu) { if (plo < static_cast<uint32_t>(ldo)) stage[plo] = static_cast<uint16_t>(w[i] & 0xffffu); w[i] &= 0xffff0000u; }
-        if (phi != 0xffffu) { if (phi < static_cast<uint32_t>(ldo)) stage[phi] = static_cast<uint16_t>(w[i] >> 16);     w[i] &= 0x0000ffffu; }
-    }
-    v = make_uint4(w[0], w[1], w[2], w[3]);
+// One chunk against its eight AND-masks: a chunk with a marked element goes to the LDS row image (chunk c at halves [8 c, 8 c + 8)) and
+// continues with those elements zeroed.  Returns true when the chunk held any.
+__device__ __forceinline__ bool kept_apply8(uint4& v, const uint4& mk, uint16_t* rowimg, int c) {
+    if ((mk.x & mk.y & mk.z & mk.w) == 0xffffffffu) return false;
+    reinterpret_cast<uint4*>(rowimg)[c] = v;
+    v = make_uint4(v.x & mk.x, v.y & mk.y, v.z & mk.z, v.w & mk.w);
     return true;
 }
 

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
     uint16_t* __restrict__ out, int ldout, uint16_t* __restrict__ x_scale,
     void* __restrict__ q, uint16_t* __restrict__ x_out, int ldxo, int32_t* __restrict__ flag, float thr_scale, int rows16, int fmt)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];     // column bitmask, 8 floats, [ldxo] fp16: the x_out row (kept route)
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];     // column bitmask, 8 floats, (16-byte aligned) [K] fp16: the row's LDS image (kept route)
     const int row = blockIdx.x, tid = threadIdx.x;
     const int mask_words = (K + 31) >> 5;
     float* red = reinterpret_cast<float*>(smem + mask_words);
@@ -67,14 +67,15 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
             wk[i] = reinterpret_cast<const uint4*>(w)[c];
         }
     }
-    // col_mask (mixq_rmsnorm_quant_fused_masked): the next layer's KEPT OUTLIER MAP (bits, count, per-column positions: quant.hip).  A
-    // chunk's eight positions are 16 bytes of it, requested here with the row and the live count: the normalised outlier values are then
-    // taken out of the registers that hold the row - unmasked they cost three dependent round trips (count, ind[j], x[ind[j]]) and two
-    // barriers around the LDS mask in front of the row maximum.
-    const uint4* pv = (QUANT && col_mask) ? reinterpret_cast<const uint4*>(col_mask + ((mask_words + 1 + 3) & ~3)) : nullptr;
+    // col_mask (mixq_rmsnorm_quant_fused_masked): the next layer's KEPT OUTLIER MAP (bits, count, per-column AND-masks: common.h).  A
+    // chunk's eight masks are 16 bytes of it, requested here with the row, the live count and this lane's column ind[tid]: the normalised
+    // outlier values are then taken out of the registers that hold the row (a marked chunk goes to the row's LDS image as a whole) -
+    // unmasked they cost three dependent round trips (count, ind[j], x[ind[j]]) and two barriers around the LDS mask in front of the row maximum.
+    const uint4* pv = (QUANT && col_mask) ? kept_mask_table(col_mask, K) : nullptr;
     uint4 pg[NCH];
-    int nd0 = n_cap, mcount = 0;
+    int nd0 = n_cap, mcount = 0, gi = 0;
     if (pv) {
+        if (tid < n_cap) gi = ind[tid];
         mcount = static_cast<int>(col_mask[mask_words]);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
 
     int n = 0;
     bool have_out = false, kept = false;
-    uint16_t* stage = reinterpret_cast<uint16_t*>(red + 8);              // kept route: this row of x_out, assembled in LDS
+    uint16_t* rowimg = reinterpret_cast<uint16_t*>(smem + ((mask_words + 8 + 3) & ~3));   // kept route: marked chunks of the normalised row
     if constexpr (QUANT) {
         n = n_cap;
         if (pv) n = nd0 < n_cap ? nd0 : n_cap;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
                 y[e] = lo | (hi << 16);
             }
             keep[i] = make_uint4(y[0], y[1], y[2], y[3]);
-            if (kept) (void)kept_extract8(keep[i], pg[i], stage, ldxo);    // normalised outlier values -> the LDS copy of the x_out row; zeroed in the chunk
+            if (kept) (void)kept_apply8(keep[i], pg[i], rowimg, c);        // a chunk with normalised outlier values -> the row's LDS image; zeroed in the chunk
             const uint32_t z[4] = {keep[i].x, keep[i].y, keep[i].z, keep[i].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
     if constexpr (!QUANT) return;
 
     amax = block_max(amax, red + 4);                                      // (its barrier also orders the LDS copy of the x_out row)
-    if (kept && x_out) for (int j = tid; j < ldxo; j += NT) x_out[static_cast<size_t>(row) * ldxo + j] = j < n ? stage[j] : static_cast<uint16_t>(0);
+    if (kept && x_out) for (int j = tid; j < ldxo; j += NT) x_out[static_cast<size_t>(row) * ldxo + j] = j < n ? rowimg[j == tid ? gi : ind[j]] : static_cast<uint16_t>(0);
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const uint16_t sh = mixq_row_scale(amax, QMAX);
     const float s = h2f(sh);
@@ -219,7 +220,7 @@ int launch_norm(const uint16_t* x, int ldx, const uint16_t* w, float eps, uint16
                 const int32_t* n_dev, uint16_t* x_scale, void* q, uint16_t* x_out, int ldxo, int32_t* flag, int M, int K,
                 float thr, int qfmt, hipStream_t st, const uint32_t* col_mask = nullptr)
 {
-    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + 8) * sizeof(uint32_t) + (col_mask ? static_cast<size_t>(ldxo) * 2 + 4 : 0);
+    const size_t shm = ((static_cast<size_t>((K + 31) >> 5) + 8 + 3) & ~static_cast<size_t>(3)) * sizeof(uint32_t) + (col_mask ? static_cast<size_t>(K) * 2 : 0);
     const int nchunk = K >> 3;
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g(M), b(NT);
@@ -262,7 +263,7 @@ static int rmsnorm_quant_common(const uint16_t* x, const uint16_t* weight, uint1
     const float qmax = static_cast<float>((1 << (bit - 1)) - 1);
     const float thr = fp16_round(fp16_round(sigma) / qmax);
     uint16_t* xo = (n > 0) ? x_out : nullptr;
-    if (ldxo > 4096 || K > 65528) col_mask = nullptr;   // (as mixq_quant_fused_masked: the kept route assembles the x_out row in LDS, 16-bit columns)
+    if (K > 30000) col_mask = nullptr;                  // (as mixq_quant_fused_masked: the kept route keeps an fp16 image of the row in LDS, inside the default 64 KB)
     if (bit == 8)
         return launch_norm<8, true>(x, ldx, weight, eps, out, ldout, ind, n, n_dev, x_scale, q, xo, ldxo, flag, M, K, thr, qfmt,
                                     mixq_stream(stream), col_mask);

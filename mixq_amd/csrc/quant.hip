@@ -207,9 +207,11 @@ __global__ __launch_bounds__(QT) void quant_rows_kernel(
 // memory while the row loads are in flight (no LDS copy of the row, no second pass over it), the column bitmask is built
 // once per workgroup and shared by its RPB rows, and with TPR == 64 a row lives in ONE wave, so the absmax needs no LDS
 // round trip and no barrier at all when the layer has no outlier columns.  Results are bit-identical to the first form.
-template <int BIT, int TPR, int RPB, int NCH>
+template <int BIT, int TPR, int RPB, int NCH, bool KEPT>
 // (parameter order: what a thread needs before it can request its row - 12 dwords - comes FIRST: built with -amdgpu-kernarg-preload-count
 // those arrive in SGPRs with the wave, and no scalar load stands in front of the row request; the rest is waited for behind it)
+// KEPT: the caller handed over the layer's kept outlier map (col_mask != nullptr, n_cap > 0) - the instantiation holds only that route (and
+// its slow form for a map that does not describe the live count); !KEPT: the route that builds the column mask in LDS.
 __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     uint16_t* __restrict__ x, const uint32_t* __restrict__ col_mask, const int32_t* __restrict__ n_dev, const int32_t* __restrict__ ind,
     int ldx, int M, int K, int n_cap,
@@ -217,12 +219,14 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     int32_t* __restrict__ flag, float thr_scale, int rows16, int fmt, int dbg)
 {
     constexpr int NT = TPR * RPB, WPR = TPR / 64;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [K/32] column bitmask, RPB * WPR floats, [RPB][ldo] fp16: the x_out rows (kept route)
-    const int tid = threadIdx.x, rw = tid / TPR, t = tid - rw * TPR;
+    // !KEPT: [K/32] column bitmask, RPB * WPR floats.  KEPT: RPB * WPR floats (padded to 16 bytes), [RPB][K] fp16: the rows' LDS images
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, rw = RPB == 1 ? 0 : tid / TPR, t = tid - rw * TPR;
     const int row = blockIdx.x * RPB + rw;
-    const bool valid = row < M;
+    const bool valid = RPB == 1 || row < M;
     const int mask_words = (K + 31) >> 5;
-    float* red = reinterpret_cast<float*>(smem + mask_words);
+    float* red = reinterpret_cast<float*>(KEPT ? smem : smem + mask_words);
+    uint16_t* rowimg = reinterpret_cast<uint16_t*>(smem + ((RPB * WPR + 3) & ~3)) + static_cast<size_t>(rw) * K;   // (KEPT)
     uint16_t* xr = x + static_cast<size_t>(valid ? row : 0) * ldx;
     const int nchunk = K >> 3;
     const uint4* xv = reinterpret_cast<const uint4*>(xr);
@@ -238,28 +242,32 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         const int c = chunk(i);
         keep[i] = (valid && c < nchunk) ? xv[c] : make_uint4(0, 0, 0, 0);
     }
-    // col_mask (mixq_quant_fused_masked): the caller's KEPT OUTLIER MAP (a frozen layer's never changes; layout above).  A chunk's eight
-    // positions are 16 bytes of it, requested here beside the row: everything the pass needs then arrives in ONE memory round trip - the
-    // row maximum waits for neither the device-resident count, nor `ind`, nor the two barriers around building a mask in LDS, and the
-    // outlier values are taken from the registers that hold the row (no second, dependent round trip for x[row][ind[j]]).
-    const uint4* pv = col_mask ? kept_pos_table(col_mask, K) : nullptr;
-    const int mcount = col_mask ? static_cast<int>(col_mask[mask_words]) : 0;
-    uint4 pg[NCH];
+    // col_mask (mixq_quant_fused_masked): the caller's KEPT OUTLIER MAP (a frozen layer's never changes; layout: common.h).  A chunk's eight
+    // AND-masks are 16 bytes of it, requested here beside the row, with the count it was built for and this lane's column ind[t]:
+    // everything the pass needs then arrives in ONE memory round trip - the row maximum waits for neither the device-resident count, nor
+    // `ind`, nor the two barriers around building a mask in LDS, and the outlier values are taken from the registers that hold the row (no
+    // second, dependent round trip for x[row][ind[j]]).
+    uint4 mk[KEPT ? NCH : 1];
+    int mcount = 0, gi = 0;
+    if constexpr (KEPT) {
+        const uint4* mv = kept_mask_table(col_mask, K);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = chunk(i);
-        pg[i] = (pv && c < nchunk) ? pv[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int i = 0; i < NCH; ++i) {
+            const int c = chunk(i);
+            mk[i] = c < nchunk ? mv[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
 #ifdef MIXQ_TUNING
-        if (dbg & 64) pg[i] = make_uint4(~0u, ~0u, ~0u, ~0u);          // timing probe: positions loaded, nothing extracted
+            if (dbg & 64) mk[i] = make_uint4(~0u, ~0u, ~0u, ~0u);          // timing probe: masks loaded, nothing extracted
 #endif
+        }
+        mcount = static_cast<int>(col_mask[mask_words]);
+        if (t < n_cap) gi = ind[t];
     }
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
     const bool have_out = (n > 0) && ind != nullptr && !(dbg & 4);
     // (the kept map must describe the LIVE count, which device code may have lowered behind the host's back: the word behind the bits
-    // says how many columns it marks - requested with the row - and a map built for another count is not used: the kernel builds its own mask)
-    const bool kept = pv != nullptr && have_out && mcount == n;
-    uint16_t* stage = reinterpret_cast<uint16_t*>(red + RPB * WPR) + rw * ldo;   // kept route: this row's x_out, assembled in LDS
+    // says how many columns it marks - requested with the row - and a map built for another count is not used: the slow form below)
+    const bool kept = KEPT && have_out && mcount == n;
     // Without a kept map the gather of the outlier values (ind[j] -> x[row][ind[j]]) is a second, dependent memory round trip.  Only the
     // column bitmask has to exist before the row can be processed; the gathered values are REQUESTED here (up to GQ per thread, the rest
     // in the tail loop) and only consumed - stored to x_out, their column zeroed in x - after the quantised row has been written,
@@ -267,21 +275,37 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     constexpr int GQ = 2;
     int gcol[GQ] = {-1, -1};
     uint16_t gval[GQ] = {0, 0};
-    if (have_out && !kept) {
-        for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
+    if constexpr (!KEPT) {
+        if (have_out) {
+            for (int i = tid; i < mask_words; i += NT) smem[i] = 0u;
 #pragma unroll
-        for (int g = 0; g < GQ; ++g) { const int j = t + g * TPR; if (j < n) gcol[g] = ind[j]; }
-        __syncthreads();
-        if (rw == 0) {                                     // one row's threads build the mask for the whole workgroup
+            for (int g = 0; g < GQ; ++g) { const int j = t + g * TPR; if (j < n) gcol[g] = ind[j]; }
+            __syncthreads();
+            if (rw == 0) {                                     // one row's threads build the mask for the whole workgroup
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0) atomicOr(&smem[gcol[g] >> 5], 1u << (gcol[g] & 31));
-            for (int j = t + GQ * TPR; j < n; j += TPR) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
+                for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0) atomicOr(&smem[gcol[g] >> 5], 1u << (gcol[g] & 31));
+                for (int j = t + GQ * TPR; j < n; j += TPR) { const int c = ind[j]; atomicOr(&smem[c >> 5], 1u << (c & 31)); }
+            }
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0 && !(dbg & 2)) gval[g] = xr[gcol[g]];
+            }
+            __syncthreads();
         }
-        if (valid) {
+    } else if (have_out && !kept) {
+        // slow form (a map for another count than the live one): the whole row through its LDS image, lane j takes and zeroes column ind[j]
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) if (gcol[g] >= 0 && !(dbg & 2)) gval[g] = xr[gcol[g]];
+        for (int i = 0; i < NCH; ++i) { const int c = chunk(i); if (c < nchunk) reinterpret_cast<uint4*>(rowimg)[c] = keep[i]; }
+        __syncthreads();
+        for (int j = t; j < n; j += TPR) {
+            const int c = ind[j];
+            const uint16_t v = rowimg[c];
+            rowimg[c] = 0;
+            if (valid) { if (x_out) x_out[static_cast<size_t>(row) * ldo + j] = v; xr[c] = 0; }
         }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) { const int c = chunk(i); if (c < nchunk) keep[i] = reinterpret_cast<const uint4*>(rowimg)[c]; }
     }
 
     uint32_t amax_acc = 0u;
@@ -289,10 +313,10 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     for (int i = 0; i < NCH; ++i) {
         const int c = chunk(i);
         if (c < nchunk) {
-            if (kept) {
-                // marked elements -> the LDS copy of the x_out row, zeroed in the registers; the chunk goes back to x with its outlier
-                // columns zeroed (the reference zeroes the caller's tensor in place; the other six or seven halves are rewritten unchanged)
-                if (kept_extract8(keep[i], pg[i], stage, ldo) && valid && !(dbg & 1)) reinterpret_cast<uint4*>(xr)[c] = keep[i];
+            if constexpr (KEPT) {
+                // a chunk with marked elements -> the LDS image of the row, zeroed in the registers; it goes back to x with its outlier columns
+                // zeroed (the reference zeroes the caller's tensor in place; the other six or seven halves are rewritten unchanged)
+                if (kept && kept_apply8(keep[i], mk[i], rowimg, c) && valid && !(dbg & 1)) reinterpret_cast<uint4*>(xr)[c] = keep[i];
                 amax_acc = amax8_masked(keep[i], 0u, amax_acc);
             } else {
                 const uint32_t m8 = have_out ? ((smem[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
@@ -307,9 +331,7 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         amax = red[rw * WPR];
 #pragma unroll
         for (int w = 1; w < WPR; ++w) amax = fmaxf(amax, red[rw * WPR + w]);
-    } else {
-        if (kept) __syncthreads();                         // (the row lives in one wave: only its LDS copy of x_out needs the order)
-    }
+    }                                                      // (WPR == 1: the row lives in ONE wave, whose LDS operations are ordered - the image needs no barrier)
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const uint16_t sh = mixq_row_scale(amax, QMAX);
     const float s = h2f(sh);
@@ -377,8 +399,15 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
             if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
         }
     }
-    if (kept) {                                                     // the whole x_out row (zeros behind the live columns) from its LDS copy
-        if (x_out && !(dbg & 8)) for (int j = t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = j < n ? stage[j] : static_cast<uint16_t>(0);
+    if constexpr (KEPT) {
+        if (x_out && !(dbg & 8)) {
+            uint16_t* orow = x_out + static_cast<size_t>(row) * ldo;
+            if (kept) {                                             // x_out[row][j] = element ind[j] of the row's image; zeros behind the live columns
+                for (int j = t; j < ldo; j += TPR) orow[j] = j < n ? rowimg[j == t ? gi : ind[j]] : static_cast<uint16_t>(0);
+            } else {                                                // (the slow form stored the live columns already)
+                for (int j = (have_out ? n : 0) + t; j < ldo; j += TPR) orow[j] = 0;
+            }
+        }
         return;
     }
     if (have_out) {
@@ -399,7 +428,6 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
     if (x_out && !(dbg & 8)) for (int j = (have_out ? n : 0) + t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = 0;
 }
 
-
 // One-pass form for a row whose masked |x| maximum is already KNOWN (the GEMM that produced x left it in row_amax, as fp16 bit
 // patterns maximised with atomics - mixq_gemm_i8_fused_amax): no reduction, no column-mask build (col_mask is the layer's kept outlier
 // map, whose bit words the producer used), one barrier that only orders "everybody has read the maximum" before it is cleared for the next forward.
@@ -410,13 +438,14 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(       // (parameter o
     const int32_t* __restrict__ ind, int ldx, int K, int n_cap, int ldo,
     uint16_t* __restrict__ x_scale, void* __restrict__ q, uint16_t* __restrict__ x_out, int32_t* __restrict__ flag, float thr_scale, int rows16, int fmt)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t kstage[];       // [ldo]: this row of x_out (kept-map route)
+    extern __shared__ __attribute__((aligned(16))) uint16_t kimg[];         // [K]: the row's LDS image (kept-map route; K <= 30000)
     const int row = blockIdx.x, t = threadIdx.x;
     uint16_t* xr = x + static_cast<size_t>(row) * ldx;
     const int nchunk = K >> 3, mask_words = (K + 31) >> 5;
     const uint4* xv = reinterpret_cast<const uint4*>(xr);
-    const uint4* pv = col_mask ? kept_pos_table(col_mask, K) : nullptr;     // (col_mask is the layer's kept outlier map: bits, count, positions)
+    const uint4* pv = (col_mask && K <= 30000) ? kept_mask_table(col_mask, K) : nullptr;     // (col_mask is the layer's kept outlier map: bits, count, AND-masks)
     const int mcount = col_mask ? static_cast<int>(col_mask[mask_words]) : 0;
+    const int gi = (ind && t < n_cap) ? ind[t] : 0;                         // lane j's column: x_out[row][j] = element ind[j] of the row's image
     uint4 keep[NCH], pg[NCH];
     uint32_t m8[NCH];
 #pragma unroll
@@ -430,7 +459,7 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(       // (parameter o
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
     const bool have_out = (n > 0) && ind != nullptr;
-    const bool kept = have_out && pv != nullptr && mcount == n && ldo <= 16384;   // (a map built for another live count: the dependent gather below)
+    const bool kept = have_out && pv != nullptr && mcount == n;           // (a map built for another live count: the dependent gather below)
     // without a usable map the outlier values of this row are requested now and consumed (x_out, in-place zero) after the quantised row has been written
     constexpr int GQ = 2;
     int gcol[GQ] = {-1, -1};
@@ -444,7 +473,7 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(       // (parameter o
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = t + i * TPR;
-            if (c < nchunk && kept_extract8(keep[i], pg[i], kstage, ldo)) reinterpret_cast<uint4*>(xr)[c] = keep[i];   // (in-place zeroing of the marked columns)
+            if (c < nchunk && kept_apply8(keep[i], pg[i], kimg, c)) reinterpret_cast<uint4*>(xr)[c] = keep[i];   // (in-place zeroing of the marked columns)
         }
     }
     __syncthreads();                                                      // every thread of the row has read the maximum (and dropped its outlier values into LDS) ...
@@ -467,7 +496,7 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(       // (parameter o
         }
     }
     if (kept) {
-        if (x_out) for (int j = t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = j < n ? kstage[j] : static_cast<uint16_t>(0);
+        if (x_out) for (int j = t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = j < n ? kimg[j == t ? gi : ind[j]] : static_cast<uint16_t>(0);
         return;
     }
     if (have_out) {
@@ -662,16 +691,21 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
                        const uint32_t* col_mask)
 {
     const int nchunk = K >> 3;
-    const size_t shm = (static_cast<size_t>((K + 31) >> 5) + RPB * (TPR / 64)) * sizeof(uint32_t) + (col_mask ? static_cast<size_t>(RPB) * ldo * 2 + 4 : 0);
+    // kept route: the reduction floats (padded to 16 bytes) and one fp16 image per row; otherwise the column bitmask and the floats
+    if (static_cast<size_t>(RPB) * K * 2 > 60000) col_mask = nullptr;       // (the images stay inside the default 64 KB of dynamic LDS: beyond, the in-kernel mask)
+    const size_t shm = col_mask ? static_cast<size_t>((RPB * (TPR / 64) + 3) & ~3) * sizeof(uint32_t) + static_cast<size_t>(RPB) * K * 2
+                                : (static_cast<size_t>((K + 31) >> 5) + RPB * (TPR / 64)) * sizeof(uint32_t);
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0;
     dim3 g((M + RPB - 1) / RPB), b(TPR * RPB);
-#define MIXQ_QLAUNCH2(NCH) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH>), g, b, shm, st, x, col_mask, n_dev, ind, ldx, M, K, n, x_scale, q, x_out, ldo, flag, thr_scale, rows16, qfmt, g_quant_dbg)
+#define MIXQ_QLAUNCH2K(NCH, KEPT) hipLaunchKernelGGL((quant_rows2_kernel<BIT, TPR, RPB, NCH, KEPT>), g, b, shm, st, x, col_mask, n_dev, ind, ldx, M, K, n, x_scale, q, x_out, ldo, flag, thr_scale, rows16, qfmt, g_quant_dbg)
+#define MIXQ_QLAUNCH2(NCH) do { if (col_mask) MIXQ_QLAUNCH2K(NCH, true); else MIXQ_QLAUNCH2K(NCH, false); } while (0)
     if      (nchunk <= 1 * TPR)  MIXQ_QLAUNCH2(1);
     else if (nchunk <= 2 * TPR)  MIXQ_QLAUNCH2(2);
     else if (nchunk <= 4 * TPR)  MIXQ_QLAUNCH2(4);
     else if (nchunk <= 8 * TPR)  MIXQ_QLAUNCH2(8);
     else if (nchunk <= 16 * TPR) MIXQ_QLAUNCH2(16);
     else return -100;                                     // the caller falls back to the any-K kernel
+#undef MIXQ_QLAUNCH2K
 #undef MIXQ_QLAUNCH2
     return mixq_launch_status();
 }
@@ -800,7 +834,7 @@ static int quant_fused_common(uint16_t* x, const int32_t* ind, int n, const int3
     // reference: `x_scale.max() > self.sigma / qmax` with sigma an fp16 [1,1] tensor -> fp16(fp16(sigma)/qmax)
     const float thr = fp16_round(fp16_round(sigma) / qmax);
     uint16_t* xo = (n > 0) ? x_out : nullptr;
-    if (ldo > 4096 || K > 65528) col_mask = nullptr;   // (the kept route assembles x_out rows in LDS and addresses columns with 16 bits: beyond that, the in-kernel mask)
+    if (K > 32768) col_mask = nullptr;                 // (the kept route keeps an fp16 image of the row in LDS: beyond 64 KB per row, the in-kernel mask)
     if (bit == 8) return launch_quant_rows<8>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream), col_mask);
     return launch_quant_rows<4>(x, ldx, ind, n, n_dev, x_scale, q, xo, ldo, flag, M, K, thr, qfmt, mixq_stream(stream), col_mask);
 }
@@ -838,7 +872,7 @@ extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, con
     uint16_t* xo = (n > 0) ? x_out : nullptr;
     const int rows16 = qfmt ? ((M + 15) & ~15) : 0, nchunk = K >> 3;
     hipStream_t st = mixq_stream(stream);
-#define MIXQ_QK(BITv, TPRv, NCHv) hipLaunchKernelGGL((quant_known_kernel<BITv, TPRv, NCHv>), dim3(M), dim3(TPRv), static_cast<size_t>(ldo <= 16384 ? ldo : 0) * 2 + 4, st, x, col_mask, row_amax, n_dev, ind, \
+#define MIXQ_QK(BITv, TPRv, NCHv) hipLaunchKernelGGL((quant_known_kernel<BITv, TPRv, NCHv>), dim3(M), dim3(TPRv), static_cast<size_t>(K <= 30000 ? K : 0) * 2 + 16, st, x, col_mask, row_amax, n_dev, ind, \
                                                      ldx, K, n, ldo, x_scale, q, xo, flag, thr, rows16, qfmt)
 #define MIXQ_QK_BY_SIZE(BITv)                                             \
     if      (nchunk <= 256)      MIXQ_QK(BITv, 256, 1);                   \

@@ -173,9 +173,9 @@ def kept_outlier_map(ind, K):
     head[:words] = w
     head[words] = n
     kp = ((K + 7) // 8) * 8
-    pos = torch.full((kp,), 0xffff, dtype=torch.int64, device=dev)
-    pos[ind.long()] = torch.arange(n, device=dev, dtype=torch.int64)
-    pw = pos.view(kp // 2, 2)
+    keep = torch.full((kp,), 0xffff, dtype=torch.int64, device=dev)          # per-column AND-mask: 0x0000 for an outlier column
+    keep[ind.long()] = 0
+    pw = keep.view(kp // 2, 2)
     pw = pw[:, 0] | (pw[:, 1] << 16)
     pw = torch.where(pw >= 2 ** 31, pw - 2 ** 32, pw).to(torch.int32)
     return torch.cat([head, pw])
@@ -493,7 +493,7 @@ class MixLinear_GEMM(nn.Module):
     def _col_mask(self):
         """This layer's KEPT OUTLIER MAP (include/mixq_hip.h, mixq_quant_fused_masked), int32 words: [ceil(K / 32) words: bit k set <=> input
         column k is one of this layer's outlier columns][ONE word: the number of columns marked - what the quantise passes check a kept map
-        against][pad to a multiple of 4 words][K uint16, two per word: pos[k] = j with ind[j] == k, 0xffff elsewhere].  None without outliers.
+        against][pad to a multiple of 4 words][K uint16 AND-masks, two per word: 0x0000 for an outlier column, 0xffff elsewhere].  None without outliers.
         A producing GEMM reads only the bits (its row-maximum side output skips the marked columns)."""
         n = int(self.ind.shape[0])
         if n == 0:

@@ -622,7 +622,7 @@ def _want_fmt(packed, fmt):
 
 
 def kept_map_words(K):
-    """int32 words of the kept outlier map of K columns (include/mixq_hip.h: bits, count, pad to 4 words, K 16-bit positions)."""
+    """int32 words of the kept outlier map of K columns (include/mixq_hip.h: bits, count, pad to 4 words, K 16-bit AND-masks)."""
     return (((K + 31) // 32 + 1 + 3) // 4) * 4 + ((K + 7) // 8) * 4
 
 
@@ -631,7 +631,7 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
     quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n]).  With fmt = FMT_P16X64 /
     FMT_F16X64 (or packed=True: P16x64) q_x is emitted directly in that layout ([roundup(M,16), KB] bytes) and tagged.
     `n_dev` (device int32[1]) overrides the count: `ind` then is a buffer of capacity ind.numel().
-    `col_mask`: the caller's kept outlier map of the live `ind` entries (device int32 words - bit words, count word, per-column positions:
+    `col_mask`: the caller's kept outlier map of the live `ind` entries (device int32 words - bit words, count word, per-column AND-masks:
     include/mixq_hip.h, linear.kept_outlier_map) - the pass then needs ONE memory round trip (mixq_quant_fused_masked; same bytes out)."""
     _dev_check(x, x_scale, ind, col_mask)
     fmt = _want_fmt(packed, fmt)
@@ -655,7 +655,7 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
         op, ldo, ip = None, 0, None
     if col_mask is not None and n:
         if col_mask.element_size() != 4 or col_mask.numel() < kept_map_words(K) or not col_mask.is_contiguous():
-            raise RuntimeError("QuantFused: col_mask must be the kept outlier map of K columns (bit words, count word, pad, K 16-bit positions)")
+            raise RuntimeError("QuantFused: col_mask must be the kept outlier map of K columns (bit words, count word, pad, K 16-bit AND-masks)")
         _capi.call("mixq_quant_fused_masked", xp, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K,
                    ldx, ldo, bit, float(sigma), fmt, _stream())
     else:
@@ -877,7 +877,7 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
         x_out, xop, ldxo, ip = None, None, 0, None
     if col_mask is not None and n:
         if col_mask.element_size() != 4 or col_mask.numel() < kept_map_words(K) or not col_mask.is_contiguous():
-            raise RuntimeError("RMSNormQuantFused: col_mask must be the kept outlier map of K columns (bit words, count word, pad, K 16-bit positions)")
+            raise RuntimeError("RMSNormQuantFused: col_mask must be the kept outlier map of K columns (bit words, count word, pad, K 16-bit AND-masks)")
         _capi.call("mixq_rmsnorm_quant_fused_masked", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(),
                    q.data_ptr(), xop, _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), fmt, _stream())
     else:

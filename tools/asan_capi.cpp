@@ -37,8 +37,8 @@ static float h2f(uint16_t b) { _Float16 h; memcpy(&h, &b, 2); return static_cast
 static std::vector<uint32_t> kept_map(const std::vector<int32_t>& ind, int n, int K) {
     const int W = (K + 31) / 32, head = (W + 1 + 3) / 4 * 4;
     std::vector<uint32_t> m(head + (K + 7) / 8 * 4, 0u);
-    std::vector<uint16_t> pos((K + 7) / 8 * 8, 0xffffu);
-    for (int j = 0; j < n; ++j) { m[ind[j] >> 5] |= 1u << (ind[j] & 31); pos[ind[j]] = static_cast<uint16_t>(j); }
+    std::vector<uint16_t> pos((K + 7) / 8 * 8, 0xffffu);                       // per-column AND-masks: 0 for an outlier column
+    for (int j = 0; j < n; ++j) { m[ind[j] >> 5] |= 1u << (ind[j] & 31); pos[ind[j]] = 0; }
     m[W] = static_cast<uint32_t>(n);
     memcpy(m.data() + head, pos.data(), pos.size() * 2);
     return m;
