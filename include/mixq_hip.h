@@ -319,8 +319,17 @@ int mixq_gemm_set_workspace(void* ws, long long bytes);
  * description.  Every configuration of the product library computes the same (correct) result; the ablation forms used for
  * tuning, the in-kernel timeline stamps (mixq_gemm_set_trace), the forced tile-order group (mixq_gemm_set_krot) and the quantise kernel's
  * timing probes (mixq_quant_set_config >= 100) exist only in the -DMIXQ_TUNING build (`make -C mixq_amd/csrc tuning` ->
- * libmixq_hip_tuning.so, loaded by the tools/ scripts): in the product library those calls return MIXQ_EINVAL. */
+ * libmixq_hip_tuning.so, loaded by the tools/ scripts): in the product library those calls return MIXQ_EINVAL.
+ * cfg = -2: automatic, but always ONE launch - without the N split described at mixq_gemm_pick_split (its A/B partner). */
 int mixq_gemm_set_config(int cfg);
+/* The N split of the automatic choice.  A launch of T tiles on the device's 256 CUs takes ceil(T / 256) rounds of the tile's time
+ * whatever the last round holds (4096 x 11008 x 4096 on 128 x 256 tiles: 1376 tiles = 5.4 rounds, paid as 6).  With fragment-order
+ * weights (MIXQ_FMT_F16X64 / MIXQ_FMT_F6X128) and no forced configuration the fused GEMMs then run TWO launches over disjoint ranges of
+ * the weight rows (output columns): the picked tiling over the columns of its full rounds, the tiling priced cheapest over the rest -
+ * same weight image, same Y, no partial tile through memory, bit-identical results (profiles/r05_prefill_sweep.txt: 4-8 % at the
+ * shapes it applies to).  Returns 1 and writes the first range's width and the second tiling's id when (M, N, K, bit, fmt) is split,
+ * else 0. */
+int mixq_gemm_pick_split(int M, int N, int K, int bit, int fmt, int* n1, int* cfg2);
 /* Launch geometry of the extract + scale + quantise pass (mixq_quant_fused / mixq_find_row_scale): -1 automatic, 0 the
  * one-row-per-256-thread-workgroup kernel, 1..9 (threads per row, rows per workgroup) = (64,1) (64,2) (64,4) (128,1)
  * (128,2) (256,1) (256,2) (512,1) (512,2).  Every geometry produces identical bytes.  Per device, like mixq_gemm_set_config. */

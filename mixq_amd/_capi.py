@@ -80,6 +80,7 @@ SIGNATURES = {
     "mixq_gemm_config_name": [_I, C.c_char_p, _I],
     "mixq_gemm_pick_config": [_I, _I, _I, _I],
     "mixq_gemm_pick_config_fmt": [_I, _I, _I, _I, _I],
+    "mixq_gemm_pick_split": [_I, _I, _I, _I, _I, _P, _P],
     "mixq_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "mixq_rmsnorm_quant_fused": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
     "mixq_rmsnorm_quant_fused_masked": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
@@ -190,6 +191,17 @@ def w8a16_config_names():
         lib.mixq_gemm_w8a16_config_name(i, buf, 64)
         out.append(buf.value.decode())
     return out
+
+
+def gemm_split_plan(M, N, K, bit=8, fmt=2):
+    """(width of the first launch's column range, name of the second launch's tiling) when the automatic choice splits (M, N, K) along N
+    (include/mixq_hip.h: mixq_gemm_pick_split), else None."""
+    lib = load()
+    n1, c2 = C.c_int(0), C.c_int(-1)
+    rc = lib.mixq_gemm_pick_split(M, N, K, bit, fmt, C.byref(n1), C.byref(c2))
+    if rc < 0:
+        raise RuntimeError(f"mixq_gemm_pick_split: status {rc}")
+    return (n1.value, gemm_config_names()[c2.value]) if rc == 1 else None
 
 
 def gemm_config_names():

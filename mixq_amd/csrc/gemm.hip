@@ -853,15 +853,10 @@ int pick_stream_k(int M, int N, int KB) {
     return 3;                                            // sk128x128_w2x2_s5
 }
 
-// Prefill rule (M >= 1024, int8, fragment-order weights): rounds over the 256 CUs of the 256 x 256 tiling, at 2 x 0.9 of a 128 x 256
-// round each (measured: 4096 x 11008 x 4096 181 vs 200 us, 8192 x 11008 358 vs 368, 4096 x 4096 69.6 vs 72.6; 2048 x 11008 111 vs 103 and
-// 2048 x 28672 x 8192 433 vs 411 the other way - there the 128 x 256 tile count fills its last round better)
-constexpr int LDS256 = 13;                           // 256x256_w4x2_s5_l0
-bool prefill_prefers_lds256(int M, int N) {
-    if (M < 1024) return false;
-    const int t256 = cdiv(M, 256) * cdiv(N, 256), t128 = cdiv(M, 128) * cdiv(N, 256);
-    return t256 >= 200 && 1.8 * cdiv(t256, 256) < 1.0 * cdiv(t128, 256);
-}
+// (Rounds 3-4 preferred this file's 256 x 256 tiling - cfg LDS256 - at prefill sizes; since the weights-in-registers kernels got the
+// panel epilogue, 128 x 256 is ahead of it at every prefill shape measured, by 2.7-13 %: profiles/r05_prefill_sweep.txt.  The tiling stays
+// selectable by configuration and reads the fragment-order weight image through a remapped DMA source.)
+// (cfg 13: 256x256_w4x2_s5_l0)
 
 int launch_gemm(GemmArgs& a, int mode, hipStream_t st, int cfg = -1) {
     const bool packed = a.x_packed && a.w_packed;
@@ -921,6 +916,13 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
         if (g_forced >= 0 && g_forced < wr0) return MIXQ_EINVAL;                // only the weights-in-registers kernels read this format
         const int c = g_forced >= wr0 ? g_forced - wr0 : (pair ? mixq_wr_pick_pair(6, M, N, KB) : mixq_wr_pick(6, M, N, KB));
         if (pair && !mixq_wr_has_pair(6, c)) return MIXQ_EINVAL;
+        int n1 = 0, c2 = -1;
+        if (g_forced == -1 && !pair && mixq_wr_split(6, M, N, KB, c, &n1, &c2)) {   // (a partial last round of tiles: two launches, as for int8 below)
+            if (int rc = mixq_wr_launch(c, 6, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+                                        ldy, M, N, KB, act, g_trace, mixq_stream(stream), nullptr, nullptr, 0, n1)) return rc;
+            return mixq_wr_launch(c2, 6, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+                                  ldy, M, N, KB, act, nullptr, mixq_stream(stream), nullptr, nullptr, n1, N - n1);
+        }
         return mixq_wr_launch(c, 6, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                               ldy, M, N, KB, act, g_trace, mixq_stream(stream), nullptr, nullptr);
     }
@@ -936,9 +938,8 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
         }
         if (g_forced == skinny_id && !pair) return MIXQ_EINVAL;
     }
-    // fragment-order weights: the weights-in-registers kernels (gemm_wreg.hip) - except at prefill sizes, where the LDS-staged
-    // 256 x 256 tiling of this file (8 waves of 64 x 128, cfg LDS256) is 2.5-9 % ahead once its tile count quantises no worse
-    // (profiles/r03_prefill_ab.txt); it reads the same F16X64 weight image through a remapped DMA source
+    // fragment-order weights: the weights-in-registers kernels (gemm_wreg.hip); a forced tiling of this file reads the same F16X64 weight
+    // image through a remapped DMA source
     if (wf16) {
         int c;
         if (pair) {
@@ -947,13 +948,23 @@ int gemm_fused_common(const void* q_x, const void* q_w, const uint16_t* x_scale,
         }
         else if (g_forced >= wr0) c = g_forced - wr0;
         else if (g_forced >= NUM_CFGS) return MIXQ_EINVAL;               // a stream-K form was forced: it takes P16X64 weights only
-        else if (g_forced >= 0 || (bit == 8 && !row_amax && prefill_prefers_lds256(M, N))) {
+        else if (g_forced >= 0) {                                          // a tiling of this file, forced: it reads the fragment-order image too
             if (row_amax) return MIXQ_ESHAPE;
             a.w_packed = 1; a.w_f16 = 1;
-            return launch_gemm(a, bit == 8 ? 0 : 1, mixq_stream(stream), g_forced >= 0 ? g_forced : LDS256);
+            return launch_gemm(a, bit == 8 ? 0 : 1, mixq_stream(stream), g_forced);
         }
         else if (bit == 8 && !row_amax && mixq_wr_ksplit_pays(M, N, KB)) c = mixq_wr_ksplit_config();   // long K, few tiles: two workgroups per tile
-        else c = mixq_wr_pick(bit, M, N, KB);
+        else {
+            c = mixq_wr_pick(bit, M, N, KB);
+            // a partial last round of tiles: the full rounds' columns with this tiling, the rest with the cheapest one, two launches
+            int n1 = 0, c2 = -1;
+            if (g_forced == -1 && bit == 8 && mixq_wr_split(8, M, N, KB, c, &n1, &c2)) {
+                if (int rc = mixq_wr_launch(c, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+                                            ldy, M, N, KB, act, g_trace, mixq_stream(stream), row_amax, amax_mask, 0, n1)) return rc;
+                return mixq_wr_launch(c2, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
+                                      ldy, M, N, KB, act, nullptr, mixq_stream(stream), row_amax, amax_mask, n1, N - n1);
+            }
+        }
         return mixq_wr_launch(c, bit, q_x, q_w, x_scale, scale_col, x_out, ldxo, w_out, ldwo, n_out, n_out_dev, addend, lda, bias, y,
                               ldy, M, N, KB, act, g_trace, mixq_stream(stream), row_amax, amax_mask);
     }
@@ -1001,7 +1012,6 @@ extern "C" int mixq_gemm_amax_supported(int M, int N, int K, int layout)
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || !(layout & MIXQ_W_F16X64) || !(layout & MIXQ_X_PACKED)) return 0;
     const bool wide_wr = N >= 8192;
     if (!wide_wr && mixq_skinny_applies(8, M, N, K, true, true)) return 0;
-    if (prefill_prefers_lds256(M, N)) return 0;                  // the LDS-staged prefill tiling is worth more than the side output
     return 1;
 }
 
@@ -1051,7 +1061,7 @@ extern "C" int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_sca
 // weights-in-registers tilings of gemm_wreg.hip (MIXQ_FMT_F16X64 operands only).
 static int total_configs() { return NUM_CFGS + mixq_sk_num_configs() + 1 + mixq_wr_num_configs(); }
 extern "C" int mixq_gemm_set_config(int cfg) {
-    if (cfg < -1 || cfg >= total_configs()) return MIXQ_EINVAL;
+    if (cfg < -2 || cfg >= total_configs()) return MIXQ_EINVAL;            // (-1: automatic; -2: automatic without the N split - the A/B partner of tools/prefill_sweep.py)
     g_forced_cfg.set(cfg);
     return MIXQ_OK;
 }
@@ -1079,6 +1089,17 @@ extern "C" int mixq_gemm_pick_config(int M, int N, int K, int bit) {
 }
 // The config the automatic choice runs for weights in the packed format `fmt` (MIXQ_FMT_P16X64 / MIXQ_FMT_F16X64; the
 // activations are P16X64 either way).
+extern "C" int mixq_gemm_pick_split(int M, int N, int K, int bit, int fmt, int* n1, int* cfg2) {
+    if ((bit != 8 && bit != 4) || M <= 0 || N <= 0 || K <= 0 || !n1 || !cfg2) return MIXQ_EINVAL;
+    const bool f6 = fmt == MIXQ_FMT_F6X128 && bit == 4;
+    if (!f6 && !(fmt == MIXQ_FMT_F16X64 && bit == 8)) return 0;
+    const int KB = bit == 8 ? K : K / 2, wbit = f6 ? 6 : 8;
+    if (!f6 && ((N < 8192 && mixq_skinny_applies(8, M, N, KB, true, true)) || mixq_wr_ksplit_pays(M, N, KB))) return 0;
+    int c2 = -1;
+    if (!mixq_wr_split(wbit, M, N, KB, mixq_wr_pick(wbit, M, N, KB), n1, &c2)) return 0;
+    *cfg2 = NUM_CFGS + mixq_sk_num_configs() + 1 + c2;
+    return 1;
+}
 extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) {
     if (M <= 0 || N <= 0 || K <= 0 || (bit != 4 && bit != 8)) return MIXQ_EINVAL;
     const int KB = bit == 8 ? K : K / 2;
@@ -1086,8 +1107,7 @@ extern "C" int mixq_gemm_pick_config_fmt(int M, int N, int K, int bit, int fmt) 
     if (fmt == MIXQ_FMT_F6X128) return bit == 4 ? dec + 1 + mixq_wr_pick(6, M, N, KB) : MIXQ_EINVAL;   // (FP6-coded operands: the weights-in-registers kernels only)
     const bool wide_wr = fmt == MIXQ_FMT_F16X64 && bit == 8 && N >= 8192;                 // as in gemm_fused_common
     if (!wide_wr && fmt != MIXQ_FMT_PLAIN && mixq_skinny_applies(bit, M, N, KB, true, true)) return dec;
-    if (fmt == MIXQ_FMT_F16X64) return (bit == 8 && prefill_prefers_lds256(M, N)) ? LDS256
-                                     : dec + 1 + ((bit == 8 && mixq_wr_ksplit_pays(M, N, KB)) ? mixq_wr_ksplit_config() : mixq_wr_pick(bit, M, N, KB));
+    if (fmt == MIXQ_FMT_F16X64) return dec + 1 + ((bit == 8 && mixq_wr_ksplit_pays(M, N, KB)) ? mixq_wr_ksplit_config() : mixq_wr_pick(bit, M, N, KB));
     return mixq_gemm_pick_config(M, N, K, bit);
 }
 

@@ -11,7 +11,11 @@ int mixq_wr_pick(int bit, int M, int N, int KB);
 int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
-                   unsigned long long* trace, hipStream_t st, uint32_t* row_amax = nullptr, const uint32_t* amax_mask = nullptr);
+                   unsigned long long* trace, hipStream_t st, uint32_t* row_amax = nullptr, const uint32_t* amax_mask = nullptr,
+                   int n_begin = 0, int n_cols = -1);     // the launch covers the weight rows [n_begin, n_begin + n_cols) (default: all from n_begin)
+// N split for a partial last round of tiles: true when running tiling c over the first *n1 weight rows and tiling *c2 over the rest is priced
+// cheaper than one launch of c (gemm_wreg.hip)
+bool mixq_wr_split(int bit, int M, int N, int KB, int c, int* n1, int* c2);
 // pairwise split-K form (two workgroups per 128 x 128 tile, half of K each, int32 hand-off through the registered workspace)
 int mixq_wr_ksplit_config();                 // its configuration index
 int mixq_wr_ksplit_ok(int M, int N, int KB); // MIXQ_OK when it can run this problem on the current device (workspace, residency), else the reason

@@ -45,6 +45,7 @@ struct WrArgs {
     int tiles_m, tiles_n;
     int xblocks, wblocks;                             // 16-row blocks per k-step of each operand
     int gm;                                           // M tiles per group of the tile order (see the tile map in the kernel)
+    int n_begin;                                      // first weight row (output column) of this launch: tiles_n tiles of BN rows from here (N split)
     // reciprocals for the tile map's two divisions (q = mulhi(n, m), exact for n d < 2^32, m = floor(2^32 / d) + 1; 0 stands for d = 1):
     // by gm x tiles_n, by gm, by the last group's size - three run-time divisions (~25 dependent scalar instructions each, through the
     // float reciprocal) stood in front of every wave's first operand request
@@ -185,7 +186,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // one scalar load per use site with a wait behind each (nine dependent round trips to a cold scalar cache in front of the first
     // operand request: ~0.3 us of the 1.0 us between entry and the first k-step); named together here they become a few wide loads and ONE wait.
     asm volatile("" :: "s"(a.qx), "s"(a.qw), "s"(a.sx), "s"(a.sw), "s"(a.M), "s"(a.N), "s"(a.KB), "s"(a.tiles_m), "s"(a.tiles_n),
-                 "s"(a.xblocks), "s"(a.wblocks), "s"(a.gm), "s"(a.n_out_dev), "s"(a.bias), "s"(a.n_out), "s"(a.mg_group), "s"(a.mg_gm),
+                 "s"(a.xblocks), "s"(a.wblocks), "s"(a.gm), "s"(a.n_begin), "s"(a.n_out_dev), "s"(a.bias), "s"(a.n_out), "s"(a.mg_group), "s"(a.mg_gm),
                  "s"(a.mg_last), "s"(a.ldy), "s"(a.y));
     const bool staged = (((PAIR ? a.N >> 1 : a.N) & 7) == 0) && ((a.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
 
@@ -218,7 +219,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         const int r = tile - grp * per_group;
         tn = fdiv(r, last ? a.mg_last : a.mg_gm); tm = first_m + (r - tn * gsz);
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN + a.n_begin;                            // (n_begin: this launch covers the weight rows from there - mixq_wr_split)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
     const int nk_all = a.KB >> 6;
@@ -1913,13 +1914,62 @@ bool mixq_wr_ksplit_pays(int M, int N, int KB)
     return t_split < 0.97 * best;
 }
 
+// N split for the last, partial round of tiles.  A launch of T tiles on 256 CUs takes ceil(T / 256) rounds of the tile's time whatever the
+// last round holds: 4096 x 11008 x 4096 on 128 x 256 tiles is 1376 tiles = 5.4 rounds and pays for 6 (profiles/r05_prefill_sweep.txt: 179 us
+// where the vendor's stream-K schedule takes 176).  The same kernels cover it in TWO launches over disjoint ranges of the weight rows: the
+// picked tiling over the columns of its FULL rounds, then whatever tiling the model prices cheapest over the rest (WrArgs::n_begin: the
+// tile map of a launch starts at that row; same image, same Y, no partial tile through memory, results bit-identical).  It pays when the
+// remainder's cheaper tiles save more than the second launch's floor (2.2 us).
+static double wr_tile_us(int bit, int cfg, int KB)
+{
+    static const struct { int cfg; float tk, fixed; } c8[] = {
+        {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f}, {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
+    static const struct { int cfg; float tk, fixed; } c6[] = {{0, 0.37f, 10.0f}, {4, 0.304f, 7.5f}, {6, 0.23f, 5.1f}, {7, 0.29f, 5.9f}, {8, 0.35f, 6.5f}};
+    const int nk = KB >> 6;
+    if (bit == 6) { for (const auto& c : c6) if (c.cfg == cfg) return nk * static_cast<double>(c.tk) + c.fixed; }
+    else          { for (const auto& c : c8) if (c.cfg == cfg) return nk * static_cast<double>(c.tk) + c.fixed; }
+    return -1.0;
+}
+bool mixq_wr_split(int bit, int M, int N, int KB, int c, int* n1, int* c2)
+{
+    if (c < 0 || c >= NUM_WR || c == WR_SMALL || c == WR_KSPLIT || (bit != 8 && bit != 6) || M <= 32) return false;
+    const WrConfig& g = g_wr[c];
+    const int bm = g.mb * 16, bn = g.wnb * 64, tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn), tiles = tiles_m * tiles_n;
+    const int full = tiles / 256;
+    if (full < 1 || tiles % 256 == 0) return false;
+    const int tn1 = full * 256 / tiles_m;                                    // column tiles whose tiles fit the full rounds
+    if (tn1 <= 0 || tn1 >= tiles_n) return false;
+    const double T = wr_tile_us(bit, c, KB);
+    if (T <= 0) return false;
+    const int nrest = N - tn1 * bn;
+    static const int cand8[] = {0, 4, 5, 6, 7, 8, 9, 10}, cand6[] = {0, 4, 6, 7, 8};
+    const int* cand = bit == 6 ? cand6 : cand8;
+    const int ncand = bit == 6 ? 5 : 8;
+    double best = 1e30; int bc = -1;
+    for (int qi = 0; qi < ncand; ++qi) {
+        const int q = cand[qi];
+        const WrConfig& h = g_wr[q];
+        if (bit == 6 && !h.k6) continue;
+        const int t2 = cdiv(M, h.mb * 16) * cdiv(nrest, h.wnb * 64);
+        const double t = cdiv(t2, 256) * wr_tile_us(bit, q, KB);
+        if (t < best) { best = t; bc = q; }
+    }
+    if (bc < 0) return false;
+    const double t_single = (full + 1) * T, t_split = cdiv(tn1 * tiles_m, 256) * T + best + 2.2;
+    if (t_split >= 0.975 * t_single) return false;
+    *n1 = tn1 * bn; *c2 = bc;
+    return true;
+}
+
 // bit: 8, 4 (nibble-packed operands) or 6 (int4 as FP6 codes, MIXQ_FMT_F6X128 operands; KB is K / 2 as for bit 4)
 int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
-                   unsigned long long* trace, hipStream_t st, uint32_t* row_amax, const uint32_t* amax_mask)
+                   unsigned long long* trace, hipStream_t st, uint32_t* row_amax, const uint32_t* amax_mask, int n_begin, int n_cols)
 {
     if (c < 0 || c >= NUM_WR) return MIXQ_EINVAL;
+    if (n_cols < 0) n_cols = N - n_begin;                                   // (the default: every weight row from n_begin on)
+    if (n_begin < 0 || (n_begin & 63) || n_cols <= 0 || n_begin + n_cols > N) return MIXQ_EINVAL;
     const bool pair = act == MIXQ_ACT_SILU_PAIR;                            // (the paired epilogue is a kernel form, not a run-time switch)
     if (pair && ((bit != 8 && bit != 6) || (N & 3) || addend)) return MIXQ_EINVAL;
     const WrConfig& g = g_wr[c];
@@ -1930,7 +1980,8 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     a.addend = addend; a.bias = bias; a.y = y;
     a.M = M; a.N = N; a.KB = KB; a.ldxo = ldxo; a.ldwo = ldwo; a.n_out = n_out; a.lda = lda; a.ldy = ldy; a.act = act;
     const int bm = g.mb * 16, bn = g.wnb * 64;
-    a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(N, bn);
+    a.tiles_m = cdiv(M, bm); a.tiles_n = cdiv(n_cols, bn); a.n_begin = n_begin;
+    if (n_begin + n_cols < N && n_cols % bn) return MIXQ_EINVAL;           // (only the launch that ends at N may hold a partial tile)
     a.xblocks = (M + 15) >> 4; a.wblocks = (N + 15) >> 4;
     {
         const int forced_gm = g_wr_krot >> 16;                               // (tuning build: mixq_gemm_set_krot(gm << 16 | krot); 0 = automatic)
@@ -1949,6 +2000,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     if (!k) return MIXQ_EINVAL;
     int units = a.tiles_m * a.tiles_n;
     if (c == WR_KSPLIT) {
+        if (n_begin || n_cols != N) return MIXQ_EINVAL;
         if (int rc = mixq_wr_ksplit_ok(M, N, KB)) return rc;
         void* ws; size_t bytes, fb;
         mixq_ws_get(&ws, &bytes, &fb);

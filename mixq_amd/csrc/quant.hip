@@ -341,6 +341,18 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
     }
+    if constexpr (KEPT) {
+        // the x_out row, requested from the image as soon as the barrier of the maximum has ordered it: its LDS round trip and stores run
+        // under the quantise arithmetic instead of behind the last quantised store
+        if (x_out && !(dbg & 8)) {
+            uint16_t* orow = x_out + static_cast<size_t>(row) * ldo;
+            if (kept) {                                             // x_out[row][j] = element ind[j] of the row's image; zeros behind the live columns
+                for (int j = t; j < ldo; j += TPR) orow[j] = j < n ? rowimg[j == t ? gi : ind[j]] : static_cast<uint16_t>(0);
+            } else {                                                // (the slow form stored the live columns already)
+                for (int j = (have_out ? n : 0) + t; j < ldo; j += TPR) orow[j] = 0;
+            }
+        }
+    }
     void* qrow = fmt ? q : static_cast<void*>(static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1)));
     if constexpr (BIT == 4 && NCH >= 2) {
         if (pairs) {                                               // (K % 128 == 0: a pair is inside the row or entirely outside)
@@ -399,17 +411,7 @@ __global__ __launch_bounds__(TPR * RPB) void quant_rows2_kernel(
             if (c < nchunk) quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
         }
     }
-    if constexpr (KEPT) {
-        if (x_out && !(dbg & 8)) {
-            uint16_t* orow = x_out + static_cast<size_t>(row) * ldo;
-            if (kept) {                                             // x_out[row][j] = element ind[j] of the row's image; zeros behind the live columns
-                for (int j = t; j < ldo; j += TPR) orow[j] = j < n ? rowimg[j == t ? gi : ind[j]] : static_cast<uint16_t>(0);
-            } else {                                                // (the slow form stored the live columns already)
-                for (int j = (have_out ? n : 0) + t; j < ldo; j += TPR) orow[j] = 0;
-            }
-        }
-        return;
-    }
+    if constexpr (KEPT) return;                                     // (x_out left in front of the quantise arithmetic)
     if (have_out) {
 #pragma unroll
         for (int g = 0; g < GQ; ++g) {
@@ -447,14 +449,12 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(       // (parameter o
     const int mcount = col_mask ? static_cast<int>(col_mask[mask_words]) : 0;
     const int gi = (ind && t < n_cap) ? ind[t] : 0;                         // lane j's column: x_out[row][j] = element ind[j] of the row's image
     uint4 keep[NCH], pg[NCH];
-    uint32_t m8[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = t + i * TPR;
         const bool in = c < nchunk;
         keep[i] = in ? xv[c] : make_uint4(0, 0, 0, 0);
         pg[i] = (in && pv) ? pv[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
-        m8[i] = (in && col_mask) ? ((col_mask[c >> 2] >> ((c & 3) * 8)) & 0xffu) : 0u;
     }
     int n = n_cap;
     if (n_dev) { const int nd = *n_dev; n = nd < n_cap ? nd : n_cap; }
@@ -486,19 +486,19 @@ __global__ __launch_bounds__(TPR) void quant_known_kernel(       // (parameter o
         x_scale[row] = sh;
         if (flag && s > thr_scale) atomicOr(flag, 1);
     }
+    // kept route: the x_out row from the image the barrier has just ordered - its LDS round trip and stores run under the quantise arithmetic
+    if (kept && x_out) for (int j = t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = j < n ? kimg[j == t ? gi : ind[j]] : static_cast<uint16_t>(0);
     void* qrow = fmt ? q : static_cast<void*>(static_cast<char*>(q) + static_cast<size_t>(row) * (BIT == 8 ? K : (K >> 1)));
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = t + i * TPR;
         if (c < nchunk) {
-            if (!kept) (void)amax8_masked(keep[i], m8[i], 0u);            // zero the outlier columns of the chunk (whatever the load saw there)
+            // (without a usable map: zero the outlier columns of the chunk, whatever the load saw there, from the map's bit words)
+            if (!kept && col_mask) (void)amax8_masked(keep[i], (col_mask[c >> 2] >> ((c & 3) * 8)) & 0xffu, 0u);
             quant_store8<BIT>(keep[i], s, rs, qrow, c, row, rows16, fmt);
         }
     }
-    if (kept) {
-        if (x_out) for (int j = t; j < ldo; j += TPR) x_out[static_cast<size_t>(row) * ldo + j] = j < n ? kimg[j == t ? gi : ind[j]] : static_cast<uint16_t>(0);
-        return;
-    }
+    if (kept) return;                                                     // (x_out left in front of the quantise arithmetic)
     if (have_out) {
 #pragma unroll
         for (int g = 0; g < GQ; ++g) {

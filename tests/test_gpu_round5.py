@@ -8,7 +8,7 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mixq_amd import mixlib  # noqa: E402
+from mixq_amd import _capi, mixlib  # noqa: E402
 from mixq_amd import linear as L  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -109,3 +109,88 @@ def test_fused_norm_kept_map_route_is_byte_identical(bit, fmt, M, K, ncols, cap)
         outs.append((q.clone(), sx, xo[:, :ncols].clone(), out))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+# ---- N split of a partial last round of tiles (include/mixq_hip.h: mixq_gemm_pick_split) ---------------------------------------------------
+def _split_operands(M, N, K, bit, n_out, seed):
+    g = torch.Generator().manual_seed(seed)
+    if bit == 8:
+        qx = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8)
+        qw = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8)
+        xp, wp = mixlib.PackOperand(qx.to(DEV), 1), mixlib.PackOperand(qw.to(DEV), 2)
+    else:
+        from mixq_amd.linear import pack_to_i4
+        qx = pack_to_i4(torch.randint(-7, 8, (M, K), generator=g, dtype=torch.int8))
+        qw = pack_to_i4(torch.randint(-8, 8, (N, K), generator=g, dtype=torch.int8))
+        xp, wp = mixlib.PackOperand(qx.to(DEV), 4), mixlib.PackOperand(qw.to(DEV), 3)
+    sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(DEV)
+    sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(DEV)
+    xo = wo = None
+    if n_out:
+        pad = (n_out + 15) // 16 * 16
+        xo = torch.zeros((M, pad), dtype=torch.float16)
+        wo = torch.zeros((N, pad), dtype=torch.float16)
+        xo[:, :n_out] = torch.randn(M, n_out, generator=g).half() * 8
+        wo[:, :n_out] = torch.randn(N, n_out, generator=g).half() * 0.02
+        xo, wo = xo.to(DEV)[:, :n_out], wo.to(DEV)[:, :n_out]
+    bias = torch.randn(N, generator=g).half().to(DEV)
+    return xp, wp, sx, sw, xo, wo, bias
+
+
+@pytest.mark.parametrize("M,N,K,bit,n_out,act", [(4096, 11008, 4096, 8, 41, 0), (2048, 14336, 4096, 8, 0, 1), (2048, 5120, 13824, 8, 138, 0),
+                                                 (2048, 14336, 4096, 4, 128, 0), (4096, 11008, 4096, 4, 128, 1)])
+def test_the_n_split_of_a_partial_last_round_is_bit_identical_to_one_launch(M, N, K, bit, n_out, act):
+    """The automatic choice at these shapes runs two launches over disjoint column ranges (the picked tiling over its full rounds'
+    columns, a cheaper tiling over the rest); mixq_gemm_set_config(-2) runs the same problem as ONE launch: identical bits, with the fp16
+    outlier tail, bias and the SiLU epilogue, int8 and the FP6-coded 4-bit form."""
+    lib = _capi.load()
+    fmt = 2 if bit == 8 else 3
+    plan = _capi.gemm_split_plan(M, N, K, bit, fmt)
+    if bit == 8:
+        assert plan is not None and 0 < plan[0] < N and plan[0] % 64 == 0, plan
+    if plan is None:
+        pytest.skip("the model prices no split for this shape in this form")
+    xp, wp, sx, sw, xo, wo, bias = _split_operands(M, N, K, bit, n_out, seed=M + N + K + bit)
+    outs = []
+    try:
+        for cfg in (-2, -1):
+            assert lib.mixq_gemm_set_config(cfg) == 0
+            y = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+            mixlib.FusedLinear(xp, wp, sx, sw, xo, wo, n_out, bias, M, N, K, bit=bit, act=act, out=y)
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        lib.mixq_gemm_set_config(-1)
+    assert not torch.isnan(outs[1]).any()
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_the_n_split_keeps_the_row_maximum_side_output():
+    """mixq_gemm_i8_fused_amax over a split problem: the per-row maxima (atomic max of bit patterns over the unmasked columns) and Y are the
+    ones of the single launch."""
+    lib = _capi.load()
+    M, N, K = 2048, 14336, 4096
+    assert _capi.gemm_split_plan(M, N, K, 8, 2) is not None
+    xp, wp, sx, sw, xo, wo, bias = _split_operands(M, N, K, 8, 0, seed=77)
+    ind = torch.randperm(N, generator=torch.Generator().manual_seed(5))[:143].to(torch.int32).to(DEV)
+    mask = L.kept_outlier_map(ind, N)
+    outs = []
+    try:
+        for cfg in (-2, -1):
+            assert lib.mixq_gemm_set_config(cfg) == 0
+            amax = torch.zeros(M, dtype=torch.int32, device=DEV)
+            y = mixlib.FusedLinear(xp, wp, sx, sw, None, None, 0, bias, M, N, K, bit=8, act=1, row_amax=amax, col_mask=mask)
+            torch.cuda.synchronize()
+            outs.append((y, amax))
+    finally:
+        lib.mixq_gemm_set_config(-1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert int(outs[1][1].max()) > 0
+
+
+def test_split_plan_is_off_for_one_round_and_for_forced_tilings():
+    assert _capi.gemm_split_plan(512, 11008, 4096, 8, 2) is None            # 232 tiles: one round
+    assert _capi.gemm_split_plan(4096, 12288, 4096, 8, 2) is None           # 1536 tiles of 128 x 256: six full rounds
+    assert _capi.gemm_split_plan(16, 11008, 4096, 8, 2) is None             # a weight stream
+    n1, name = _capi.gemm_split_plan(4096, 11008, 4096, 8, 2)
+    assert n1 == 10240 and name.startswith("wr")                            # five full rounds of 128 x 256 tiles, the last 768 columns apart
