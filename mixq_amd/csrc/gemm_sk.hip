@@ -25,7 +25,12 @@
 #include <string.h>
 #include <type_traits>
 
+// Round 5: the kernels of this file are compiled into the TUNING build only (make tuning -> libmixq_hip_tuning.so).  The automatic choice
+// never picked them since round 2, and the one place where a stream-K schedule had something to offer - the partial last round of tiles at
+// prefill sizes - is covered by the N split of the data-parallel kernels (gemm_wreg.hip: mixq_wr_split; profiles/r05_prefill_sweep.txt).
+// The product library keeps the workspace registration (a no-op there) so that callers of the C ABI need not care which build they link.
 namespace {
+#ifdef MIXQ_TUNING
 
 struct SkArgs {
     const uint8_t* qx;  const uint8_t* qw;
@@ -436,6 +441,7 @@ const SkConfig g_sk[] = {
 constexpr int NUM_SK = sizeof(g_sk) / sizeof(g_sk[0]);
 
 // per-device state (one process may drive several GPUs): the registered workspace and the CU count of the CURRENT device
+#endif  // MIXQ_TUNING
 constexpr int SK_MAX_DEV = 64;
 struct SkDev { void* ws; size_t bytes; int num_cu; };
 SkDev g_dev[SK_MAX_DEV] = {};
@@ -447,14 +453,14 @@ SkDev* sk_dev() {
 
 }  // namespace
 
-int mixq_sk_num_configs() { return NUM_SK; }
-const char* mixq_sk_config_name(int c) { return (c >= 0 && c < NUM_SK) ? g_sk[c].name : ""; }
-
 // Workspace layout: SK_FLAG_BYTES of int32 flags (zero on entry; every launch leaves them zero), then [G slots][BM*BN int32].  The
 // flags sit at a FIXED place: behind the slots their offset would depend on the configuration's tile size, and one configuration's
 // partial tiles would land on another one's flag words (a finisher of the next launch of the smaller tiling then reads a slot before
 // its contributor wrote it).
 constexpr size_t SK_FLAG_BYTES = 4096;                   // up to 1024 workgroups
+#ifdef MIXQ_TUNING
+int mixq_sk_num_configs() { return NUM_SK; }
+const char* mixq_sk_config_name(int c) { return (c >= 0 && c < NUM_SK) ? g_sk[c].name : ""; }
 size_t mixq_sk_workspace_need(int c, int G) { return SK_FLAG_BYTES + static_cast<size_t>(G) * g_sk[c].bm * g_sk[c].bn * 4; }
 
 bool mixq_sk_usable(int c) {
@@ -467,13 +473,6 @@ bool mixq_sk_usable(int c) {
         d->num_cu = p.multiProcessorCount;
     }
     return d->num_cu > 0 && mixq_sk_workspace_need(c, d->num_cu) <= d->bytes;
-}
-
-bool mixq_ws_get(void** ws, size_t* bytes, size_t* flag_bytes) {
-    SkDev* d = sk_dev();
-    if (!d || !d->ws) return false;
-    *ws = d->ws; *bytes = d->bytes; *flag_bytes = SK_FLAG_BYTES;
-    return true;
 }
 
 int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
@@ -506,6 +505,21 @@ int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     return mixq_launch_status();
 }
 
+#else
+int mixq_sk_num_configs() { return 0; }
+const char* mixq_sk_config_name(int) { return ""; }
+size_t mixq_sk_workspace_need(int, int) { return 0; }
+bool mixq_sk_usable(int) { return false; }
+int mixq_sk_launch(int, int, const void*, const void*, const uint16_t*, const uint16_t*, const uint16_t*, int, const uint16_t*, int, int, const int32_t*,
+                   const uint16_t*, int, const uint16_t*, uint16_t*, int, int, int, int, int, hipStream_t) { return MIXQ_EINVAL; }
+#endif
+bool mixq_ws_get(void** ws, size_t* bytes, size_t* flag_bytes) {
+    SkDev* d = sk_dev();
+    if (!d || !d->ws) return false;
+    *ws = d->ws; *bytes = d->bytes; *flag_bytes = SK_FLAG_BYTES;
+    return true;
+}
+
 extern "C" int mixq_gemm_set_workspace(void* ws, long long bytes)
 {
     if (bytes < 0 || (bytes > 0 && !ws)) return MIXQ_EINVAL;
@@ -518,8 +532,12 @@ extern "C" int mixq_gemm_set_workspace(void* ws, long long bytes)
 
 extern "C" long long mixq_gemm_workspace_bytes(void)
 {
+#ifdef MIXQ_TUNING
     // enough for every stream-K configuration on a 256-CU part: 256 slots of the largest tile + flags
     size_t need = 0;
     for (int c = 0; c < NUM_SK; ++c) { const size_t n = mixq_sk_workspace_need(c, 256); if (n > need) need = n; }
     return static_cast<long long>(need);
+#else
+    return 0;                                            // no form of the product library hands tiles through memory
+#endif
 }

@@ -1742,8 +1742,11 @@ const WrConfig g_wr[] = {
     // (round 4: with an FP6 form too - 12 stages of 3 KiB, weight ring 4 k-steps of 128 elements (10 k-steps: no faster - the loop's barrier per k-step is what a 2-MFMA k-step waits for) - so a 4-bit layer serves its small
     // batches from the ONE FP6 image it keeps; tools/time_w4_small_batch.py)
     MIXQ_WR6P(2, 1, 8, 6, 1, 12, 4, "32x64_s8_d6_l1"), // 14 (WR_SMALL)
-    MIXQ_WR(8, 2, 16, 4, 2, 50, "128x128_s16_d4_l2_k2"),   // 15 (WR_KSPLIT): two workgroups per tile, half of K each (pairwise split-K)
-#ifdef MIXQ_TUNING                                     // ablation forms (results are garbage by design): only in the tools build (make tuning)
+#ifdef MIXQ_TUNING                                     // only in the tools build (make tuning):
+    // 15 (WR_KSPLIT): two workgroups per tile, half of K each (pairwise split-K).  Correct, tested, and slower than the data-parallel tilings at
+    // every shape it was built for (32.6 vs 28.8 us at 11008 -> 4096, profiles/r03_splitk_ab.txt): round 5 moved it out of the product library
+    MIXQ_WR(8, 2, 16, 4, 2, 50, "128x128_s16_d4_l2_k2"),
+    // ablation forms (results are garbage by design)
     { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
     { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 2>, 8 },
     { "wr128x192_f6_abl3_mfma", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 3>, 8 },
@@ -1880,6 +1883,7 @@ int mixq_wr_ksplit_config() { return WR_KSPLIT; }
 // resident at once (2 x tiles <= CUs), the workspace registered with mixq_gemm_set_workspace must hold a flag word and an int32 slot per tile.
 int mixq_wr_ksplit_ok(int M, int N, int KB)
 {
+    if (WR_KSPLIT >= NUM_WR) return MIXQ_EINVAL;                            // (product library: the form is not compiled in)
     const WrConfig& g = g_wr[WR_KSPLIT];
     const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
     if ((KB >> 6) < 2) return MIXQ_ESHAPE;
