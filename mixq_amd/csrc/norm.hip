@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int NT = 256;
+typedef unsigned short us2n_t __attribute__((ext_vector_type(2)));
 
 // y = fp16( fp32(fp32(x * inv) * w) ): every product is rounded to fp32 before the next step.  Written with the _rn
 // intrinsics and an opaque barrier so the compiler cannot fold the last multiply and the conversion into one
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
         if (have_out && !kept) __syncthreads();
     }
 
-    float amax = 0.f;
+    uint32_t amax_acc = 0u;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + i * NT;
@@ -146,16 +147,19 @@ __global__ __launch_bounds__(NT) void rmsnorm_kernel(            // (parameter o
             }
             keep[i] = make_uint4(y[0], y[1], y[2], y[3]);
             if (kept) (void)kept_apply8(keep[i], pg[i], rowimg, c);        // a chunk with normalised outlier values -> the row's LDS image; zeroed in the chunk
+            // running maximum of |y| as packed fp16 bit patterns (finite halves: |a| < |b| <=> (a & 0x7fff) < (b & 0x7fff) as unsigned): one
+            // v_and + one v_pk_max_u16 per pair instead of two conversions and two maxima (the pass is issue- and latency-bound)
             const uint32_t z[4] = {keep[i].x, keep[i].y, keep[i].z, keep[i].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                amax = fmaxf(amax, fmaxf(fabsf(h2f(static_cast<uint16_t>(z[e] & 0xffffu))), fabsf(h2f(static_cast<uint16_t>(z[e] >> 16)))));
+                amax_acc = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2n_t, amax_acc), __builtin_bit_cast(us2n_t, z[e] & 0x7fff7fffu)));
             reinterpret_cast<uint4*>(out + static_cast<size_t>(row) * ldout)[c] = keep[i];
         }
     }
     if constexpr (!QUANT) return;
 
-    amax = block_max(amax, red + 4);                                      // (its barrier also orders the LDS copy of the x_out row)
+    float amax = h2f(static_cast<uint16_t>((amax_acc & 0xffffu) > (amax_acc >> 16) ? (amax_acc & 0xffffu) : (amax_acc >> 16)));
+    amax = block_max(amax, red + 4);                                      // (its barrier also orders the row's LDS image)
     if (kept && x_out) for (int j = tid; j < ldxo; j += NT) x_out[static_cast<size_t>(row) * ldxo + j] = j < n ? rowimg[j == tid ? gi : ind[j]] : static_cast<uint16_t>(0);
     constexpr float QMAX = static_cast<float>((1 << (BIT - 1)) - 1);
     const uint16_t sh = mixq_row_scale(amax, QMAX);

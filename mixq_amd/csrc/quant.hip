@@ -701,6 +701,7 @@ int launch_quant_rows2(uint16_t* x, int ldx, const int32_t* ind, int n, const in
 #define MIXQ_QLAUNCH2(NCH) do { if (col_mask) MIXQ_QLAUNCH2K(NCH, true); else MIXQ_QLAUNCH2K(NCH, false); } while (0)
     if      (nchunk <= 1 * TPR)  MIXQ_QLAUNCH2(1);
     else if (nchunk <= 2 * TPR)  MIXQ_QLAUNCH2(2);
+    else if (BIT == 8 && nchunk <= 3 * TPR) { if constexpr (BIT == 8) MIXQ_QLAUNCH2(3); }   // (K = 11008 at 512 threads: 2.7 chunks per thread; the FP6 forms pair chunks)
     else if (nchunk <= 4 * TPR)  MIXQ_QLAUNCH2(4);
     else if (nchunk <= 8 * TPR)  MIXQ_QLAUNCH2(8);
     else if (nchunk <= 16 * TPR) MIXQ_QLAUNCH2(16);
@@ -878,6 +879,7 @@ extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, con
     if      (nchunk <= 256)      MIXQ_QK(BITv, 256, 1);                   \
     else if (nchunk <= 512)      MIXQ_QK(BITv, 512, 1);                   \
     else if (nchunk <= 2 * 512)  MIXQ_QK(BITv, 512, 2);                   \
+    else if (nchunk <= 3 * 512)  MIXQ_QK(BITv, 512, 3);                   \
     else if (nchunk <= 4 * 512)  MIXQ_QK(BITv, 512, 4);                   \
     else if (nchunk <= 8 * 512)  MIXQ_QK(BITv, 512, 8);                   \
     else                         MIXQ_QK(BITv, 512, 16);
