@@ -194,3 +194,43 @@ def test_split_plan_is_off_for_one_round_and_for_forced_tilings():
     assert _capi.gemm_split_plan(16, 11008, 4096, 8, 2) is None             # a weight stream
     n1, name = _capi.gemm_split_plan(4096, 11008, 4096, 8, 2)
     assert n1 == 10240 and name.startswith("wr")                            # five full rounds of 128 x 256 tiles, the last 768 columns apart
+
+
+# ---- the metric shape against COMMITTED oracle outputs (tests/golden/g7: no oracle at run time) ----------------------------------------------
+def test_metric_shape_against_the_committed_fullsize_fixture():
+    """512 x 4096 -> 11008, 41 outlier columns x 20 (BASELINE.json configs[1]), rebuilt from seeds: the layer's quantised weights (scale_col
+    bit-exact, row sums of q_weight exact), the quantise pass (x_scale of EVERY row, q_x / x_out of eight rows: bit-exact, kept-map and
+    mask-building routes) and y of those rows (<= 2 fp16 ulp, the tolerance of tests/test_gpu_parity.py) against oracle/gen_fullsize_fixture.py's
+    committed outputs."""
+    import numpy as np
+    from mixq_amd import MixLibCache, MixLinear_GEMM
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_fullsize_512x4096x11008.npz"))
+    M, K, N = 512, 4096, 11008
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(K, N, bias=False).half()
+    cols = torch.randperm(K, generator=torch.Generator().manual_seed(1))[: round(0.01 * K)]
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(12)).half()
+    x[:, cols] *= 20
+    ind = torch.from_numpy(f["ind"]).to(DEV)
+    assert sorted(cols.tolist()) == f["ind"].tolist()
+    rows = torch.from_numpy(f["rows"].astype("int64")).to(DEV)
+    cache = MixLibCache(M, device=DEV)
+    layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
+    assert np.array_equal(layer.scale_col.cpu().numpy().reshape(-1).view(np.uint16), f["scale_col"].view(np.uint16))
+    assert np.array_equal(layer.q_weight.to(torch.int32).sum(dim=1).cpu().numpy(), f["q_weight_rowsum"])
+    wo = mixlib.DequantWeightCols(layer.q_weight, layer.scale_col, ind, 8)
+    assert np.array_equal(wo[:, :4].cpu().numpy().view(np.uint16), f["weight_cache_head"].view(np.uint16))
+    for cm in (None, L.kept_outlier_map(ind, K)):
+        xd = x.clone().to(DEV)
+        sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        q, xo = mixlib.QuantFused(xd, ind, sx, 8, 6.0, fmt=1, col_mask=cm)
+        torch.cuda.synchronize()
+        assert np.array_equal(sx.cpu().numpy().reshape(-1).view(np.uint16), f["x_scale"].view(np.uint16))
+        assert np.array_equal(mixlib.UnpackOperand(q, M)[rows].cpu().numpy(), f["q_x"])
+        assert np.array_equal(xo[rows].cpu().numpy().view(np.uint16), f["x_out"].view(np.uint16))
+        assert int((xd[:, ind.long()] != 0).sum()) == 0
+        y = mixlib.FusedLinear(q, mixlib.PackOperand(layer.q_weight, 2), sx, layer.scale_col, xo, wo, int(ind.numel()), None, M, N, K)
+        got, ref = y[rows].float().cpu().numpy(), f["y"].astype(np.float32)
+        a = np.abs(ref)
+        tol = np.maximum(2 * np.where(a > 0, 2.0 ** (np.floor(np.log2(np.maximum(a, 6e-5))) - 10), 2.0 ** -24), 1e-3)
+        assert (np.abs(got - ref) <= tol).all(), float(np.abs(got - ref).max())

@@ -129,3 +129,23 @@ def test_row_scale_multiplication_equals_the_division_for_every_fp16_maximum():
         div = (a / np.float32(qmax)).astype(np.float16)
         mul = (a * (np.float32(1.0) / np.float32(qmax))).astype(np.float16)
         assert np.array_equal(div.view(np.uint16), mul.view(np.uint16))
+
+
+def test_fullsize_fixture_is_what_the_oracle_computes(oracle):
+    """tests/golden/g7 (the metric shape, committed so that the GPU box needs no oracle for it) against a fresh run of its generator's recipe."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("gen_fullsize_fixture", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "gen_fullsize_fixture.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_fullsize_512x4096x11008.npz"))
+    w, x, ind = gen.inputs()
+    assert np.array_equal(ind, f["ind"]) and list(f["rows"]) == gen.ROWS
+    qw, sw = oracle.quant_weight_w8(w)
+    assert np.array_equal(sw.reshape(-1).view(np.uint16), f["scale_col"].view(np.uint16))
+    assert np.array_equal(qw.astype(np.int32).sum(axis=1), f["q_weight_rowsum"])
+    xz = x.copy()
+    xo = oracle.extract_outliers_zero(xz, ind)
+    qx, sx = oracle.find_row_scale(xz, 8)
+    assert np.array_equal(sx.view(np.uint16), f["x_scale"].view(np.uint16)) and np.array_equal(qx[gen.ROWS], f["q_x"])
+    assert np.array_equal(xo[gen.ROWS].view(np.uint16), f["x_out"].view(np.uint16))

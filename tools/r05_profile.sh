@@ -27,14 +27,9 @@ done
 python3 tools/driver_gaps.py $(find gpurun_out/prof_r05p_kt -name "*.db" | head -1) 20 > $O/r05p_driver_gaps.txt 2>&1
 rm -rf gpurun_out/prof_r05p_*
 python3 tools/make_traffic_json.py gpurun_out/r05p_fetch.txt gpurun_out/r05p_write.txt gpurun_out/r05p_hbm_traffic.json "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over python bench.py --steps 20 --warmup 2 --no-graph (tools/r05_profile.sh)" 512 4096 11008 8 41 > $O/r05p_traffic.log 2>&1
-python3 tools/quant_family.py 2>&1 | grep -v amdgpu.ids > $O/r05p_quant_family.txt
-for lib in libmixq_hip.so libmixq_hip_rcp.so libmixq_hip.so libmixq_hip_rcp.so; do
-  for extra in "" "--shape 4096,4096" "--shape 11008,4096"; do
-  MIXQ_LIB_FILE=$lib python3 bench.py --no-cpu-baseline --no-secondary $extra 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', '$extra', 'step', round(d['ms_per_step']*1e3,3), 'gemm', d['roofline']['us_per_launch'], 'min', round(d['timing']['replay_ms_min']*50,3))"
-done; done > $O/r05p_rcp_ab.txt 2>&1
-cat $O/r05p_driver_gaps.txt; cat $O/r05p_rcp_ab.txt; cat $O/r05p_quant_family.txt
+python3 tools/trace_gemm.py --shapes 512x11008x4096 --cfgs wr128x192_s16_d4_l2 --nout 41 2>&1 | grep -v amdgpu.ids > $O/r05p_gemm_trace.txt
+python3 tools/trace_gemm.py --shapes 512x4096x4096,512x4096x11008 --cfgs wr64x128_s16_d4_l2 --nout 41 2>&1 | grep -v amdgpu.ids >> $O/r05p_gemm_trace.txt
+cat $O/r05p_driver_gaps.txt
 grep -h "quant\|rmsnorm" $O/r05p_kt.txt $O/r05p_kt_k11008.txt $O/r05p_kt_mlp.txt | head -20
 python3 -c "
 import json

@@ -9,4 +9,5 @@ python3 tools/time_arch9.py 2>&1 | grep -v amdgpu.ids > $O/r05u_arch9_route.txt
 python3 tools/yardstick.py --no-power --rounds 10 2>&1 | grep -v amdgpu.ids > $O/r05u_ceiling.txt
 python3 tools/bench_mlp.py 2>&1 | grep -v amdgpu.ids > $O/r05u_mlp_block.txt
 python3 tools/bench_block.py --layers 32 --passes 1 2>&1 | grep -v amdgpu.ids > $O/r05u_block.txt
+python3 tools/prefill_sweep.py 2>&1 | grep -v amdgpu.ids > $O/r05u_prefill_sweep.txt
 tail -5 $O/r05u_configs_operator.txt; tail -3 $O/r05u_msweep_operator.txt; tail -3 $O/r05u_arch9_route.txt; tail -8 $O/r05u_ceiling.txt
