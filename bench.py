@@ -267,17 +267,26 @@ def cpu_baseline(rows):
                       f"(sweep over threads: " + ", ".join(f"{c}: {results[c][0]:.3f}" for c in cands) + f" TFLOPS; {logical} logical CPUs)"}
 
 
-def hbm_traffic_from_profile(tag=""):
+def hbm_traffic_from_profile(tag="", cfgname=None):
     """(HBM bytes per GEMM launch, source file) from the committed rocprofv3 PMC passes - the newest profiles/rNN_hbm_traffic<tag>.json -
-    or (None, None).  The counters need their own rocprofv3 --pmc passes (tools/r05_profile.sh), so the bench line carries the committed
-    figure of the same configuration (tag "" = the metric shape W8A8, "_w4a4", "_8192x28672")."""
+    or (None, reason).  The counters need their own rocprofv3 --pmc passes (tools/r05_profile.sh), so the bench line carries the committed
+    figure of the same configuration (tag "" = the metric shape W8A8, "_w4a4", "_8192x28672") - and ONLY while the kernel it was
+    measured on is the kernel this run picked: the file names the kernel instantiation (`gemm_wreg_kernel<MB, WNB, ...>`), the tiling's name
+    (`wr<16 MB>x<64 WNB>_...`) must agree, otherwise the figure is stale and the line says so instead of carrying it."""
     try:
         best = src = None
         pdir = os.path.join(ROOT, "profiles")
         for f in sorted(os.listdir(pdir)):
             if f.endswith(f"hbm_traffic{tag}.json"):
                 best, src = json.load(open(os.path.join(pdir, f))), "profiles/" + f
-        return (None, None) if best is None else (best.get("hbm_bytes_per_launch"), src)
+        if best is None:
+            return None, None
+        if cfgname:
+            import re
+            m, k = re.match(r"wr(\d+)x(\d+)_", cfgname), re.search(r"gemm_wreg_kernel<(\d+), (\d+),", best.get("kernel", ""))
+            if not m or not k or (int(m.group(1)) // 16, int(m.group(2)) // 64) != (int(k.group(1)), int(k.group(2))):
+                return None, f"stale: {src} was measured on {best.get('kernel', '?')[:60]}, this run picked {cfgname}"
+        return best.get("hbm_bytes_per_launch"), src
     except Exception:
         return None, None
 
@@ -534,7 +543,8 @@ def main(argv=None):
         fmt = layer.x_fmt()
         # (the committed PMC passes profiled the metric configuration: any other shape / bit width / per-rank batch carries no traffic figure)
         ttag = {(8, 512, 4096, 11008): "", (4, 512, 4096, 11008): "_w4a4", (8, 512, 8192, 28672): "_8192x28672"}.get((bit, rows, K, N))
-        traffic, traffic_src = hbm_traffic_from_profile(ttag) if ttag is not None else (None, None)
+        cfg_now = _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(rows, N, K, bit, mixlib.fmt_of(layer._wpk))]
+        traffic, traffic_src = hbm_traffic_from_profile(ttag, cfg_now) if ttag is not None else (None, None)
         shape_note = "Llama-2-7b up_proj shape" if (K, N) == (4096, 11008) else f"{K}->{N}"
         out = {
             "metric": f"effective int8 TFLOPS, W{bit}A{bit}O16 MixQ Linear forward (quantise + {'int8' if bit == 8 or fmt != 4 else 'FP6-pipe'} MFMA GEMM + fused dequant/outlier "

@@ -218,7 +218,8 @@ def test_metric_shape_against_the_committed_fullsize_fixture():
     layer = MixLinear_GEMM.from_linear(lin, 8, cache=cache, dev=DEV)
     assert np.array_equal(layer.scale_col.cpu().numpy().reshape(-1).view(np.uint16), f["scale_col"].view(np.uint16))
     assert np.array_equal(layer.q_weight.to(torch.int32).sum(dim=1).cpu().numpy(), f["q_weight_rowsum"])
-    wo = mixlib.DequantWeightCols(layer.q_weight, layer.scale_col, ind, 8)
+    wo = torch.zeros((N, 48), dtype=torch.float16, device=DEV)[:, :41]            # (the tail's operands are padded to 16 columns)
+    mixlib.DequantWeightCols(layer.q_weight, layer.scale_col, ind, 8, out=wo)
     assert np.array_equal(wo[:, :4].cpu().numpy().view(np.uint16), f["weight_cache_head"].view(np.uint16))
     for cm in (None, L.kept_outlier_map(ind, K)):
         xd = x.clone().to(DEV)
