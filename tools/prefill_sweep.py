@@ -15,14 +15,14 @@ from mixq_amd import _capi, mixlib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--tokens", default="1024,2048,4096,8192")
 ap.add_argument("--layers", default="11008x4096,4096x11008,12288x4096,14336x4096,13824x5120,5120x13824,12288x8192,28672x8192,8192x28672")
-ap.add_argument("--cfgs", default="13,24,29")
+ap.add_argument("--cfgs", default="256x256_w4x2_s5_l0,wr128x192_s16_d4_l2,wr128x256_s16_d3_l2", help="tilings to force, by name or id")
 ap.add_argument("--rounds", type=int, default=3)
 args = ap.parse_args()
 dev = "cuda"
 lib = _capi.load()
 names = _capi.gemm_config_names()
 print(_capi.device_info())
-cfgs = [int(c) for c in args.cfgs.split(",")]
+cfgs = [int(c) if c.lstrip("-").isdigit() else names.index(c) for c in args.cfgs.split(",")]
 
 
 def graph_of(fn, n):
