@@ -206,7 +206,7 @@ int mixq_gemm_i4_fused(const uint8_t* q_x, const uint8_t* q_w, const uint16_t* x
  * value is exactly the maximum the quantiser would have found.  row_amax must be zero when the GEMM starts.
  * mixq_quant_known_amax is mixq_quant_fused for rows whose maximum is known: one pass, no reduction; it reads row_amax[m], CLEARS it
  * (ready for the producer's next run), and writes exactly the bytes mixq_quant_fused writes.  Its col_mask is the layer's KEPT OUTLIER MAP
- * of `ind` (the full layout of mixq_quant_fused_masked: bit words, count word, pad, positions - required when n > 0; the GEMM reads only
+ * of `ind` (the full layout of mixq_quant_fused_masked: bit words, count word, pad, per-column AND-masks - required when n > 0; the GEMM reads only
  * the bit words of the same buffer).
  * mixq_gemm_amax_supported: 1 when the side output is available for (M, N, K, layout) - int8, MIXQ_X_PACKED | MIXQ_W_F16X64, the
  * batches the weights-in-registers kernels serve - else 0 (mixq_gemm_i8_fused_amax then returns MIXQ_ESHAPE). */

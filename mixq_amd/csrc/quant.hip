@@ -846,7 +846,7 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
 {
     return quant_fused_common(x, ind, n, n_dev, nullptr, x_scale, q, x_out, flag, M, K, ldx, ldo, bit, sigma, qfmt, stream);
 }
-// ... with the caller's kept outlier map of the live `ind` entries (include/mixq_hip.h: bit words, count word, per-column positions): same
+// ... with the caller's kept outlier map of the live `ind` entries (include/mixq_hip.h: bit words, count word, per-column AND-masks): same
 // bytes out from ONE memory round trip - no in-kernel mask build in front of the row maximum, no dependent gather behind the row load
 extern "C" int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
                                        uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo,

@@ -796,7 +796,7 @@ class ForwardPlan:
             a.w_out, a.ldwo = wop, ldwo
         a.ldy = N
         self.args, self.ref, self.fn = a, C.byref(a), _capi.load().mixq_linear_forward
-        # kept_mask: the layer's kept outlier map of `ind` (include/mixq_hip.h: bits, count, positions): the quantise pass then needs one memory round trip
+        # kept_mask: the layer's kept outlier map of `ind` (include/mixq_hip.h: bits, count, AND-masks): the quantise pass then needs one memory round trip
         if kept_mask is not None:
             _dev_check(kept_mask)
             if kept_mask.element_size() != 4 or kept_mask.numel() < (K + 31) // 32 + 1 or not kept_mask.is_contiguous():

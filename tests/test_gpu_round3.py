@@ -265,7 +265,7 @@ def test_known_maximum_quantiser_writes_the_same_bytes(M, K, ncols, bit, fmt):
     if ncols:
         xm[:, cols] = 0
     amax = torch.from_numpy(xm.max(axis=1).astype(np.float16).view(np.uint16).astype(np.int32)).to(DEV)
-    mask = L.kept_outlier_map(ind, K) if ncols else None               # the layer's kept outlier map: bits, count, positions (include/mixq_hip.h)
+    mask = L.kept_outlier_map(ind, K) if ncols else None               # the layer's kept outlier map: bits, count, AND-masks (include/mixq_hip.h)
     qb = torch.empty_like(qa)
     ldo = (ncols + 15) // 16 * 16
     xob = torch.empty((M, ldo), dtype=torch.float16, device=DEV) if ncols else None

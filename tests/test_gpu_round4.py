@@ -272,7 +272,7 @@ def test_quantise_pass_with_the_kept_column_mask_writes_the_same_bytes(bit, fmt,
     ind = torch.full((cap,), K - 1, dtype=torch.int32)                   # (entries behind the live count: never read as columns)
     ind[:ncols] = cols
     ind, n_dev = ind.to(DEV), torch.tensor([ncols], dtype=torch.int32, device=DEV)
-    mask = L.kept_outlier_map(ind[:ncols], K)                            # bits, count word, per-column positions (include/mixq_hip.h)
+    mask = L.kept_outlier_map(ind[:ncols], K)                            # bits, count word, per-column AND-masks (include/mixq_hip.h)
     outs = []
     for cm in (None, mask):
         xd = x.clone().to(DEV)
@@ -316,7 +316,7 @@ def test_fused_norm_with_the_kept_column_mask_writes_the_same_bytes(bit, fmt, M,
     ind = torch.full((cap,), K - 1, dtype=torch.int32)
     ind[:ncols] = cols
     ind, n_dev = ind.to(DEV), torch.tensor([ncols], dtype=torch.int32, device=DEV)
-    mask = L.kept_outlier_map(ind[:ncols], K)                            # bits, count word, per-column positions (include/mixq_hip.h)
+    mask = L.kept_outlier_map(ind[:ncols], K)                            # bits, count word, per-column AND-masks (include/mixq_hip.h)
     outs = []
     for cm in (None, mask):
         xd = x.clone().to(DEV)

@@ -1,4 +1,4 @@
-"""Round 5: the kept OUTLIER MAP of a frozen layer (bits, count, per-column positions) - the quantise passes take the outlier values out
+"""Round 5: the kept OUTLIER MAP of a frozen layer (bits, count, per-column AND-masks) - the quantise passes take the outlier values out
 of the registers that hold the row instead of gathering x[row][ind[j]] through two dependent memory round trips.  Everything here
 compares the kept route with the in-kernel-mask route through the C ABI, byte for byte."""
 import os
