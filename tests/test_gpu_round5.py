@@ -138,7 +138,8 @@ def _split_operands(M, N, K, bit, n_out, seed):
 
 
 @pytest.mark.parametrize("M,N,K,bit,n_out,act", [(4096, 11008, 4096, 8, 41, 0), (2048, 14336, 4096, 8, 0, 1), (2048, 5120, 13824, 8, 138, 0),
-                                                 (2048, 14336, 4096, 4, 128, 0), (4096, 11008, 4096, 4, 128, 1)])
+                                                 (2048, 14336, 4096, 4, 128, 0), (4096, 11008, 4096, 4, 128, 1),
+                                                 (4000, 11000, 4096, 8, 70, 2), (3970, 11004, 4096, 8, 3, 0)])   # ragged M, N % 8 != 0 (unstaged stores), > 64 tail columns, the multiplier form
 def test_the_n_split_of_a_partial_last_round_is_bit_identical_to_one_launch(M, N, K, bit, n_out, act):
     """The automatic choice at these shapes runs two launches over disjoint column ranges (the picked tiling over its full rounds'
     columns, a cheaper tiling over the rest); mixq_gemm_set_config(-2) runs the same problem as ONE launch: identical bits, with the fp16
@@ -151,12 +152,13 @@ def test_the_n_split_of_a_partial_last_round_is_bit_identical_to_one_launch(M, N
     if plan is None:
         pytest.skip("the model prices no split for this shape in this form")
     xp, wp, sx, sw, xo, wo, bias = _split_operands(M, N, K, bit, n_out, seed=M + N + K + bit)
+    addend = torch.randn((M, N), generator=torch.Generator().manual_seed(9)).half().to(DEV) if act == 2 else None
     outs = []
     try:
         for cfg in (-2, -1):
             assert lib.mixq_gemm_set_config(cfg) == 0
             y = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
-            mixlib.FusedLinear(xp, wp, sx, sw, xo, wo, n_out, bias, M, N, K, bit=bit, act=act, out=y)
+            mixlib.FusedLinear(xp, wp, sx, sw, xo, wo, n_out, bias, M, N, K, bit=bit, act=act, addend=addend, out=y)
             torch.cuda.synchronize()
             outs.append(y)
     finally:
