@@ -17,6 +17,7 @@ ap.add_argument("--tokens", default="1024,2048,4096,8192")
 ap.add_argument("--layers", default="11008x4096,4096x11008,12288x4096,14336x4096,13824x5120,5120x13824,12288x8192,28672x8192,8192x28672")
 ap.add_argument("--cfgs", default="256x256_w4x2_s5_l0,wr128x192_s16_d4_l2,wr128x256_s16_d3_l2", help="tilings to force, by name or id")
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--bit", type=int, default=8, help="4: W4A4 with both operands as FP6 codes (the FP6-pipe form of the weights-in-registers kernels)")
 args = ap.parse_args()
 dev = "cuda"
 lib = _capi.load()
@@ -56,15 +57,19 @@ for layer in args.layers.split(","):
     N, K = (int(v) for v in layer.split("x"))
     g0 = torch.Generator(device="cpu").manual_seed(0)
     qw = torch.randint(-127, 128, (N, K), generator=g0, dtype=torch.int8).to(dev)
-    wf = mixlib.PackOperand(qw, 2)
+    if args.bit == 4:
+        from mixq_amd.linear import pack_to_i4
+        wf = mixlib.PackOperand(pack_to_i4(torch.randint(-8, 8, (N, K), generator=g0, dtype=torch.int8)).to(dev), 3)
+    else:
+        wf = mixlib.PackOperand(qw, 2)
     sw = (torch.rand(1, N, generator=g0) * 0.01 + 0.001).half().to(dev)
     for M in (int(v) for v in args.tokens.split(",")):
         qx = torch.randint(-127, 128, (M, K), generator=g0, dtype=torch.int8).to(dev)
-        xp = mixlib.PackOperand(qx, 1)
+        xp = mixlib.PackOperand(pack_to_i4(torch.randint(-7, 8, (M, K), generator=g0, dtype=torch.int8)).to(dev), 4) if args.bit == 4 else mixlib.PackOperand(qx, 1)
         sx = (torch.rand(M, 1, generator=g0) * 0.01 + 0.001).half().to(dev)
         out = torch.empty((M, N), dtype=torch.float16, device=dev)
         n = max(2, min(20, int(4000 / max(1.0, 2e-9 * M * N * K / 1.8))))
-        auto = lib.mixq_gemm_pick_config_fmt(M, N, K, 8, 2)
+        auto = lib.mixq_gemm_pick_config_fmt(M, N, K, args.bit, 3 if args.bit == 4 else 2)
         arms = {}
         ref = None
         # -1: the automatic choice (tiling by the model, N split when the last round of tiles is partial); -2: the same without the split
@@ -72,7 +77,7 @@ for layer in args.layers.split(","):
             assert lib.mixq_gemm_set_config(c) == 0
             nm = names[c] if c >= 0 else ("auto" if c == -1 else "auto-1launch")
             try:
-                f = lambda: mixlib.FusedLinear(xp, wf, sx, sw, None, None, 0, None, M, N, K, bit=8, out=out)
+                f = lambda: mixlib.FusedLinear(xp, wf, sx, sw, None, None, 0, None, M, N, K, bit=args.bit, out=out)
                 out.zero_()
                 f()
                 torch.cuda.synchronize()
