@@ -66,6 +66,30 @@ def test_quantise_kept_map_route_is_byte_identical(bit, fmt, M, K, ncols, cap):
     assert torch.equal(outs[1][3].cpu()[:, keep], x[:, keep])                # every other column of x is untouched
 
 
+@pytest.mark.parametrize("bit,fmt,M,K", [(4, 4, 71, 2048), (4, 3, 33, 1024), (8, 2, 129, 11008), (4, 1, 5, 256)])
+def test_the_slow_form_of_the_kept_route_in_every_launch_geometry(bit, fmt, M, K):
+    """A kept map whose count word disagrees with the live count, through the geometries the formats select: two rows per workgroup with an odd
+    row count (FP6 activations: the last workgroup holds an invalid row and still takes both barriers of the slow form), 128 / 256 / 512
+    threads per row, three chunks per thread - same bytes as the route that never saw a map, and x zeroed at exactly the live columns."""
+    ncols, cap = 23, 32
+    x, cols, ind = _case(M, K, ncols, cap, seed=M + K)
+    kept = L.kept_outlier_map(ind[:ncols], K)
+    live = ncols - 4
+    n_dev = torch.tensor([live], dtype=torch.int32, device=DEV)
+    outs = []
+    for cm in (None, kept):
+        xd = x.clone().to(DEV)
+        sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV)
+        q, xo = mixlib.QuantFused(xd, ind, sx, bit, 6.0, n_dev=n_dev, fmt=fmt, col_mask=cm)
+        torch.cuda.synchronize()
+        outs.append((mixlib.UnpackOperand(q, M).clone(), sx, xo[:, :live].clone(), xd))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    zeroed = outs[1][3][:, cols[:live].long().to(DEV)]
+    assert int((zeroed != 0).sum()) == 0
+    assert torch.equal(outs[1][3][:, cols[live:].long().to(DEV)].cpu(), x[:, cols[live:].long()])      # the columns past the live count keep their values
+
+
 @pytest.mark.parametrize("what", ["quant", "norm"])
 def test_a_kept_map_built_for_another_live_count_is_ignored(what):
     """Device code may lower the live count behind the host's back: the map's count word then disagrees and the pass builds its own mask
