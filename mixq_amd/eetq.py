@@ -22,13 +22,6 @@ _packed = {}          # (data_ptr, version, shape) -> (q_weight, packed weights)
                       # The entry keeps q_weight itself alive: a key made of an address must not outlive the allocation it names.
 
 
-def set_backend(module):
-    """Tests on machines without a GPU install a CPU-oracle backend here (test infrastructure)."""
-    global _backend
-    _backend = module
-    _packed.clear()
-
-
 def quant_weights(weight, dtype=torch.int8, return_unprocessed_quantized_tensor=False):
     """weight: [K,N] (W^T) on the CPU or GPU -> (q int8 [K,N], scales [N] in weight's dtype)."""
     if dtype != torch.int8:

@@ -18,12 +18,6 @@ _backend = _hip_mixlib
 # (the switches of rounds 1-4 - FUSE_DOWN_AMAX, JOINT_GATE_UP, NORM_KEPT_MASK - are fields of the model's MixqConfig now: config.py)
 
 
-def set_backend(mod):
-    global _backend
-    prev, _backend = _backend, mod
-    return prev
-
-
 def interleave_pair_rows(up: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     """Rows of up_proj's and gate_proj's per-channel tensors ([N, ...] each, N even) in the order MIXQ_ACT_SILU_PAIR reads them
     (include/mixq_hip.h): groups of four - up[2g], up[2g+1], gate[2g], gate[2g+1] - so that the four consecutive channels a lane holds

@@ -25,16 +25,9 @@ from . import mixlib as _hip_mixlib
 from .config import MixqConfig
 from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_F16X64, FMT_F6X128, FMT_R6X128
 
-# The kernel backend.  Always the HIP module in the product; tests that exercise the host-side state machine on a
-# machine without a GPU swap in an oracle-backed stand-in (tests/backend_oracle.py) via `set_backend`.
+# The kernel backend: always the HIP module.  (The host-side tests that run without a GPU rebind this module attribute to an oracle-backed
+# stand-in themselves - tests/conftest.py: swap_backend - the product carries no switch for it.)
 _backend = _hip_mixlib
-
-
-def set_backend(mod):
-    global _backend
-    prev = _backend
-    _backend = mod
-    return prev
 
 
 def _fmt_of(t):

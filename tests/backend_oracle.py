@@ -1,5 +1,5 @@
 """A `mixq_amd.mixlib`-shaped backend on top of the CPU oracle, for testing the operator's HOST logic (state machine,
-buffer management) on machines without a GPU.  Test infrastructure: installed with mixq_amd.linear.set_backend() by
+buffer management) on machines without a GPU.  Test infrastructure: installed with tests/conftest.py's swap_backend(mixq_amd.linear, ...) by
 the tests only; the product never imports it."""
 import numpy as np
 import torch

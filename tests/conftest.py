@@ -50,3 +50,13 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+def swap_backend(module, backend):
+    """Test seam: rebind a product module's kernel backend (`mixq_amd.linear / fused / eetq._backend`, always the HIP `mixlib` in the product)
+    to `backend` - tests/backend_oracle.py on machines without a GPU - and return the previous one.  The product has no API for this."""
+    prev = module._backend
+    module._backend = backend
+    if hasattr(module, "_packed"):
+        module._packed.clear()                            # (eetq: packed-weight cache keyed by addresses of the other backend's tensors)
+    return prev

@@ -3,6 +3,7 @@ RMSNorm hands the next linear exactly what its own unfused pre-pass would have p
 operator the way mixquant/modules/fused/mlp.py:57-70 does."""
 import numpy as np
 import pytest
+from conftest import swap_backend
 import torch
 
 import backend_oracle
@@ -14,11 +15,11 @@ from oracle import oracle as O
 
 @pytest.fixture()
 def oracle_backend():
-    p1, p2 = L.set_backend(backend_oracle), F.set_backend(backend_oracle)
+    p1, p2 = swap_backend(L, backend_oracle), swap_backend(F, backend_oracle)
     backend_oracle.calls.clear()
     yield backend_oracle
-    L.set_backend(p1)
-    F.set_backend(p2)
+    swap_backend(L, p1)
+    swap_backend(F, p2)
 
 
 def test_rmsnorm_oracle_matches_fp64_definition():

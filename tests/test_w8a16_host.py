@@ -3,6 +3,7 @@ checkpoint layout, with the oracle standing in for the kernels (tests/backend_or
 UNPINNED (EETQ is absent from the reference tree): the oracle restates the published FasterTransformer rule."""
 import numpy as np
 import pytest
+from conftest import swap_backend
 import torch
 import torch.nn as nn
 
@@ -14,13 +15,13 @@ from oracle import oracle as O
 
 @pytest.fixture(autouse=True)
 def _oracle_backend():
-    prev = linmod.set_backend(backend_oracle)
-    eetq.set_backend(backend_oracle)
+    prev = swap_backend(linmod, backend_oracle)
+    swap_backend(eetq, backend_oracle)
     backend_oracle.calls.clear()
     yield
-    linmod.set_backend(prev)
+    swap_backend(linmod, prev)
     from mixq_amd import mixlib
-    eetq.set_backend(mixlib)
+    swap_backend(eetq, mixlib)
 
 
 @pytest.mark.parametrize("K,N,seed", [(64, 16, 0), (256, 96, 1), (512, 40, 2)])
