@@ -87,6 +87,14 @@ template <int I, int N, class F> __device__ __forceinline__ void wr_static_for(F
 // 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only, 4 weight loads issued but never waited for, 5 the loader
 // never waits for its DMA, 6 no k-loop barriers (4-6: timing probes, results are garbage), 7 no stores of Y, 8 ordinary instead of
 // nt stores, 9 return at entry, 12 no prologue ramp in the loader.
+#ifndef MIXQ_Y_ST
+#define MIXQ_Y_ST 2                         // cache policy of the stores of Y (buffer-store aux bits): 2 = nt (streaming), 16 = sc1 (write-through), 18 = both, 0 = ordinary (A/B build switch)
+#endif
+#ifndef MIXQ_Y_WT_MB
+#define MIXQ_Y_WT_MB 4                      // tiles of at most this many 16-row blocks store Y write-through (sc1 | nt): the layers they serve write a few MB of Y in ONE round of
+                                            // tiles, and lines written through during the epilogue are not left for the kernel's closing release to write back: -0.1 ... -0.25 us per launch at
+                                            // N = 4096 / small batches, nothing at the metric tile, +0.6 % at 2048 tokens if the big tiles did it too (profiles/r05_y_store_policy_ab.txt)
+#endif
 #ifndef MIXQ_PAIR_ST
 #define MIXQ_PAIR_ST 2                      // cache policy of the joint gate / up form's stores of Y: 2 = nt (streaming), 0 = ordinary (A/B build switch)
 #endif
@@ -279,7 +287,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         for (int it = 0; it < IT; ++it) v[it] = *reinterpret_cast<const u32x4*>(lds + p * PROWS * OPITCH + loff[it]);
         if (ABLK != 7 || a.act == 12345) {
 #pragma unroll
-            for (int it = 0; it < IT; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs, voff[it], 0, ABLK == 8 ? 0 : (PAIR ? MIXQ_PAIR_ST : 2 /* nt */));
+            for (int it = 0; it < IT; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs, voff[it], 0, ABLK == 8 ? 0 : (PAIR ? MIXQ_PAIR_ST : (MB <= MIXQ_Y_WT_MB ? 18 : MIXQ_Y_ST)));
         }
     };
     uint32_t voffA[IT_A];                                                        // this thread's chunks when all NT threads copy a panel
