@@ -319,7 +319,7 @@ int mixq_gemm_set_workspace(void* ws, long long bytes);
  * description.  Every configuration of the product library computes the same (correct) result; the ablation forms used for
  * tuning, the in-kernel timeline stamps (mixq_gemm_set_trace), the forced tile-order group (mixq_gemm_set_krot) and the quantise kernel's
  * timing probes (mixq_quant_set_config >= 100) exist only in the -DMIXQ_TUNING build (`make -C mixq_amd/csrc tuning` ->
- * libmixq_hip_tuning.so, loaded by the tools/ scripts): in the product library those calls return MIXQ_EINVAL.
+ * libmixq_hip_tuning.so, loaded by the tools/ scripts): the product library does not export the first two and returns MIXQ_EINVAL for the probes.
  * cfg = -2: automatic, but always ONE launch - without the N split described at mixq_gemm_pick_split (its A/B partner). */
 int mixq_gemm_set_config(int cfg);
 /* The N split of the automatic choice.  A launch of T tiles on the device's 256 CUs takes ceil(T / 256) rounds of the tile's time
@@ -334,6 +334,7 @@ int mixq_gemm_pick_split(int M, int N, int K, int bit, int fmt, int* n1, int* cf
  * one-row-per-256-thread-workgroup kernel, 1..9 (threads per row, rows per workgroup) = (64,1) (64,2) (64,4) (128,1)
  * (128,2) (256,1) (256,2) (512,1) (512,2).  Every geometry produces identical bytes.  Per device, like mixq_gemm_set_config. */
 int mixq_quant_set_config(int cfg);
+#ifdef MIXQ_TUNING   /* exported by libmixq_hip_tuning.so only (make -C mixq_amd/csrc tuning): the product library does not have them */
 /* Diagnostics: when buf is non-null every workgroup of the data-parallel fused GEMM writes 16 x u64 to
  * buf[16 * workgroup + i]: i in 0..7 = the 100 MHz device wall clock at 0 entry, 1 first stage landed, 2 k loop
  * done, 3 epilogue arithmetic done, 4 stores issued, 5 stores retired, 6/7 inside the epilogue; 8 + i = s_memtime
@@ -342,8 +343,9 @@ int mixq_quant_set_config(int cfg);
 int mixq_gemm_set_trace(unsigned long long* buf);
 /* Tuning (tools build): bits 16.. = M tiles per group of the weights-in-registers kernels' tile order (0: automatic).  The low 16 bits
  * used to rotate the K walk between neighbouring N tiles (rounds 1-2; it never changed a timing and cost two scalar counters per wave):
- * removed in round 4, ignored.  The product library returns MIXQ_EINVAL for any non-zero value. */
+ * removed in round 4, ignored. */
 int mixq_gemm_set_krot(int krot);
+#endif
 /* Diagnostics: exhaustive self-test of the division-free quantiser used by the quantise kernels (q = rint(x / s) for all
  * finite fp16 x and all finite fp16 s > 0, ~2e9 pairs, ~1 s): adds the number of disagreements with the IEEE-division form
  * to *mismatches_dev (a zeroed device counter).  bit = 8 or 4. */

@@ -113,10 +113,16 @@ class LinearArgs(C.Structure):
 _lib = None
 
 
-def header_symbols(path: str = HEADER_PATH):
-    """Function names declared in include/mixq_hip.h (used by the symbol-export test)."""
+TUNING_ONLY = ("mixq_gemm_set_trace", "mixq_gemm_set_krot")     # exported by libmixq_hip_tuning.so only (include/mixq_hip.h: #ifdef MIXQ_TUNING)
+
+
+def header_symbols(path: str = HEADER_PATH, tuning: bool = False):
+    """Function names declared in include/mixq_hip.h (used by the symbol-export test); the `#ifdef MIXQ_TUNING` section counts only for the
+    tuning library."""
     txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    if not tuning:
+        txt = re.sub(r"#ifdef MIXQ_TUNING.*?#endif", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(?:int|long long)\s+(mixq_\w+)\s*\(", txt)))
 
 
@@ -141,6 +147,8 @@ def load():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
+            if name in TUNING_ONLY:
+                continue                                   # the product library: no trace stamps, no tile-order knob
             raise MixqBuildError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = RESTYPES.get(name, _I)

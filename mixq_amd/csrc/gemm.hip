@@ -1068,10 +1068,7 @@ extern "C" int mixq_gemm_set_config(int cfg) {
 #ifdef MIXQ_TUNING
 extern "C" int mixq_gemm_set_trace(unsigned long long* buf) { g_trace = buf; return MIXQ_OK; }
 extern "C" int mixq_gemm_set_krot(int v) { return mixq_wr_set_krot(v); }
-#else                                              // product build: no in-kernel stamps, no K rotation knob
-extern "C" int mixq_gemm_set_trace(unsigned long long* buf) { return buf ? MIXQ_EINVAL : MIXQ_OK; }
-extern "C" int mixq_gemm_set_krot(int v) { return v ? MIXQ_EINVAL : MIXQ_OK; }
-#endif
+#endif                                             // (product build: no in-kernel stamps, no tile-order knob - and no entry points for them)
 extern "C" int mixq_gemm_num_configs(void) { return total_configs(); }
 extern "C" int mixq_gemm_config_name(int cfg, char* buf, int cap) {
     if (cfg < 0 || cfg >= total_configs() || !buf || cap <= 0) return MIXQ_EINVAL;

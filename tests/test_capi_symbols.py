@@ -21,7 +21,8 @@ def test_every_header_symbol_is_exported_and_bound():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mixq_hip.h but not exported"
-    assert set(declared) == set(_capi.SIGNATURES), "ctypes table and header disagree"
+    assert set(declared) == set(_capi.SIGNATURES) - set(_capi.TUNING_ONLY), "ctypes table and header disagree"
+    assert set(_capi.header_symbols(tuning=True)) == set(_capi.SIGNATURES)       # ... and with the tuning library's section
 
 
 def test_header_arity_matches_ctypes_table():
@@ -111,8 +112,8 @@ def test_product_library_ships_no_tuning_variants():
     lib = _capi.load()
     assert all("abl" not in nm for nm in _capi.gemm_config_names()), _capi.gemm_config_names()
     assert all("abl" not in nm for nm in _capi.w8a16_config_names())
-    assert lib.mixq_gemm_set_trace(C.c_void_p(4096)) == _capi.MIXQ_EINVAL and lib.mixq_gemm_set_trace(None) == 0
-    assert lib.mixq_gemm_set_krot(3) == _capi.MIXQ_EINVAL and lib.mixq_gemm_set_krot(0) == 0
+    for name in _capi.TUNING_ONLY:                                          # trace stamps / tile-order knob: not even an entry point
+        assert not hasattr(lib, name), name
     assert lib.mixq_quant_set_config(100) == _capi.MIXQ_EINVAL and lib.mixq_quant_set_config(-1) == 0
     blob = open(_capi.LIB_PATH, "rb").read()
     assert b"abl3_mfma" not in blob and b"abl1_noW" not in blob

@@ -101,7 +101,8 @@ def main():
         for c, krot, rotv in [(c, int(kr), int(rv)) for c in cfgs for kr in args.packed.split(",") for rv in args.krot.split(",")]:
             if krot not in packs or (rotv and not names[c].startswith("wr")):
                 continue
-            lib.mixq_gemm_set_krot(rotv)
+            if hasattr(lib, "mixq_gemm_set_krot"):
+                lib.mixq_gemm_set_krot(rotv)
             if names[c].startswith("wr") != (krot == 2) and names[c] != "decode32":
                 continue                                   # the weights-in-registers tilings take F16x64 only, the others never
             if names[c] == "decode32" and (krot == 0 or M > 32):
@@ -128,7 +129,8 @@ def main():
             print(f"{shp} cfg{c:2d} packed={krot:1d} rot={rotv:2d} {names[c]:24s} err={err:.3e} rel={rel:.2e} eager={us:8.2f}us graph={usg:8.2f}us "
                   f"{tops:7.1f} TOPS ({100 * tops / PEAK_TOPS:4.1f}%)", flush=True)
         lib.mixq_gemm_set_config(-1)
-        lib.mixq_gemm_set_krot(0)
+        if hasattr(lib, "mixq_gemm_set_krot"):
+            lib.mixq_gemm_set_krot(0)
         for fmt in (1, 2):
             auto = lib.mixq_gemm_pick_config_fmt(M, N, K, args.bit, fmt)
             print(f"{shp}: auto pick (fmt {fmt}) = cfg{auto} {names[auto]}", flush=True)
