@@ -728,6 +728,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             }
         };
         auto xread = [&](int slot, int j) MIXQ_INL {
+            if (ABLK == 14 && (j & 1)) { if constexpr (!F6) { xf[j] = xf[j - 1]; asm volatile("" : "+v"(xf[j])); } return; }   // timing probe (tuning build): HALF of the activation fragment reads - odd fragments are register copies of their even neighbours (real data for the MFMAs; results are garbage)
             if constexpr (F6 && (ABLK == 2 || ABLK == 3)) {
                 // (ablation: no LDS reads)
             } else if constexpr (F6) {
@@ -1776,6 +1777,7 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic
     MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // cfg 0, MFMA + epilogue only
+    MIXQ_WR(8, 3, 16, 4, 2, 14, "128x192_abl14_halfXreads"),   // cfg 0 with every other activation fragment never re-read from LDS: what halving the fragment reads would buy
     MIXQ_WR(8, 3, 16, 4, 2, 7, "128x192_abl7_nostore"),// cfg 0 without the stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// cfg 0 with ordinary (not nt) stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 9, "128x192_abl9_empty"),  // returns at entry: the launch floor of this grid and LDS footprint
