@@ -103,7 +103,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 {
     // ABL = 90 is not an ablation but a kernel FORM - the paired gate / up epilogue (PAIR below) on the shipped loop: everywhere else in this
     // body the loop variant is ABLK, which reads 0 for it
-    constexpr int ABLK = ABL == 90 ? 0 : ABL;
+    // (ABL 16 / 17 / 18: the feed ablations 3 / 2 / 1 with PSEUDO-RANDOM bytes in the operands that are never loaded - the MFMA's power, hence the clock of a
+    // power-limited launch, depends on how its operands switch: lane-constant stand-ins flatter every ablation; profiles/r05_ablations_random_operands.txt)
+    constexpr bool RNDOPS = ABL >= 16 && ABL <= 18;
+    constexpr int ABLK = ABL == 90 ? 0 : (RNDOPS ? 19 - ABL : ABL);
     constexpr int CW = WR_CW;
     constexpr int NT = (CW + LOADERS) * 64;
     constexpr int BM = MB * 16, WN = WNB * 16, BN = CW * WN;
@@ -603,14 +606,19 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     asm volatile("" : "=v"(wq[d][i]));
                     if constexpr (F6) asm volatile("" : "=v"(wq2[d][i]));
                 } else {
-                    wq[d][i] = i32x4{lane, lane, lane, lane};
+                    if constexpr (RNDOPS) { const unsigned h = static_cast<unsigned>(lane) * 0x9E3779B1u + static_cast<unsigned>(d * WNB + i + 1) * 0x85EBCA6Bu; wq[d][i] = i32x4{static_cast<int>(h), static_cast<int>(h * 0x27D4EB2Fu), static_cast<int>(h ^ 0x5bd1e995u), static_cast<int>(h * 0x165667B1u)}; }
+                    else wq[d][i] = i32x4{lane, lane, lane, lane};
                     if constexpr (F6) wq2[d][i] = i32x2{lane, lane};
                     asm volatile("" : "+v"(wq[d][i]));
                 }
             }
         if constexpr (ABLK != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
 #pragma unroll
-            for (int j = 0; j < MB; ++j) { xf[j] = i32x4{lane, 1, lane, 1}; asm volatile("" : "+v"(xf[j])); }
+            for (int j = 0; j < MB; ++j) {
+                if constexpr (RNDOPS) { const unsigned h = static_cast<unsigned>(lane) * 0xC2B2AE35u + static_cast<unsigned>(j + 1) * 0x9E3779B1u; xf[j] = i32x4{static_cast<int>(h), static_cast<int>(h * 0x27D4EB2Fu), static_cast<int>(h ^ 0x2545F491u), static_cast<int>(h * 0x165667B1u)}; }
+                else xf[j] = i32x4{lane, 1, lane, 1};
+                asm volatile("" : "+v"(xf[j]));
+            }
             if constexpr (F6) {
 #pragma unroll
                 for (int j = 0; j < XR; ++j) xf6[j] = i32x6{lane, 1, lane, 1, 2, 3};
@@ -1777,6 +1785,9 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic
     MIXQ_WR(8, 3, 16, 4, 2, 3, "128x192_abl3_mfma"),   // cfg 0, MFMA + epilogue only
+    MIXQ_WR(8, 3, 16, 4, 2, 16, "128x192_abl16_mfma_rnd"),    // abl3 / abl2 / abl1 with pseudo-random bytes in the never-loaded operands
+    MIXQ_WR(8, 3, 16, 4, 2, 17, "128x192_abl17_noX_rnd"),
+    MIXQ_WR(8, 3, 16, 4, 2, 18, "128x192_abl18_noW_rnd"),
     MIXQ_WR(8, 3, 16, 4, 2, 14, "128x192_abl14_halfXreads"),   // cfg 0 with every other activation fragment never re-read from LDS: what halving the fragment reads would buy
     MIXQ_WR(8, 3, 16, 4, 2, 7, "128x192_abl7_nostore"),// cfg 0 without the stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// cfg 0 with ordinary (not nt) stores of Y
