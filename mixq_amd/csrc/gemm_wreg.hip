@@ -184,8 +184,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr bool EPI2 = !SELF && ABLK != 50 && ABLK != 60 && (MB % PJ == 0) &&
                           (((BM * OPITCH + 15) & ~15) + WR_CW * 4 * BM * 4 <= TAILX);   // (the staged tile and the row-maximum slots stay clear of the tail's X_out blocks)
     static_assert(MB % ISSUERS == 0 && (STAGE_BYTES / 1024) % ISSUERS == 0, "pieces must divide evenly over the issuing waves");
-    static_assert(!F6 || (!SELF && (ABLK == 0 || ABLK == 1 || ABLK == 2 || ABLK == 3)), "the FP6 form exists for the shipped loop (and its feed ablations) only");
-    static_assert(!F6R || ABLK == 0, "the tuple-ring form has no ablations");
+    // (round 6: the tuple-ring form's feed ablations - 1 no weight loads, 2 no X traffic, 3 MFMA only, 6 no k-loop barriers, 32 DMA without fragment
+    // reads, 33 fragment reads without DMA - with pseudo-random stand-ins, and 36: the in-k-step timeline of tools/trace_kstep.py)
+    static_assert(!F6 || (!SELF && (ABLK == 0 || ABLK == 1 || ABLK == 2 || ABLK == 3 || (F6R && (ABLK == 6 || ABLK == 32 || ABLK == 33 || ABLK == 36 || ABLK == 38 || ABLK == 39)))), "the FP6 form exists for the shipped loop (and its feed ablations) only");
     static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
     static_assert(!SELF || (LOOK == D + 1 && !I4 && ABLK == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
     static_assert(!EPI2 || SC_END <= 160 * 1024, "X ring + tail blocks + panel flags + scales must fit the 160 KiB of LDS");
@@ -333,7 +334,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         }
         size_t xoff = 0;                                 // byte offset of the k-step the next stage reads
         auto stage = [&](int slot) MIXQ_INL {
-            if constexpr (ABLK != 2 && ABLK != 3) {
+            if constexpr (ABLK != 2 && ABLK != 3 && ABLK != 33) {
 #pragma unroll
                 for (int i = 0; i < LOADS; ++i) {
                     wr_glds16(src[i] + xoff, lds + slot * STAGE_BYTES + dsto[i]);
@@ -393,10 +394,25 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         }
         size_t toff = static_cast<size_t>(kt + LOOK) * static_cast<size_t>(a.wblocks) * 1024;   // (the k-step whose stage the next iteration requests)
         int tsink = 0;
+        // ABLK 36 (tools/trace_kstep.py): s_memtime stamps inside ONE k-step (k-step nk / 2; the test sits inside the asm statement, so the other
+        // k-steps pay a compare and a branch per stamp): the loader's issue / wait / barrier here, the consumer's waits and MFMA groups below
+        unsigned long long lst[4] = {0ull, 0ull, 0ull, 0ull};
+        const int kmark_l = nk >> 1;
+        auto lstamp = [&](int i, int ktv) MIXQ_INL {
+#if defined(MIXQ_TUNING) && defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (ABLK == 36) { const int ku = __builtin_amdgcn_readfirstlane(ktv); asm volatile("s_cmp_lg_u32 %1, %2\n\ts_cbranch_scc1 1f\n\ts_memtime %0\n1:" : "+s"(lst[i]) : "s"(ku), "s"(kmark_l) : "scc"); }
+#else
+            (void)i; (void)ktv;
+#endif
+        };
         for (; kt + LOOK < nk; ++kt) {
+            lstamp(0, kt);
             stage(nxt);
+            lstamp(1, kt);
             if constexpr (ABLK != 5) wr_wait_vmcnt<LOADS * NEWER>();              // stage kt+1 landed
+            lstamp(2, kt);
             if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
+            lstamp(3, kt);
             nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
             if constexpr (TOUCH) {
                 // (the destination stays a LIVE register until the loader's last vmcnt(0): a dead one would be handed to something else while
@@ -454,6 +470,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         }
         wr_wait_vmcnt<0>();                                                      // (nk = 1: no drain iteration waited for the tail blocks)
         if constexpr (TOUCH) asm volatile("" :: "v"(tsink));
+#ifdef MIXQ_TUNING
+        if constexpr (ABLK == 36) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lst[0]), "+s"(lst[1]), "+s"(lst[2]), "+s"(lst[3]));
+            if (a.trace && lw == 0 && lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a.trace[2 * 16 * 4096 + blockIdx.x * 16 + 11 + i] = lst[i];
+            }
+        }
+#endif
         uint32_t voffL[IT_L];
         int loffL[IT_L];
         if constexpr (EPI2) {
@@ -566,7 +591,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         };
         auto wload6 = [&](auto d_c, int i) MIXQ_INL {               // F6R: fragment i of the k-step at woff -> tuple i of ring slot d
             constexpr int d = decltype(d_c)::value;
-            if constexpr (F6R) {
+            if constexpr (F6R && ABLK != 1 && ABLK != 3) {
                 const uint8_t* src = wb[i] + woff;
                 const int l16 = lane * 16, l8 = lane * 8;
                 i32x4 lo; i32x2 hi;
@@ -591,7 +616,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // F6: activation fragments as the 6-register operand tuples - a rotating window of XR of a k-step's MB fragments (all MB would
         // not fit next to 6-register weight fragments: 256 registers per wave at 6 waves per CU).  Group j runs on window slot j % XR and
         // requests fragment j + XR behind its last MFMA - of this stage, or of the next one (landed: the k-step's barrier) once j + XR >= MB.
-        constexpr int XR = F6 ? (MB < MIXQ_XR ? MB : MIXQ_XR) : 1;
+        constexpr int XR = F6 ? (ABLK == 38 ? MB : (ABLK == 39 ? 2 : (MB < MIXQ_XR ? MB : MIXQ_XR))) : 1;   // (ABLK 38 / 39, tuning build: window of MB / of 2 tuples)
         i32x6 xf6[XR];
         static_assert(!F6 || MB % XR == 0, "window slots must be compile-time");
         i32x4 xc[2];                                     // (probe ABLK 30: copies of the last two fragments)
@@ -619,7 +644,24 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 else xf[j] = i32x4{lane, 1, lane, 1};
                 asm volatile("" : "+v"(xf[j]));
             }
-            if constexpr (F6) {
+            if constexpr (F6R) {
+                // (the tuple-ring form's ablations: pseudo-random six-bit codes in whatever is never loaded - see RNDOPS)
+                auto rnd6 = [&](unsigned salt) MIXQ_INL {
+                    const unsigned h = static_cast<unsigned>(lane) * 0x9E3779B1u + salt * 0x85EBCA6Bu;
+                    return i32x6{static_cast<int>(h), static_cast<int>(h * 0x27D4EB2Fu), static_cast<int>(h ^ 0x5bd1e995u), static_cast<int>(h * 0x165667B1u),
+                                 static_cast<int>(h * 0xC2B2AE35u), static_cast<int>((h >> 3) * 0x2545F491u)};
+                };
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int j = 0; j < XR; ++j) { xf6[j] = rnd6(100u + j); asm volatile("" : "+v"(xf6[j])); }
+                if constexpr (ABLK == 1 || ABLK == 3) {
+#pragma unroll
+                    for (int d = 0; d < NSLOT; ++d)
+#pragma unroll
+                        for (int i = 0; i < WNB; ++i) { wr6[d][i] = rnd6(1u + d * WNB + i); asm volatile("" : "+v"(wr6[d][i])); }
+                }
+#endif
+            } else if constexpr (F6) {
 #pragma unroll
                 for (int j = 0; j < XR; ++j) xf6[j] = i32x6{lane, 1, lane, 1, 2, 3};
 #pragma unroll
@@ -737,7 +779,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         };
         auto xread = [&](int slot, int j) MIXQ_INL {
             if (ABLK == 14 && (j & 1)) { if constexpr (!F6) { xf[j] = xf[j - 1]; asm volatile("" : "+v"(xf[j])); } return; }   // timing probe (tuning build): HALF of the activation fragment reads - odd fragments are register copies of their even neighbours (real data for the MFMAs; results are garbage)
-            if constexpr (F6 && (ABLK == 2 || ABLK == 3)) {
+            if constexpr (F6 && (ABLK == 2 || ABLK == 3 || ABLK == 32)) {
                 // (ablation: no LDS reads)
             } else if constexpr (F6) {
                 const i32x4 p4 = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * BLK + xoff);
@@ -758,6 +800,16 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             for (int e = 0; e < 4; ++e) o[e] = static_cast<int>(static_cast<uint32_t>(v[e]) & nib);
             return o; };
 
+        unsigned long long kst[11] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};   // ABLK 36: see the loader's lstamp
+        const int kmark = nk >> 1;
+        int kcur = -1;                                                           // (the k-step `one` is running)
+        auto kstamp = [&](int i) MIXQ_INL {
+#if defined(MIXQ_TUNING) && defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (ABLK == 36) { const int ku = __builtin_amdgcn_readfirstlane(kcur); asm volatile("s_cmp_lg_u32 %1, %2\n\ts_cbranch_scc1 1f\n\ts_memtime %0\n1:" : "+s"(kst[i]) : "s"(ku), "s"(kmark) : "scc"); }
+#else
+            (void)i;
+#endif
+        };
         // one k-step: MFMAs of ring slot C, X fragment j re-read from stage kt+1 right behind its last MFMA (REFILL), weight load
         // i of k-step kt+D issued into slot L = (C + D) % NSLOT behind MFMA group WPOS(i) (FULL: unconditionally)
         auto step = [&](auto c_c, auto full_c, bool refill, int issue, int rslot) MIXQ_INL {
@@ -793,6 +845,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     if (j + XR < MB) xread(rslot == 0 ? NSTAGE - 1 : rslot - 1, j + XR);
                     else if (refill) xread(rslot, j + XR - MB);
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (ABLK == 36) { if (j < 8) kstamp(3 + j); __builtin_amdgcn_sched_barrier(0); }
                 }
 #undef MIXQ_F6_MMA
             } else if constexpr (F6) {
@@ -1037,8 +1090,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         auto one = [&](auto c_c, auto full_c) MIXQ_INL {
             constexpr bool FULL = decltype(full_c)::value;                       // FULL: stage kt+1 and k-step kt+D exist
             if constexpr (FULL) {
+                kcur = kt;
+                kstamp(0);
                 if constexpr (ABLK != 4) wwait(c_c, std::integral_constant<int, WL * (D - 1)>{});    // the D-1 younger k-steps stay in flight
+                kstamp(1);
                 if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();            // stage kt+1 landed; stage kt-2's slot is free
+                kstamp(2);
                 step(c_c, full_c, true, 1, slot1);
             } else {
                 wwait_rt(c_c, nk - 1 - kt);
@@ -1062,6 +1119,15 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // (read-write operands of the wait statements): the ring stays allocated until nothing can land in it any more.
         if constexpr (WRAP) wr_static_for<0, NSLOT>([&](auto d_c) MIXQ_INL { wwait(d_c, std::integral_constant<int, 0>{}); });
         if constexpr (F6) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // asm MFMA -> accumulator reads: wait states the compiler cannot count
+#ifdef MIXQ_TUNING
+        if constexpr (ABLK == 36) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kst[0]), "+s"(kst[1]), "+s"(kst[2]), "+s"(kst[3]), "+s"(kst[4]), "+s"(kst[5]), "+s"(kst[6]), "+s"(kst[7]), "+s"(kst[8]), "+s"(kst[9]), "+s"(kst[10]));
+            if (a.trace && wave == 0 && lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 11; ++i) a.trace[2 * 16 * 4096 + blockIdx.x * 16 + i] = kst[i];
+            }
+        }
+#endif
         if constexpr (KS) {
             // ---- pairwise split-K hand-off (see KS above): slot = [wave][MB x WNB fragments][64 lanes x 16 bytes], register order ------
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.ks_slots + static_cast<size_t>(tile) * (BM * BN * 4), 0, BM * BN * 4, 0x00020000);
@@ -1773,6 +1839,19 @@ const WrConfig g_wr[] = {
     { "wr128x192_f6r_d3", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 3, 3, 2, 0>, 8 },           // Q = 3 ring variants
     { "wr128x192_f6r_s10", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 10, 2, 3, 2, 0>, 10 },
     { "wr128x192_f6_l4", 8, 3, 16, 4, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 4, 0>, 8 },            // four loader waves
+    // round 6: the tuple-ring (shipped) form's feed ablations with pseudo-random stand-ins, ring variants, and the in-k-step timeline
+    { "wr128x192_f6r_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 1>, 8 },
+    { "wr128x192_f6r_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 2>, 8 },
+    { "wr128x192_f6r_abl3_mfma", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 3>, 8 },
+    { "wr128x192_f6r_abl6_nobar", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 6>, 8 },
+    { "wr128x192_f6r_abl32_dma_noreads", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 32>, 8 },
+    { "wr128x192_f6r_abl33_reads_nodma", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 33>, 8 },
+    { "wr128x192_f6r_t36_kstep_timeline", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 36>, 8 },
+    { "wr128x192_f6r_xr8", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 38>, 8 },
+    { "wr128x192_f6r_xr2", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 39>, 8 },
+    { "wr128x192_f6r_l4", 8, 3, 16, 4, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 4, 0>, 8 },
+    { "wr128x192_f6r_d4", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 4, 3, 2, 0>, 8 },
+    { "wr128x192_f6r_s6", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 6, 2, 3, 2, 0>, 6 },
     MIXQ_WR(8, 3, 16, 4, 2, 61, "128x192_p61_epi2_copy_at_end"),
     MIXQ_WR(8, 3, 16, 4, 2, 62, "128x192_p62_epi2_loaders_prio0"),
     MIXQ_WR(8, 3, 16, 4, 2, 6, "128x192_abl6_no_kloop_barriers"),   // (timing probe: what the per-k-step barrier costs; results are garbage)

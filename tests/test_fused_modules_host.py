@@ -121,3 +121,24 @@ def test_pair_row_order_of_the_joint_gate_up_launch():
     zu, zg = z(u) + u["b"].astype(np.float64), z(g)
     want = (zg / (1 + np.exp(-zg)) + g["b"].astype(np.float64)) * zu
     assert np.abs(got.astype(np.float64) - want).max() <= 4e-3 * np.abs(want).max() + 1e-3
+
+
+# ---- G8: the reference's own norm.py + mlp.py + linear.py flow, recorded by oracle/gen_golden_g8.py -------------------------------
+@pytest.mark.parametrize("name", ["g8_mlp_block_w8.npz", "g8_mlp_block_w4.npz"])
+def test_g8_block_trace_step_by_step(golden, oracle_backend, name):
+    """State after every step of mlp.py:57-70 behind the fused norm, bit-exact; in the 8-bit trace a new outlier column arrives at call 1,
+    so gate_proj's take-over from cache.new_ind (linear.py:298-315) IS exercised."""
+    import g8_replay
+    g = golden(name)
+    worst = g8_replay.replay_walk(g, "cpu", lambda cache, M, KB: cache.q_xcache.numpy().view(np.uint8))
+    assert worst <= 4e-3
+    if int(g["bit"]) == 8:
+        assert g["c0_up_ind"].tolist() == [7, 100] and g["c1_gate_ind"].tolist() == [7, 100, 201] and g["c1_new_ind"].tolist() == [201]
+
+
+@pytest.mark.parametrize("name", ["g8_mlp_block_w8.npz", "g8_mlp_block_w4.npz"])
+def test_g8_block_trace_through_forward(golden, oracle_backend, name):
+    """MixLlamaMLP.forward (the multiply in gate_proj's epilogue instead of a separate pass) against the reference's y and layer state."""
+    import g8_replay
+    worst = g8_replay.replay_forward(golden(name), "cpu")
+    assert worst <= 1e-2

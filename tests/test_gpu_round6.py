@@ -1,0 +1,116 @@
+"""Round 6 GPU tests: the G8 fixtures (the reference's own norm.py + mlp.py + linear.py flow, oracle/gen_golden_g8.py) on the HIP backend
+- through the operator mirror step by step, through MixLlamaMLP.forward with the joint gate / up launch on and off, and native by native
+through the `mixlib` shim with the operands the reference's flow handed each native."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import g8_replay  # noqa: E402
+from mixq_amd import MixqConfig, _capi, mixlib  # noqa: E402
+from mixq_amd.mixlib import fmt_of  # noqa: E402
+from test_pack_properties import packed_unpack  # noqa: E402
+
+DEV = "cuda"
+G8 = ["g8_mlp_block_w8.npz", "g8_mlp_block_w4.npz"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint16)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    assert "gfx950" in _capi.device_info()
+    _capi.load().mixq_gemm_set_config(-1)
+    yield
+    _capi.load().mixq_gemm_set_config(-1)
+
+
+def _unpacked_q(cache, M, KB):
+    q = n(cache.q_xcache)
+    fmt = fmt_of(cache.q_xcache)
+    if fmt:
+        return packed_unpack(q.reshape(-1).view(np.uint8), M, KB, fmt)
+    return q.view(np.uint8)[:M]
+
+
+@pytest.mark.parametrize("name", G8)
+def test_g8_block_trace_step_by_step_on_gpu(golden, name):
+    """Every step of mlp.py:57-70 behind the fused norm on the HIP kernels: the state the reference's flow left (ind, weight_cache, cnt,
+    forward_without_precondition_len, cache.new_ind, x_scale, q_xcache, activation_outliers, the in-place zeroed activation) bit-exact."""
+    worst = g8_replay.replay_walk(golden(name), DEV, _unpacked_q)
+    assert worst <= 4e-3
+
+
+@pytest.mark.parametrize("joint", [True, False])
+@pytest.mark.parametrize("name", G8)
+def test_g8_block_trace_through_forward_on_gpu(golden, name, joint):
+    """MixLlamaMLP.forward as the product runs it - gate_proj + up_proj as ONE launch once both predictions are frozen (calls 2, 3 of the
+    8-bit trace; every call of the 4-bit one) or as two launches - against the reference's y (<= 1e-2) and final layer state (bit-exact)."""
+    worst = g8_replay.replay_forward(golden(name), DEV, config=MixqConfig(joint_gate_up=joint))
+    assert worst <= 1e-2
+
+
+def test_g8_natives_through_the_mixlib_shim(golden):
+    """Option A: the reference's Python calling `mixlib`.  /root/reference does not exist on the GPU box, so the
+    reference's flow is replayed NATIVE BY NATIVE from the 8-bit fixture: each shim entry point gets the operands the reference's own flow
+    handed that native at that point (recorded `ind`, `weight_cache`, the call order in c{i}_calls) and must return what the flow went on
+    with - integer / byte results bit-exact, fp16 outputs <= 4e-3 (two roundings against one)."""
+    g = golden("g8_mlp_block_w8.npz")
+    I, K = g["up_weight"].shape
+    x_scale = torch.zeros((64, 1), dtype=torch.float16, device=DEV)
+    zeros = torch.zeros((1, 1), dtype=torch.float16, device=DEV).expand(64, 4096)
+    norm_w = t(g["norm_weight"])
+    qw = {k: t(g[k + "_q_weight"]) for k in ("up", "gate", "down")}
+    sw = {k: t(g[k + "_scale_col"]) for k in ("up", "gate", "down")}
+    prev_ind = np.zeros((0,), np.int32)
+    for i in range(int(g["ncalls"])):
+        calls = [str(c) for c in g[f"c{i}_calls"]]
+        x = t(g[f"c{i}_x_in"].copy())
+        M = x.numel() // K
+        out = torch.empty_like(x)
+        assert calls[0] == "layernorm_forward_cuda_extract_outliers"
+        ao, q = mixlib.layernorm_forward_cuda_extract_outliers(x, norm_w, out, float(g["eps"]), t(prev_ind), x_scale)   # norm.py:25-28
+        assert np.array_equal(bits(n(out)), bits(g[f"c{i}_n_hidden"])) and np.array_equal(bits(n(x_scale)[:M]), bits(g[f"c{i}_n_x_scale"]))
+        assert np.array_equal(n(q)[:M].view(np.uint8), g[f"c{i}_n_q_xcache"].view(np.uint8))
+        if prev_ind.size:
+            assert np.array_equal(bits(n(ao)), bits(g[f"c{i}_n_activation_outliers"]))
+        inputs = out.reshape(-1, K)
+        if "ExtractOutliersAndSetToZeros" in calls:                               # linear.py:203-221: new columns found by up_proj_
+            new_ind = t(g[f"c{i}_new_ind"])
+            new = mixlib.ExtractOutliersAndSetToZeros(new_ind, inputs)
+            wc_new = mixlib.DequantWeightCols(qw["up"], sw["up"], new_ind, 8)       # (q_weight[:, ind].half() * scale_col.T, linear.py:207)
+            assert np.array_equal(bits(n(wc_new)), bits(g[f"c{i}_up_weight_cache"][:, prev_ind.size:]))
+            ao = torch.hstack((ao, new)) if prev_ind.size else new
+            q = mixlib.FindRowScale(inputs, x_scale, M, K, 8)
+            assert np.array_equal(bits(n(inputs)), bits(g[f"c{i}_u_hidden_after"].reshape(-1, K)))
+        ind_now = g[f"c{i}_up_ind"]
+        assert np.array_equal(bits(n(x_scale)[:M]), bits(g[f"c{i}_u_x_scale"])) and np.array_equal(n(q)[:M].view(np.uint8), g[f"c{i}_u_q_xcache"].view(np.uint8))
+        if ind_now.size:
+            assert np.array_equal(bits(n(ao)), bits(g[f"c{i}_u_activation_outliers"]))
+            add_u = torch.mm(ao, t(g[f"c{i}_up_weight_cache"]).T)                 # linear.py:248
+            add_g = torch.mm(ao, t(g[f"c{i}_gate_weight_cache"]).T)
+        else:
+            add_u = add_g = zeros
+        y_up = mixlib.int8FusedDequantize(q, qw["up"], x_scale, sw["up"], add_u, M, I, K)
+        y_g = mixlib.int8FusedDequantizeSilu(q, qw["gate"], x_scale, sw["gate"], add_g, M, I, K)
+        assert np.abs(n(y_up).astype(np.float32) - g[f"c{i}_u_y"].reshape(M, I).astype(np.float32)).max() <= 4e-3
+        assert np.abs(n(y_g).astype(np.float32) - g[f"c{i}_g_y"].reshape(M, I).astype(np.float32)).max() <= 4e-3
+        prod = t(g[f"c{i}_prod"]).reshape(M, I).clone()                           # down_proj_ from the reference's own product
+        qd = mixlib.FindRowScale(prod, x_scale, M, I, 8)                           # linear.py:190 (down_proj_ found no outlier column)
+        assert np.array_equal(bits(n(x_scale)[:M]), bits(g[f"c{i}_d_x_scale"])) and np.array_equal(n(qd)[:M].view(np.uint8), g[f"c{i}_d_q_xcache"].view(np.uint8))
+        y = mixlib.int8FusedDequantize(qd, qw["down"], x_scale, sw["down"], zeros, M, K, I)
+        assert np.abs(n(y).astype(np.float32) - g[f"c{i}_y"].reshape(M, K).astype(np.float32)).max() <= 4e-3
+        assert g[f"c{i}_down_ind"].size == 0
+        prev_ind = ind_now
