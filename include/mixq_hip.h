@@ -148,7 +148,12 @@ int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const int32_t* n_de
  * *n_dev when given - device code may lower it without the host knowing) is ignored: the kernel then builds its own mask, as
  * mixq_quant_fused does; so is a map when the row's fp16 image does not fit the default 64 KB of LDS (K > 30000).  A producing GEMM reads only the bit words
  * (mixq_gemm_i8_fused_amax).  mixq_linear_forward takes this route when args->col_mask is set. */
-int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
+/* map_words: the number of int32 words the caller's map holds.  It must be at least mixq_kept_map_words(K) and the map 16-byte aligned,
+ * else MIXQ_EINVAL: the layout grew in round 5 (the per-column AND-masks behind the bit words), and a buffer in the older, shorter layout
+ * handed to these kernels would be read up to 2 K bytes past its end (the entry points that take a map all carry this argument -
+ * mixq_quant_known_amax, mixq_rmsnorm_quant_fused_masked, mixq_linear_args::col_mask_words). */
+int mixq_kept_map_words(int K);
+int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask, int map_words,
                             uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                             int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
 
@@ -218,7 +223,7 @@ int mixq_gemm_i8_fused_amax(const int8_t* q_x, const int8_t* q_w, const uint16_t
                             uint32_t* row_amax, const uint32_t* col_mask, mixq_stream_t stream);
 int mixq_gemm_amax_supported(int M, int N, int K, int layout);
 int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint32_t* row_amax,
-                          const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
+                          const uint32_t* col_mask, int map_words, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag,
                           int M, int K, int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream);
 
 /* ---- the whole forward of a frozen layer in ONE call ---------------------------------------------------------
@@ -244,6 +249,7 @@ typedef struct mixq_linear_args {
     uint16_t* y; int ldy;
     int M, N, K, bit; float sigma; int act, qfmt, wfmt;
     uint32_t* row_amax; const uint32_t* col_mask;   /* row_amax non-NULL: the rows' maxima are known (mixq_quant_known_amax runs instead) */
+    int col_mask_words;                             /* int32 words behind col_mask: >= mixq_kept_map_words(K) (checked whenever col_mask is used) */
 } mixq_linear_args;
 int mixq_linear_forward(const mixq_linear_args* args, mixq_stream_t stream);
 
@@ -284,7 +290,7 @@ int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weight, uint16_t
                              mixq_stream_t stream);
 /* ... with the next layer's kept outlier map (layout: mixq_quant_fused_masked): same bytes out */
 int mixq_rmsnorm_quant_fused_masked(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
-                                    const int32_t* n_dev, const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out,
+                                    const int32_t* n_dev, const uint32_t* col_mask, int map_words, uint16_t* x_scale, void* q, uint16_t* x_out,
                                     int32_t* flag, int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma,
                                     int qfmt, mixq_stream_t stream);
 

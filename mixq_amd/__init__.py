@@ -9,9 +9,10 @@ from .config import MixqConfig
 from .cache import MixLibCache, MLPCache
 from .linear import MixLinear_GEMM, MixQLinear, pack_to_i4, two_compl, unpack_int8_to_int4
 from . import mixlib
+from .mixlib import ShimConfig
 from .fused import FasterTransformerRMSNorm, MixLlamaMLP
 from . import checkpoint
 
 __all__ = ["MixqConfig", "MixLinear_GEMM", "MixQLinear", "MixLibCache", "MLPCache", "pack_to_i4", "two_compl", "unpack_int8_to_int4",
-           "mixlib", "FasterTransformerRMSNorm", "MixLlamaMLP", "checkpoint"]
+           "mixlib", "ShimConfig", "FasterTransformerRMSNorm", "MixLlamaMLP", "checkpoint"]
 __version__ = "0.1.0"

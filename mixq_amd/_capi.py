@@ -61,7 +61,8 @@ SIGNATURES = {
     "mixq_find_row_scale": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mixq_extract_outliers_zero": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
     "mixq_quant_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
-    "mixq_quant_fused_masked": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "mixq_quant_fused_masked": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "mixq_kept_map_words": [_I],
     "mixq_detect_outlier_cols": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
     "mixq_dequant_weight_cols": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "mixq_gemm_i8_fused": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -83,7 +84,7 @@ SIGNATURES = {
     "mixq_gemm_pick_split": [_I, _I, _I, _I, _I, _P, _P],
     "mixq_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "mixq_rmsnorm_quant_fused": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
-    "mixq_rmsnorm_quant_fused_masked": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
+    "mixq_rmsnorm_quant_fused_masked": [_P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _P],
     "mixq_pack_w8a16": [_P, _P, _I, _I, _P],
     "mixq_gemm_w8a16": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mixq_gemm_w8a16_set_config": [_I],
@@ -94,7 +95,7 @@ SIGNATURES = {
     "mixq_linear_forward": [_P, _P],
     "mixq_gemm_i8_fused_amax": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "mixq_gemm_amax_supported": [_I, _I, _I, _I],
-    "mixq_quant_known_amax": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "mixq_quant_known_amax": [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
 }
 RESTYPES = {"mixq_gemm_workspace_bytes": C.c_longlong}
 
@@ -108,7 +109,7 @@ class LinearArgs(C.Structure):
                 ("addend", _P), ("lda", _I), ("bias", _P),
                 ("y", _P), ("ldy", _I),
                 ("M", _I), ("N", _I), ("K", _I), ("bit", _I), ("sigma", _F), ("act", _I), ("qfmt", _I), ("wfmt", _I),
-                ("row_amax", _P), ("col_mask", _P)]
+                ("row_amax", _P), ("col_mask", _P), ("col_mask_words", _I)]
 
 _lib = None
 

@@ -90,15 +90,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // qmax (127, 7), fp16(RN(amax * RN(1 / qmax))) is the same fp16 value (checked exhaustively: tests/test_oracle_golden.py) - one multiply
 // instead of a ~10-instruction IEEE division on every row's critical path (maximum -> scale -> quantise).
 __device__ __forceinline__ uint16_t mixq_row_scale(float amax, float qmax) { return f2h(amax * (1.0f / qmax)); }
-// 1 / s for the per-value products of quant_exact / quant8_exact below.  MIXQ_RCP_APPROX: v_rcp_f32 (1 ulp) instead of the IEEE division -
-// the exactness argument below has the slack (t within 3.5e-5 of x / s, needed < 6e-5) and the exhaustive self-test is the judge.
-__device__ __forceinline__ float mixq_rcp_scale(float s) {
-#ifdef MIXQ_RCP_APPROX
-    return s > 0.f ? __builtin_amdgcn_rcpf(s) : 0.f;
-#else
-    return s > 0.f ? __fdiv_rn(1.0f, s) : 0.f;
-#endif
-}
+// 1 / s for the per-value products of quant_exact / quant8_exact below: the IEEE division.  (v_rcp_f32, 1 ulp, passes the exhaustive self-test
+// too - the exactness argument below has the slack: t within 3.5e-5 of x / s, needed < 6e-5 - and changed no timing in round 5: not taken.)
+__device__ __forceinline__ float mixq_rcp_scale(float s) { return s > 0.f ? __fdiv_rn(1.0f, s) : 0.f; }
 
 // q = clamp(rint(x / s), +-QMAX) with the fp32 IEEE quotient rounded half-to-even (the convention of the oracle's
 // find_row_scale), WITHOUT a division per element.  x is an fp16 value, s an fp16 scale (both exact in fp32), rs = 1/s.

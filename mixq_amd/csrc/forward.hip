@@ -25,10 +25,10 @@ extern "C" int mixq_linear_forward(const mixq_linear_args* a, mixq_stream_t stre
     const bool outl = a->n_cap > 0 && a->x_out && a->w_out;
     if (a->n_cap > 0 && !outl) return MIXQ_EINVAL;                  // known outlier columns need both operands of the tail
     int rc = a->row_amax
-        ? mixq_quant_known_amax(a->x, a->ind, a->n_cap, a->n_dev, a->row_amax, a->col_mask, a->x_scale, a->q_x, a->x_out, a->flag, a->M,
+        ? mixq_quant_known_amax(a->x, a->ind, a->n_cap, a->n_dev, a->row_amax, a->col_mask, a->col_mask_words, a->x_scale, a->q_x, a->x_out, a->flag, a->M,
                                 a->K, a->ldx, a->ldxo, a->bit, a->sigma, a->qfmt, stream)
         : (a->col_mask && a->n_cap > 0         // a frozen layer keeps the mask of its outlier columns: no mask build in front of the row maximum
-           ? mixq_quant_fused_masked(a->x, a->ind, a->n_cap, a->n_dev, a->col_mask, a->x_scale, a->q_x, a->x_out, a->flag, a->M, a->K, a->ldx,
+           ? mixq_quant_fused_masked(a->x, a->ind, a->n_cap, a->n_dev, a->col_mask, a->col_mask_words, a->x_scale, a->q_x, a->x_out, a->flag, a->M, a->K, a->ldx,
                                      a->ldxo, a->bit, a->sigma, a->qfmt, stream)
            : mixq_quant_fused(a->x, a->ind, a->n_cap, a->n_dev, a->x_scale, a->q_x, a->x_out, a->flag, a->M, a->K, a->ldx, a->ldxo,
                               a->bit, a->sigma, a->qfmt, stream));

@@ -1060,6 +1060,45 @@ extern "C" int mixq_dequant(const int32_t* y32, int ldy32, const uint16_t* x_sca
 // Config ids: [0, NUM_CFGS) data-parallel tilings of this file, then the stream-K forms, "decode32", then the
 // weights-in-registers tilings of gemm_wreg.hip (MIXQ_FMT_F16X64 operands only).
 static int total_configs() { return NUM_CFGS + mixq_sk_num_configs() + 1 + mixq_wr_num_configs(); }
+
+// ---- per-device registry: the hand-off workspace (stream-K / pairwise split-K: tuning build) and the CU count -------------------------
+namespace {
+constexpr int MIXQ_MAX_DEV = 64;
+MixqDevState g_dev_state[MIXQ_MAX_DEV] = {};
+}
+MixqDevState* mixq_dev_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MIXQ_MAX_DEV) { (void)hipGetLastError(); return nullptr; }
+    return &g_dev_state[dev];
+}
+int mixq_num_cus() {
+    MixqDevState* d = mixq_dev_state();
+    if (!d) return 256;
+    if (d->num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess || p.multiProcessorCount <= 0) { (void)hipGetLastError(); return 256; }
+        d->num_cu = p.multiProcessorCount;
+    }
+    return d->num_cu;
+}
+bool mixq_ws_get(void** ws, size_t* bytes, size_t* flag_bytes) {
+    MixqDevState* d = mixq_dev_state();
+    if (!d || !d->ws) return false;
+    *ws = d->ws; *bytes = d->bytes; *flag_bytes = MIXQ_WS_FLAG_BYTES;
+    return true;
+}
+// (the product library hands no tile through memory: the registration is accepted so that callers of the C ABI need not care which build they link)
+extern "C" int mixq_gemm_set_workspace(void* ws, long long bytes)
+{
+    if (bytes < 0 || (bytes > 0 && !ws)) return MIXQ_EINVAL;
+    MixqDevState* d = mixq_dev_state();                  // the workspace belongs to the device that is current at registration
+    if (!d) return MIXQ_ENODEV;
+    d->ws = bytes ? ws : nullptr;
+    d->bytes = static_cast<size_t>(bytes);
+    return MIXQ_OK;
+}
+extern "C" long long mixq_gemm_workspace_bytes(void) { return mixq_sk_workspace_bytes(); }   // (0 in the product library)
 extern "C" int mixq_gemm_set_config(int cfg) {
     if (cfg < -2 || cfg >= total_configs()) return MIXQ_EINVAL;            // (-1: automatic; -2: automatic without the N split - the A/B partner of tools/prefill_sweep.py)
     g_forced_cfg.set(cfg);

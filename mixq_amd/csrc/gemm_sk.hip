@@ -20,6 +20,7 @@
 // The workspace (G slots of BM*BN int32 + G flags) is provided by the host once, zero-initialised
 // (mixq_gemm_set_workspace); launches that use it must be serialised on one stream.
 #include "common.h"
+#include "gemm_sk.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,9 +29,12 @@
 // Round 5: the kernels of this file are compiled into the TUNING build only (make tuning -> libmixq_hip_tuning.so).  The automatic choice
 // never picked them since round 2, and the one place where a stream-K schedule had something to offer - the partial last round of tiles at
 // prefill sizes - is covered by the N split of the data-parallel kernels (gemm_wreg.hip: mixq_wr_split; profiles/r05_prefill_sweep.txt).
-// The product library keeps the workspace registration (a no-op there) so that callers of the C ABI need not care which build they link.
+// Round 6: this file is a source of the tuning build ONLY (csrc/Makefile: TSRCS); the product library does not compile it - the workspace
+// registration its callers may still make lives in gemm.hip, the entry points below are inline stubs there (gemm_sk.h).
+#ifndef MIXQ_TUNING
+#error "gemm_sk.hip belongs to the tuning build (make tuning): the product library does not contain the stream-K kernels"
+#endif
 namespace {
-#ifdef MIXQ_TUNING
 
 struct SkArgs {
     const uint8_t* qx;  const uint8_t* qw;
@@ -440,39 +444,17 @@ const SkConfig g_sk[] = {
 };
 constexpr int NUM_SK = sizeof(g_sk) / sizeof(g_sk[0]);
 
-// per-device state (one process may drive several GPUs): the registered workspace and the CU count of the CURRENT device
-#endif  // MIXQ_TUNING
-constexpr int SK_MAX_DEV = 64;
-struct SkDev { void* ws; size_t bytes; int num_cu; };
-SkDev g_dev[SK_MAX_DEV] = {};
-SkDev* sk_dev() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SK_MAX_DEV) { (void)hipGetLastError(); return nullptr; }
-    return &g_dev[dev];
-}
-
 }  // namespace
 
-// Workspace layout: SK_FLAG_BYTES of int32 flags (zero on entry; every launch leaves them zero), then [G slots][BM*BN int32].  The
-// flags sit at a FIXED place: behind the slots their offset would depend on the configuration's tile size, and one configuration's
-// partial tiles would land on another one's flag words (a finisher of the next launch of the smaller tiling then reads a slot before
-// its contributor wrote it).
-constexpr size_t SK_FLAG_BYTES = 4096;                   // up to 1024 workgroups
-#ifdef MIXQ_TUNING
 int mixq_sk_num_configs() { return NUM_SK; }
 const char* mixq_sk_config_name(int c) { return (c >= 0 && c < NUM_SK) ? g_sk[c].name : ""; }
-size_t mixq_sk_workspace_need(int c, int G) { return SK_FLAG_BYTES + static_cast<size_t>(G) * g_sk[c].bm * g_sk[c].bn * 4; }
+size_t mixq_sk_workspace_need(int c, int G) { return MIXQ_WS_FLAG_BYTES + static_cast<size_t>(G) * g_sk[c].bm * g_sk[c].bn * 4; }
 
 bool mixq_sk_usable(int c) {
-    SkDev* d = sk_dev();
+    MixqDevState* d = mixq_dev_state();
     if (c < 0 || c >= NUM_SK || !d || !d->ws) return false;
-    if (d->num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-        d->num_cu = p.multiProcessorCount;
-    }
-    return d->num_cu > 0 && mixq_sk_workspace_need(c, d->num_cu) <= d->bytes;
+    const int cus = mixq_num_cus();
+    return cus > 0 && mixq_sk_workspace_need(c, cus) <= d->bytes;
 }
 
 int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
@@ -491,13 +473,14 @@ int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     a.xrows16 = (M + 15) & ~15; a.wrows16 = (N + 15) & ~15;
     a.nk = KB / BKB;
     a.total_units = a.tiles_m * a.tiles_n * a.nk;
-    SkDev* d = sk_dev();
-    a.G = d->num_cu < a.total_units ? d->num_cu : a.total_units;
+    MixqDevState* d = mixq_dev_state();
+    const int cus = mixq_num_cus();
+    a.G = cus < a.total_units ? cus : a.total_units;
     if (const char* e = getenv("MIXQ_SK_G")) { const int g2 = atoi(e); if (g2 > 0 && g2 <= a.G) a.G = g2; }     // tuning only
     if (const char* e = getenv("MIXQ_SK_DBG")) a.dbg = atoi(e);
     a.flags = static_cast<int32_t*>(d->ws);
-    a.ws = reinterpret_cast<int32_t*>(static_cast<char*>(d->ws) + SK_FLAG_BYTES);
-    if (static_cast<size_t>(a.G) * 4 > SK_FLAG_BYTES) return MIXQ_EINVAL;
+    a.ws = reinterpret_cast<int32_t*>(static_cast<char*>(d->ws) + MIXQ_WS_FLAG_BYTES);
+    if (static_cast<size_t>(a.G) * 4 > MIXQ_WS_FLAG_BYTES) return MIXQ_EINVAL;
     void (*k)(const SkArgs) = bit == 8 ? g.k8 : g.k4;
     const size_t shm = static_cast<size_t>(g.bm + g.bn) * BKB * g.nstage;
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
@@ -505,39 +488,9 @@ int mixq_sk_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     return mixq_launch_status();
 }
 
-#else
-int mixq_sk_num_configs() { return 0; }
-const char* mixq_sk_config_name(int) { return ""; }
-size_t mixq_sk_workspace_need(int, int) { return 0; }
-bool mixq_sk_usable(int) { return false; }
-int mixq_sk_launch(int, int, const void*, const void*, const uint16_t*, const uint16_t*, const uint16_t*, int, const uint16_t*, int, int, const int32_t*,
-                   const uint16_t*, int, const uint16_t*, uint16_t*, int, int, int, int, int, hipStream_t) { return MIXQ_EINVAL; }
-#endif
-bool mixq_ws_get(void** ws, size_t* bytes, size_t* flag_bytes) {
-    SkDev* d = sk_dev();
-    if (!d || !d->ws) return false;
-    *ws = d->ws; *bytes = d->bytes; *flag_bytes = SK_FLAG_BYTES;
-    return true;
-}
-
-extern "C" int mixq_gemm_set_workspace(void* ws, long long bytes)
-{
-    if (bytes < 0 || (bytes > 0 && !ws)) return MIXQ_EINVAL;
-    SkDev* d = sk_dev();                                 // the workspace belongs to the device that is current at registration
-    if (!d) return MIXQ_ENODEV;
-    d->ws = bytes ? ws : nullptr;
-    d->bytes = static_cast<size_t>(bytes);
-    return MIXQ_OK;
-}
-
-extern "C" long long mixq_gemm_workspace_bytes(void)
-{
-#ifdef MIXQ_TUNING
-    // enough for every stream-K configuration on a 256-CU part: 256 slots of the largest tile + flags
+// enough for every stream-K configuration on a 256-CU part: 256 slots of the largest tile + flags
+long long mixq_sk_workspace_bytes() {
     size_t need = 0;
     for (int c = 0; c < NUM_SK; ++c) { const size_t n = mixq_sk_workspace_need(c, 256); if (n > need) need = n; }
     return static_cast<long long>(need);
-#else
-    return 0;                                            // no form of the product library hands tiles through memory
-#endif
 }

@@ -63,9 +63,7 @@ struct WrArgs {
 constexpr int WR_CW = 4;
 // every lambda of the kernels below is force-inlined: at 256-row tiles their bodies are big enough for the inliner to leave them as
 // functions, and a by-reference capture of the accumulator array behind a real call puts the whole frame in scratch memory
-#ifndef MIXQ_XR
-#define MIXQ_XR 4                                                              // FP6 form: activation tuples held per wave (window)
-#endif
+constexpr int MIXQ_XR = 4;                                                     // FP6 form: activation tuples held per wave (window)
 #define MIXQ_INL __attribute__((always_inline))                              // consumer waves, 1 x 4 along N
 
 template <int N> __device__ __forceinline__ void wr_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -87,17 +85,11 @@ template <int I, int N, class F> __device__ __forceinline__ void wr_static_for(F
 // 1 no weight loads, 2 no X traffic (no DMA, no LDS reads), 3 MFMA only, 4 weight loads issued but never waited for, 5 the loader
 // never waits for its DMA, 6 no k-loop barriers (4-6: timing probes, results are garbage), 7 no stores of Y, 8 ordinary instead of
 // nt stores, 9 return at entry, 12 no prologue ramp in the loader.
-#ifndef MIXQ_Y_ST
-#define MIXQ_Y_ST 2                         // cache policy of the stores of Y (buffer-store aux bits): 2 = nt (streaming), 16 = sc1 (write-through), 18 = both, 0 = ordinary (A/B build switch)
-#endif
-#ifndef MIXQ_Y_WT_MB
-#define MIXQ_Y_WT_MB 4                      // tiles of at most this many 16-row blocks store Y write-through (sc1 | nt): the layers they serve write a few MB of Y in ONE round of
+constexpr int MIXQ_Y_ST = 2;                // cache policy of the stores of Y (buffer-store aux bits): 2 = nt (streaming), 16 = sc1 (write-through), 18 = both, 0 = ordinary
+constexpr int MIXQ_Y_WT_MB = 4;             // tiles of at most this many 16-row blocks store Y write-through (sc1 | nt): the layers they serve write a few MB of Y in ONE round of
                                             // tiles, and lines written through during the epilogue are not left for the kernel's closing release to write back: -0.1 ... -0.25 us per launch at
-                                            // N = 4096 / small batches, nothing at the metric tile, +0.6 % at 2048 tokens if the big tiles did it too (profiles/r05_y_store_policy_ab.txt)
-#endif
-#ifndef MIXQ_PAIR_ST
-#define MIXQ_PAIR_ST 2                      // cache policy of the joint gate / up form's stores of Y: 2 = nt (streaming), 0 = ordinary (A/B build switch)
-#endif
+                                            // N = 4096 / small batches, nothing at the metric tile, +0.6 % at 2048 tokens if the big tiles did it too (NOTEBOOK.md round 5)
+constexpr int MIXQ_PAIR_ST = 2;             // cache policy of the joint gate / up form's stores of Y: 2 = nt (streaming), 0 = ordinary
 template <int MB, int WNB, int NSTAGE, int D, int Q, int LOADERS, int ABL>
 __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const WrArgs a)
 {
@@ -127,12 +119,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // WRAP: every k-step requests weights unconditionally - past the end of K the requests wrap around to the first k-steps (valid
     // addresses, never consumed, drained behind the loop) - so the last D + NSLOT k-steps need no conditional loads and no run-time wait
     // tables.  The tuple-ring FP6 form and the int8 form of the shipped loop: -0.8 ... -3.2 % over the BASELINE shapes between two product
-    // builds (-1.3 % at the metric shape; profiles/r03_ab_wrap_tail.txt; -DMIXQ_NO_WRAP_TAIL builds the other one).
-#ifdef MIXQ_NO_WRAP_TAIL
-    constexpr bool WRAP = F6R || ABLK == 41;
-#else
+    // builds (-1.3 % at the metric shape; profiles/r03_ab_wrap_tail.txt).
     constexpr bool WRAP = F6R || ABLK == 41 || (Q == 0 && (ABLK == 0 || ABLK == 6 || (ABLK >= 60 && ABLK < 80)) && LOADERS != 0);
-#endif
     constexpr int BLK = F6 ? 1536 : 1024;                // bytes of one 16-row operand block of one k-step
     constexpr int STAGE_BYTES = MB * BLK;
     constexpr int LOOK = NSTAGE - 2, NEWER = LOOK - 1;
@@ -914,11 +902,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                         __builtin_amdgcn_sched_barrier(0);
                         continue;
                     }
-#ifdef MIXQ_R2_ORDER                                 // (a second product build with round 2's order, for tools/ab_libs.py; never shipped)
-                    constexpr bool NEW_ORDER = false;
-#else
-                    constexpr bool NEW_ORDER = ABLK != 31;
-#endif
+                    constexpr bool NEW_ORDER = ABLK != 31;                        // (31, tuning build: round 2's order)
                     if constexpr (NEW_ORDER) {
                         // At most ONE memory instruction per MFMA gap: a wave issues in order and a 16-cycle MFMA leaves ~12 cycles in
                         // which one fragment read or one weight load can be issued for free.  The weight load goes behind the group's
@@ -1410,16 +1394,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             // its four waves: tools/ubench_valu.hip).  (The empty asm statements pin a piece HERE: left alone, the compiler sinks the
             // multiplications down to their first use, where nothing overlaps them.)  With optional terms (SiLU, bias, addend, row maxima)
             // the staging stays behind the panel's MFMAs: its global loads and transcendentals do not fit between two MFMAs.
-            constexpr int SLOTS = TQ * NB;
-            // (staging one panel BEHIND, its conversions and LDS writes between the next panel's MFMAs - MIXQ_EPI_LAG - was built and measured:
+            // (staging one panel BEHIND, its conversions and LDS writes between the next panel's MFMAs, was built and measured in round 4:
             // 24.71 vs 24.50 us, the flags go up a panel later and the loaders start later; the MFMAs of the tail are what the phase waits for,
-            // 0.88 us of the launch in the no-tail ablation, not the LDS writes: 0.06 us.  profiles/r04_epilogue_ablations.txt)
-#ifdef MIXQ_EPI_LAG
-            constexpr bool LAGOK = TQ > 0 && SLOTS >= 2 * WNB;
-#else
-            constexpr bool LAGOK = false;
-#endif
-            const bool lag = LAGOK && !opt && staged;
+            // 0.88 us of the launch in the no-tail ablation, not the LDS writes: 0.06 us.  profiles/r04_epilogue_ablations.txt.  Removed.)
             wr_static_for<0, NPAN + 1>([&](auto p_c) MIXQ_INL {
                 constexpr int pn = decltype(p_c)::value;                         // 0 .. NPAN: MFMAs of panel pn, dequantisation of pn + 1, staging of pn - 1 (lag) or pn
                 if constexpr (pn < NPAN && TQ > 0) {
@@ -1429,19 +1406,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                         if (tail_mode(kk) == 0) continue;                        // (wave-uniform; k-step 0 always runs)
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
-                            const int slot = kk * NB + b;
                             tail_mma(pn * PJ + b / WNB, b % WNB, wo2[kk][b % WNB], xo2[kk][b / WNB]);
                             __builtin_amdgcn_sched_barrier(0);
                             if (pn + 1 < NPAN && kk == 0) {                      // the next panel's blocks, one behind each MFMA of k-step 0
                                 const int d = b, j2 = (pn + 1) * PJ + d / WNB, i2 = d % WNB;
                                 deq(pn + 1, d);
                                 asm volatile("" : "+v"(fa[j2][i2]));
-                            }
-                            if constexpr (LAGOK && pn >= 1) {
-                                // block column c of panel pn - 1 behind slot (2 c + 1) SLOTS / (2 WNB): spread over the panel's MFMAs
-#pragma unroll
-                                for (int c = 0; c < WNB; ++c)
-                                    if (slot == ((2 * c + 1) * SLOTS) / (2 * WNB)) { if (lag) finish_col(std::false_type{}, std::true_type{}, pn - 1, c); }
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -1454,16 +1424,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                         for (int b = 0; b < NB; ++b) deq(pn + 1, b);
                     }
                 }
-                if (lag) {
-                    if constexpr (pn >= 1) {
-                        if constexpr (pn == NPAN) {                              // the last panel: nothing left to hide under
-#pragma unroll
-                            for (int c = 0; c < WNB; ++c) finish_col(std::false_type{}, std::true_type{}, pn - 1, c);
-                        }
-                        stamp2(2 * (pn - 1), 0);
-                        if constexpr (pn - 1 < LP) raise_flag(pn - 1);
-                    }
-                } else {
+                {
                     if constexpr (pn < NPAN) {
                         // (straight-line code per case: the optional terms and the unstaged stores are compile-time switches of finish_col)
                         if constexpr (PAIR) {
@@ -1882,7 +1843,7 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 31, "128x192_p31_r2order"),   // round 2's order: re-read and weight load in the same gap
     MIXQ_WR(8, 3, 16, 4, 2, 30, "128x192_p30_earlyreread"),
     MIXQ_WR(8, 3, 16, 5, 2, 0, "128x192_s16_d5_l2"),
-    MIXQ_WR8(8, 3, 16, 6, 2, "128x192_s16_d6_l2"),        // (deeper weight rings for the cold-weights protocol: tools/ab_gemm.py --cold 8)
+    MIXQ_WR8(8, 3, 16, 6, 2, "128x192_s16_d6_l2"),        // (deeper weight rings for the cold-weights protocol: tools/trace_gemm.py --cold 8)
     MIXQ_WR8(8, 3, 12, 6, 2, "128x192_s12_d6_l2"),
     MIXQ_WR(8, 3, 16, 4, 4, 0, "128x192_s16_d4_l4"),
     MIXQ_WR(8, 3, 16, 4, 2, 25, "128x192_p25_w0first"),
@@ -1918,64 +1879,57 @@ int mixq_wr_set_krot(int v) { return v ? MIXQ_EINVAL : MIXQ_OK; }
 #endif
 const char* mixq_wr_config_name(int c) { return (c >= 0 && c < NUM_WR) ? g_wr[c].name : "?"; }
 
-// Estimated time = rounds over the 256 CUs x (k-steps x time per k-step of one tile + the tile's fixed prologue / epilogue), both
+// Estimated time = rounds over the device's CUs x (k-steps x time per k-step of one tile + the tile's fixed prologue / epilogue), both
 // fitted on an MI355X at M = 512 over the Llama-2-7b / 70b and Llama-3-8B shapes (tools/sweep_gemm.py, profiles/r02_sweep_shapes.txt):
 // per shape this picks the measured winner (64x128 at N = 4096, 64x192 at 6144, 128x128 at 8192, 128x192 at 10-12 k, 128x256 at
-// 14 k and 28 k).
+// 14 k and 28 k).  ONE table for every function below (round 5 had four copies); the CU count is the device's (mixq_num_cus: a
+// partitioned part - CPX mode - has fewer than 256, and whole rounds of ITS compute units are what a launch pays for).
+namespace {
+struct WrCost { int cfg; float tk, fixed; };
+// int8 (and, where a nibble form exists, nibble-packed int4) tilings: us per 64-byte k-step of one tile, fixed us per tile
+const WrCost g_cost8[] = {{0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f},
+                          {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
+// the FP6 form (k-steps of 128 elements, priced per 64 bytes of nibbles like the others): the tilings that exist in it (128 x 256 does not fit the registers)
+const WrCost g_cost6[] = {{0, 0.37f, 10.0f}, {4, 0.304f, 7.5f}, {6, 0.23f, 5.1f}, {7, 0.29f, 5.9f}, {8, 0.35f, 6.5f}};
+template <class F> void wr_for_costs(int bit, F&& f) {
+    if (bit == 6) { for (const auto& c : g_cost6) f(c); } else { for (const auto& c : g_cost8) f(c); }
+}
+double wr_tile_us(int bit, int cfg, int KB) {
+    double t = -1.0;
+    wr_for_costs(bit, [&](const WrCost& c) { if (c.cfg == cfg) t = (KB >> 6) * static_cast<double>(c.tk) + c.fixed; });
+    return t;
+}
+// cheapest tiling among those `ok` admits for (M, N) output tiles over `cus` compute units; *best_us: its estimate
+template <class F> int wr_cheapest(int bit, int M, int N, int KB, int cus, F&& ok, double* best_us = nullptr, double margin = 0.999) {
+    double best = 1e30; int bi = -1;
+    wr_for_costs(bit, [&](const WrCost& c) {
+        const WrConfig& g = g_wr[c.cfg];
+        if (!ok(c.cfg, g)) return;
+        const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
+        const double t = cdiv(tiles, cus) * wr_tile_us(bit, c.cfg, KB);           // (the busiest CU's tiles decide: whole rounds)
+        if (t < best * margin) { best = t; bi = c.cfg; }                          // (margin < 1: a later tiling must be clearly cheaper to displace an earlier one)
+    });
+    if (best_us) *best_us = best;
+    return bi;
+}
+}  // namespace
+
 int mixq_wr_pick(int bit, int M, int N, int KB)
 {
-    if (bit == 6) {
-        if (M <= 32) return WR_SMALL;                    // a weight stream: one 64-channel panel per workgroup (as for int8 below)
-        // FP6 form (k-steps of 128 elements): the tilings that exist in it, priced with the int8 model's shape - until a sweep says
-        // otherwise the tile count decides, as it does for int8
-        static const struct { int cfg; float tk, fixed; } cand6[] = {
-            {0, 0.37f, 10.0f}, {4, 0.304f, 7.5f}, {6, 0.23f, 5.1f}, {7, 0.29f, 5.9f}, {8, 0.35f, 6.5f}};   // (128 x 256 does not fit the registers in this form)
-        const int nk6 = KB >> 6;
-        double best6 = 1e30; int b6 = 0;
-        for (const auto& c : cand6) {
-            const WrConfig& g = g_wr[c.cfg];
-            const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
-            const double t = cdiv(tiles, 256) * (nk6 * static_cast<double>(c.tk) + c.fixed);
-            if (t < best6 * 0.999) { best6 = t; b6 = c.cfg; }
-        }
-        return b6;
-    }
-    if (M <= 32) return WR_SMALL;                        // (narrow layers run the weight-stream kernel of gemm_skinny.hip instead)
-    static const struct { int cfg; float tk, fixed; } cand[] = {
-        {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f},
-        {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
+    if (M <= 32) return WR_SMALL;                        // a weight stream: one 64-channel panel per workgroup (narrow int8 layers run gemm_skinny.hip instead)
+    const int cus = mixq_num_cus();
+    if (bit == 6) return wr_cheapest(6, M, N, KB, cus, [](int, const WrConfig& g) { return g.k6 != nullptr; });
     // few tiles (narrow layer, small batch): when 64-row tiles would occupy at most half the CUs and 32-row tiles still fit one round,
     // the 32 x 64 tiling wins (64 x 4096 -> 4096: 9.9 vs 11.1 us, 128 x 4096 -> 4096: 10.2 vs 11.3 us; profiles/r02_gemm_ab_mid_batch.txt)
-    if (cdiv(M, 32) * cdiv(N, 64) <= 256 && cdiv(M, 64) * cdiv(N, 64) <= 128) return WR_SMALL;
-    const int nk = KB >> 6;
-    double best = 1e30; int bi = 0;
-    for (const auto& c : cand) {
-        const WrConfig& g = g_wr[c.cfg];
-        if (bit == 4 && !g.k4) continue;                 // (tilings without a nibble form)
-        const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
-        const double t = cdiv(tiles, 256) * (nk * static_cast<double>(c.tk) + c.fixed);
-        if (t < best * 0.999) { best = t; bi = c.cfg; }
-    }
-    return bi;
+    if (cdiv(M, 32) * cdiv(N, 64) <= cus && cdiv(M, 64) * cdiv(N, 64) <= cus / 2) return WR_SMALL;
+    return wr_cheapest(bit, M, N, KB, cus, [bit](int, const WrConfig& g) { return bit != 4 || g.k4 != nullptr; });   // (bit 4: tilings with a nibble form)
 }
 
 // The joint gate / up launch (N = the interleaved rows of both layers): the same model over the tilings that have the paired epilogue.
 int mixq_wr_pick_pair(int bit, int M, int N, int KB)
 {
     if (M <= 32) return WR_SMALL;
-    struct Cand { int cfg; float tk, fixed; };
-    static const Cand cand8[4] = {{0, 0.248f, 8.8f}, {5, 0.341f, 7.1f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f}};
-    static const Cand cand6[4] = {{0, 0.37f, 10.0f}, {7, 0.29f, 5.9f}, {8, 0.35f, 6.5f}, {8, 0.35f, 6.5f}};   // (the FP6 forms, priced as in mixq_wr_pick)
-    const Cand (&cand)[4] = bit == 6 ? cand6 : cand8;
-    const int nk = KB >> 6;
-    double best = 1e30; int bi = 0;
-    for (const auto& c : cand) {
-        const WrConfig& g = g_wr[c.cfg];
-        const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
-        const double t = cdiv(tiles, 256) * (nk * static_cast<double>(c.tk) + c.fixed);    // (the busiest CU's tiles decide: whole rounds)
-        if (t < best * 0.999) { best = t; bi = c.cfg; }
-    }
-    return bi;
+    return wr_cheapest(bit == 6 ? 6 : 8, M, N, KB, mixq_num_cus(), [bit](int, const WrConfig& g) { return (bit == 6 ? g.k6p : g.k8p) != nullptr; });
 }
 bool mixq_wr_has_pair(int bit, int c) { return c >= 0 && c < NUM_WR && (bit == 6 ? g_wr[c].k6p : g_wr[c].k8p) != nullptr; }
 int mixq_wr_ksplit_config() { return WR_KSPLIT; }
@@ -1987,9 +1941,7 @@ int mixq_wr_ksplit_ok(int M, int N, int KB)
     const WrConfig& g = g_wr[WR_KSPLIT];
     const int tiles = cdiv(M, g.mb * 16) * cdiv(N, g.wnb * 64);
     if ((KB >> 6) < 2) return MIXQ_ESHAPE;
-    static int cus = 0;
-    if (!cus) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) { (void)hipGetLastError(); return MIXQ_ENODEV; } cus = p.multiProcessorCount; }
-    if (2 * tiles > cus) return MIXQ_ESHAPE;
+    if (2 * tiles > mixq_num_cus()) return MIXQ_ESHAPE;
     void* ws; size_t bytes, fb;
     if (!mixq_ws_get(&ws, &bytes, &fb)) return MIXQ_EINVAL;
     if (static_cast<size_t>(tiles) * 4 > fb || fb + static_cast<size_t>(tiles) * (g.mb * 16) * (g.wnb * 64) * 4 > bytes) return MIXQ_EINVAL;
@@ -1997,69 +1949,42 @@ int mixq_wr_ksplit_ok(int M, int N, int KB)
 }
 // ... and is it the faster choice?  The model of mixq_wr_pick with the MEASURED cost of a k-step when all 256 CUs run 128 x 128 tiles
 // (0.28 us - not the 0.218 us fitted on 128 such tiles over 256 CUs: the part is power-bound, time follows the MFMA work, not the bytes)
-// plus the hand-off (2.9 us, tools/ubench_handoff.hip).  At the shapes it was built for it does not pay: 32.6 vs 28.8 us at 11008 ->
-// 4096, 38.6 vs 35.8 us at 14336 -> 4096 against 64 x 128 (profiles/r03_splitk_ab.txt).  The form stays selectable by configuration.
+// plus the hand-off (2.9 us, r03_handoff_ubench.txt).  At the shapes it was built for it does not pay: 32.6 vs 28.8 us at 11008 ->
+// 4096, 38.6 vs 35.8 us at 14336 -> 4096 against 64 x 128 (profiles/r03_splitk_ab.txt; re-measured in round 6: profiles/r06_splitk_ab.txt).
+// The form stays selectable by configuration (tuning build).
 bool mixq_wr_ksplit_pays(int M, int N, int KB)
 {
     if (M <= 32 || mixq_wr_ksplit_ok(M, N, KB) != MIXQ_OK) return false;
     const int nk = KB >> 6;
     const double t_split = (nk - nk / 2) * 0.28 + 5.5 + 2.9;
-    const WrConfig& g = g_wr[mixq_wr_pick(8, M, N, KB)];
-    static const struct { int cfg; float tk, fixed; } cand[] = {
-        {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f}, {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
     double best = 1e30;
-    for (const auto& c : cand) {
-        const WrConfig& q = g_wr[c.cfg];
-        const int tiles = cdiv(M, q.mb * 16) * cdiv(N, q.wnb * 64);
-        const double t = cdiv(tiles, 256) * (nk * static_cast<double>(c.tk) + c.fixed);
-        if (t < best) best = t;
-    }
-    (void)g;
+    wr_cheapest(8, M, N, KB, mixq_num_cus(), [](int, const WrConfig&) { return true; }, &best, 1.0);
     return t_split < 0.97 * best;
 }
 
-// N split for the last, partial round of tiles.  A launch of T tiles on 256 CUs takes ceil(T / 256) rounds of the tile's time whatever the
-// last round holds: 4096 x 11008 x 4096 on 128 x 256 tiles is 1376 tiles = 5.4 rounds and pays for 6 (profiles/r05_prefill_sweep.txt: 179 us
+// N split for the last, partial round of tiles.  A launch of T tiles on C compute units takes ceil(T / C) rounds of the tile's time whatever the
+// last round holds: 4096 x 11008 x 4096 on 128 x 256 tiles is 1376 tiles = 5.4 rounds of 256 and pays for 6 (profiles/r05_prefill_sweep.txt: 179 us
 // where the vendor's stream-K schedule takes 176).  The same kernels cover it in TWO launches over disjoint ranges of the weight rows: the
 // picked tiling over the columns of its FULL rounds, then whatever tiling the model prices cheapest over the rest (WrArgs::n_begin: the
 // tile map of a launch starts at that row; same image, same Y, no partial tile through memory, results bit-identical).  It pays when the
 // remainder's cheaper tiles save more than the second launch's floor (2.2 us).
-static double wr_tile_us(int bit, int cfg, int KB)
-{
-    static const struct { int cfg; float tk, fixed; } c8[] = {
-        {0, 0.248f, 8.8f}, {4, 0.218f, 5.5f}, {5, 0.341f, 7.1f}, {6, 0.144f, 4.5f}, {7, 0.19f, 4.4f}, {8, 0.235f, 4.4f}, {9, 0.16f, 3.9f}, {10, 0.089f, 1.65f}};
-    static const struct { int cfg; float tk, fixed; } c6[] = {{0, 0.37f, 10.0f}, {4, 0.304f, 7.5f}, {6, 0.23f, 5.1f}, {7, 0.29f, 5.9f}, {8, 0.35f, 6.5f}};
-    const int nk = KB >> 6;
-    if (bit == 6) { for (const auto& c : c6) if (c.cfg == cfg) return nk * static_cast<double>(c.tk) + c.fixed; }
-    else          { for (const auto& c : c8) if (c.cfg == cfg) return nk * static_cast<double>(c.tk) + c.fixed; }
-    return -1.0;
-}
 bool mixq_wr_split(int bit, int M, int N, int KB, int c, int* n1, int* c2)
 {
     if (c < 0 || c >= NUM_WR || c == WR_SMALL || c == WR_KSPLIT || (bit != 8 && bit != 6) || M <= 32) return false;
+    const int cus = mixq_num_cus();
     const WrConfig& g = g_wr[c];
     const int bm = g.mb * 16, bn = g.wnb * 64, tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn), tiles = tiles_m * tiles_n;
-    const int full = tiles / 256;
-    if (full < 1 || tiles % 256 == 0) return false;
-    const int tn1 = full * 256 / tiles_m;                                    // column tiles whose tiles fit the full rounds
+    const int full = tiles / cus;
+    if (full < 1 || tiles % cus == 0) return false;
+    const int tn1 = full * cus / tiles_m;                                    // column tiles whose tiles fit the full rounds
     if (tn1 <= 0 || tn1 >= tiles_n) return false;
     const double T = wr_tile_us(bit, c, KB);
     if (T <= 0) return false;
     const int nrest = N - tn1 * bn;
-    static const int cand8[] = {0, 4, 5, 6, 7, 8, 9, 10}, cand6[] = {0, 4, 6, 7, 8};
-    const int* cand = bit == 6 ? cand6 : cand8;
-    const int ncand = bit == 6 ? 5 : 8;
-    double best = 1e30; int bc = -1;
-    for (int qi = 0; qi < ncand; ++qi) {
-        const int q = cand[qi];
-        const WrConfig& h = g_wr[q];
-        if (bit == 6 && !h.k6) continue;
-        const int t2 = cdiv(M, h.mb * 16) * cdiv(nrest, h.wnb * 64);
-        const double t = cdiv(t2, 256) * wr_tile_us(bit, q, KB);
-        if (t < best) { best = t; bc = q; }
-    }
+    double best = 1e30;
+    const int bc = wr_cheapest(bit, M, nrest, KB, cus, [bit](int, const WrConfig& h) { return bit != 6 || h.k6 != nullptr; }, &best, 1.0);
     if (bc < 0) return false;
-    const double t_single = (full + 1) * T, t_split = cdiv(tn1 * tiles_m, 256) * T + best + 2.2;
+    const double t_single = (full + 1) * T, t_split = cdiv(tn1 * tiles_m, cus) * T + best + 2.2;
     if (t_split >= 0.975 * t_single) return false;
     *n1 = tn1 * bn; *c2 = bc;
     return true;

@@ -284,11 +284,11 @@ extern "C" int mixq_rmsnorm_quant_fused(const uint16_t* x, const uint16_t* weigh
 }
 // ... for a next layer whose prediction is frozen: its kept outlier map (as mixq_quant_fused_masked)
 extern "C" int mixq_rmsnorm_quant_fused_masked(const uint16_t* x, const uint16_t* weight, uint16_t* out, const int32_t* ind, int n,
-                                               const int32_t* n_dev, const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out,
+                                               const int32_t* n_dev, const uint32_t* col_mask, int map_words, uint16_t* x_scale, void* q, uint16_t* x_out,
                                                int32_t* flag, int M, int K, int ldx, int ldout, int ldxo, float eps, int bit, float sigma,
                                                int qfmt, mixq_stream_t stream)
 {
-    if (n > 0 && !col_mask) return MIXQ_EINVAL;
+    if (n > 0 && (!col_mask || map_words < mixq_kept_map_words(K) || (reinterpret_cast<uintptr_t>(col_mask) & 15))) return MIXQ_EINVAL;   // (see mixq_quant_fused_masked)
     return rmsnorm_quant_common(x, weight, out, ind, n, n_dev, n > 0 ? col_mask : nullptr, x_scale, q, x_out, flag, M, K, ldx, ldout, ldxo, eps, bit,
                                 sigma, qfmt, stream);
 }

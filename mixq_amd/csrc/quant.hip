@@ -9,12 +9,6 @@
 // the conventions fixed in include/mixq_hip.h.
 #include "common.h"
 
-#ifdef MIXQ_PAD                                       // (placement experiment: shifts every kernel of this code object by 4 MIXQ_PAD bytes)
-#define MIXQ_STR2(x) #x
-#define MIXQ_STR(x) MIXQ_STR2(x)
-extern "C" __global__ void mixq_pad_kernel(int* p) { asm volatile(".rept " MIXQ_STR(MIXQ_PAD) "\n s_nop 0\n .endr"); if (p) *p = 1; }
-#endif
-
 namespace {
 
 constexpr int QT = 256;                 // threads per row workgroup
@@ -62,27 +56,11 @@ __device__ __forceinline__ void quant_codes8(const uint4& v, float s, float rs, 
 template <int BIT>
 __device__ __forceinline__ void quant_store8(const uint4& v, float s, float rs, void* q, int chunk, int row, int rows16, int fmt) {
     uint32_t ub[8];
-#ifdef MIXQ_OLD_QUANT_ARITH                          // (A/B build switch: round 4's per-value quant_exact)
-    {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ub[2 * i]     = static_cast<uint32_t>(quant_exact<BIT>(h2f(static_cast<uint16_t>(w[i] & 0xffffu)), s, rs) + 0x400000) | 0x4b000000u;
-            ub[2 * i + 1] = static_cast<uint32_t>(quant_exact<BIT>(h2f(static_cast<uint16_t>(w[i] >> 16)), s, rs) + 0x400000) | 0x4b000000u;
-        }
-    }
-#else
     quant8_exact<BIT>(v, s, rs, ub);
-#endif
     if constexpr (BIT == 8) {
         uint2 o;
-#ifdef MIXQ_OLD_QUANT_ARITH
-        o.x = (ub[0] & 0xff) | ((ub[1] & 0xff) << 8) | ((ub[2] & 0xff) << 16) | ((ub[3] & 0xff) << 24);
-        o.y = (ub[4] & 0xff) | ((ub[5] & 0xff) << 8) | ((ub[6] & 0xff) << 16) | ((ub[7] & 0xff) << 24);
-#else
         o.x = quant8_pack4(ub[0], ub[1], ub[2], ub[3]);
         o.y = quant8_pack4(ub[4], ub[5], ub[6], ub[7]);
-#endif
         if (fmt) *reinterpret_cast<uint2*>(static_cast<char*>(q) + packed_offset(fmt, row, chunk * 8, rows16)) = o;
         else     reinterpret_cast<uint2*>(q)[chunk] = o;
     } else if (fmt == MIXQ_FMT_F6X128 || fmt == MIXQ_FMT_R6X128) {   // FP6 codes (include/mixq_hip.h): chunk = elements 8 chunk .. + 7 of the row
@@ -848,18 +826,26 @@ extern "C" int mixq_quant_fused(uint16_t* x, const int32_t* ind, int n, const in
 }
 // ... with the caller's kept outlier map of the live `ind` entries (include/mixq_hip.h: bit words, count word, per-column AND-masks): same
 // bytes out from ONE memory round trip - no in-kernel mask build in front of the row maximum, no dependent gather behind the row load
-extern "C" int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask,
+// int32 words of the kept outlier map of K columns: bit words, the count word, pad to 4 words, K 16-bit AND-masks padded to whole 16-byte chunks
+extern "C" int mixq_kept_map_words(int K) { return K > 0 ? ((((K + 31) >> 5) + 1 + 3) & ~3) + ((K + 7) >> 3) * 4 : 0; }
+// (a map in another layout than this library's - round 4's stopped behind the count word - must not reach the kernels: they read the AND-masks
+// up to 2 K bytes behind the bit words)
+static bool kept_map_ok(const uint32_t* col_mask, int map_words, int K) {
+    return col_mask && map_words >= mixq_kept_map_words(K) && (reinterpret_cast<uintptr_t>(col_mask) & 15) == 0;
+}
+extern "C" int mixq_quant_fused_masked(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, const uint32_t* col_mask, int map_words,
                                        uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K, int ldx, int ldo,
                                        int bit, float sigma, int qfmt, mixq_stream_t stream)
 {
-    if (n > 0 && !col_mask) return MIXQ_EINVAL;
+    if (n > 0 && !kept_map_ok(col_mask, map_words, K)) return MIXQ_EINVAL;
     return quant_fused_common(x, ind, n, n_dev, n > 0 ? col_mask : nullptr, x_scale, q, x_out, flag, M, K, ldx, ldo, bit, sigma, qfmt, stream);
 }
 
 extern "C" int mixq_quant_known_amax(uint16_t* x, const int32_t* ind, int n, const int32_t* n_dev, uint32_t* row_amax,
-                                     const uint32_t* col_mask, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K,
+                                     const uint32_t* col_mask, int map_words, uint16_t* x_scale, void* q, uint16_t* x_out, int32_t* flag, int M, int K,
                                      int ldx, int ldo, int bit, float sigma, int qfmt, mixq_stream_t stream)
 {
+    if (col_mask && K > 0 && !kept_map_ok(col_mask, map_words, K)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && qfmt != MIXQ_FMT_P16X64 && qfmt != MIXQ_FMT_F16X64 && !((qfmt == MIXQ_FMT_F6X128 || qfmt == MIXQ_FMT_R6X128) && bit == 4)) return MIXQ_EINVAL;
     if (qfmt != MIXQ_FMT_PLAIN && (bit == 8 ? K : K / 2) % 64) return MIXQ_ESHAPE;
     if (M < 0 || K <= 0 || n < 0 || (M > 0 && (!x || !x_scale || !q || !row_amax))) return MIXQ_EINVAL;

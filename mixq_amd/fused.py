@@ -55,20 +55,15 @@ class FasterTransformerRMSNorm(nn.Module):
         cache = self.cache
         # the layout and the outlier bookkeeping (capacity-padded `ind`, device-resident count) are the NEXT layer's
         rows = x.numel() // x.shape[-1]                      # (4-bit layers take small batches in another layout than large ones)
-        fmt = nl.x_fmt(rows) if (hasattr(nl, "x_fmt") and hasattr(_backend, "PackOperand")) else 0
+        # (`next_layer` may be another implementation of the operator - anything with `.bit` and `.ind`: it then gets plain operands)
+        ours = isinstance(nl, _L.MixLinear_GEMM)
+        fmt = nl.x_fmt(rows) if ours else 0
         n = int(nl.ind.shape[0])
-        if n and hasattr(nl, "_ind_dev") and hasattr(_backend, "PackOperand"):
-            ind, n_dev = nl._ind_dev()
-        else:
-            ind, n_dev = (nl.ind if n else None), None
-        if hasattr(_backend, "PackOperand"):
-            # (a next layer whose prediction is frozen hands over its kept column mask: no mask build in front of the row maximum)
-            cm = nl._col_mask() if (getattr(getattr(nl, "config", None), "norm_kept_map", True) and n and hasattr(nl, "_col_mask") and not nl.add_outliers) else None
-            q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
-                                               sigma=getattr(cache, "sigma_value", 6.0), fmt=fmt, n_dev=n_dev, col_mask=cm)
-        else:                                                # host stand-in of the CPU tests
-            q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
-                                               sigma=getattr(cache, "sigma_value", 6.0))
+        ind, n_dev = nl._ind_dev() if (n and ours) else ((nl.ind if n else None), None)
+        # (a next layer whose prediction is frozen hands over its kept outlier map: no mask build in front of the row maximum)
+        cm = nl._col_mask() if (ours and n and nl.config.norm_kept_map and not nl.add_outliers) else None
+        q, xo = _backend.RMSNormQuantFused(x, self.weight, output, self.variance_epsilon, ind, cache.x_scale, nl.bit,
+                                           sigma=getattr(cache, "sigma_value", 6.0), fmt=fmt, n_dev=n_dev, col_mask=cm)
         cache.q_xcache = q
         cache.activation_outliers = xo[:, :n] if n else None
         cache.n_dev = n_dev
@@ -118,7 +113,7 @@ class MixLlamaMLP(nn.Module):
 
     def _joint_applies(self, cache):
         up, gate = self.up_proj_, self.gate_proj_
-        if not self.config.joint_gate_up or not getattr(_backend, "PAIR_LAUNCH", False):
+        if not self.config.joint_gate_up or not _backend.PAIR_LAUNCH:
             return False
         if up.bit != gate.bit or up.weight_only or gate.weight_only or up.add_outliers:
             return False
@@ -141,7 +136,7 @@ class MixLlamaMLP(nn.Module):
         j = self._joint
         key = self._joint_key()
         object.__setattr__(self, "_key_now", key)            # (handed to _joint_operands: one identity sweep per forward)
-        if (j is None or j["key"] != key) and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        if (j is None or j["key"] != key) and _L._capturing():
             # the joint image is never BUILT under capture (its packing kernels would be replayed with the graph, and the layers' own
             # images - which that graph is about to address through the two-launch route - would be freed by the build)
             object.__setattr__(self, "_two_launch_captured", True)
@@ -207,8 +202,7 @@ class MixLlamaMLP(nn.Module):
         if j is not None:                                    # the joint image is the only copy of gate_proj's / up_proj's weights: it follows the module
             w = fn(j["wpk"])
             if w is not j["wpk"]:
-                if hasattr(_backend, "set_fmt"):
-                    _backend.set_fmt(w, _L._fmt_of(j["wpk"]))
+                _backend.set_fmt(w, _L._fmt_of(j["wpk"]))
                 j["wpk"], j["key"], j["retired"] = w, None, []   # (the per-channel operands are re-made from the moved layers)
             # (an _apply that moves nothing - model.half() on an fp16 block - leaves the image, its key and the buffers a captured graph
             # addresses alone; changed per-channel tensors show up in the key on the next forward)
@@ -227,12 +221,12 @@ class MixLlamaMLP(nn.Module):
             # a direct call of up_proj / gate_proj since the last joint forward re-packed a private image from the joint one: released
             # here (the block keeps ONE copy of these weights) unless a captured graph addresses it
             d = l._d
-            if d.joint is not None and (d.wpk is not None or d.wpk_small is not None) and not torch.cuda.is_current_stream_capturing() \
+            if d.joint is not None and (d.wpk is not None or d.wpk_small is not None) and not _L._capturing() \
                     and not any(getattr(pl, "captured", False) for pl in d.plans.values()):
                 d.invalidate()
                 d.wpk = d.wpk_key = None
                 d.wpk_small = d.wpk_small_key = None
-        if not j.get("captured") and torch.cuda.is_current_stream_capturing():
+        if not j.get("captured") and _L._capturing():
             j["captured"] = True                             # a graph out there replays the joint image's address (see _apply)
         n = int(up.ind.shape[0])
         xo = wo = n_dev = None
@@ -250,7 +244,7 @@ class MixLlamaMLP(nn.Module):
             xo, wo = _L._wide(xo, n_cap), _L._wide(wo, n_cap)
         extra = {}
         target = None
-        if self.config.fuse_down_amax and up.bit == 8 and down.bit == 8 and down.in_features == N and hasattr(_backend, "amax_supported") and \
+        if self.config.fuse_down_amax and up.bit == 8 and down.bit == 8 and down.in_features == N and \
                 _backend.amax_supported(M, 2 * N, K, _L.FMT_P16X64, _L.FMT_F16X64):
             target = down.amax_target(M, x.device)
             if target is not None:

@@ -30,6 +30,11 @@ from ._capi import ACT_NONE, ACT_SILU, ACT_SILU_MUL, FMT_PLAIN, FMT_P16X64, FMT_
 _backend = _hip_mixlib
 
 
+def _capturing():
+    """Is the current HIP stream being captured into a graph?  (torch.cuda.is_current_stream_capturing raises without a device.)"""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _fmt_of(t):
     return getattr(t, "_mixq_fmt", FMT_PLAIN)
 
@@ -395,9 +400,7 @@ class MixLinear_GEMM(nn.Module):
         if d.wpk is not None:
             moved = fn(d.wpk)
             if moved is not d.wpk:
-                tag = _fmt_of(d.wpk)
-                if hasattr(_backend, "set_fmt"):
-                    _backend.set_fmt(moved, tag)
+                _backend.set_fmt(moved, _fmt_of(d.wpk))
                 d.wpk = moved
         # everything else derived is rebuilt where the module now lives: the image is re-packed from q_weight when that buffer still
         # exists, the small-batch image when such a batch arrives, and the kept argument blocks - which pin the OLD device's tensors and
@@ -450,8 +453,8 @@ class MixLinear_GEMM(nn.Module):
                 # the layer is used on its own again (its MLP block took the joint route before): its own image, from the joint one
                 self._wpk = _backend.PackOperand(self._plain_weight(), self.config.pack_fmt if self.bit == 8 else self.config.pack_fmt4)
             return self._wpk                                             # compacted: the packed image is all there is
-        if qw.shape[1] % 64 or not hasattr(_backend, "PackOperand"):
-            return None
+        if qw.shape[1] % 64:
+            return None                                                  # (plain operands: the LDS-staged kernel's own loads)
         # W4A4: FP6 codes for the FP6 matrix pipe (config.pack_fmt4); as nibbles it stays with the LDS-staged kernel (P16X64 weights), whose
         # nibble expansion hides behind 32-cycle MFMAs, not behind the 16-cycle ones of the weights-in-registers kernel (28.0 vs 32.4 us)
         fmt = self.config.pack_fmt if self.bit == 8 else self.config.pack_fmt4
@@ -500,7 +503,7 @@ class MixLinear_GEMM(nn.Module):
     def amax_target(self, M, device):
         """(row_amax buffer, column mask) a producing GEMM should fill for this layer's next forward of M rows, or None when this
         layer cannot use it (outlier search still running, weight-only).  The buffer is zero when handed out."""
-        if self.weight_only or self.add_outliers or not self.config.one_call_forward or not hasattr(_backend, "amax_supported"):
+        if self.weight_only or self.add_outliers or not self.config.one_call_forward:
             return None
         d = self._d
         # ONE buffer for the layer's lifetime on a device, sized for the largest batch the cache admits (x_scale has one row per
@@ -547,7 +550,7 @@ class MixLinear_GEMM(nn.Module):
         qx = cache.q_xcache
         w = wpk if wpk is not None else self.q_weight
         want = self.x_fmt(M)
-        if _fmt_of(qx) != want and hasattr(_backend, "PackOperand"):
+        if _fmt_of(qx) != want:
             # the producer of q_xcache (e.g. the reference's own fused norm through the mixlib shim) used another layout
             if _fmt_of(qx) != FMT_PLAIN:
                 qx = _backend.UnpackOperand(qx, M)
@@ -594,8 +597,7 @@ class MixLinear_GEMM(nn.Module):
                 id(b.get("scale_col"))) + d["config"].key()
 
     def _build_plan(self, cache, inputs, M):
-        if not hasattr(_backend, "ForwardPlan") or M == 0 or inputs.dtype != torch.float16 or inputs.stride(1) != 1 \
-                or inputs.stride(0) % 8 or not inputs.is_cuda:
+        if M == 0 or inputs.dtype != torch.float16 or inputs.stride(1) != 1 or inputs.stride(0) % 8:
             return None
         wpk = self._packed_weight(M)
         if wpk is None:
@@ -635,8 +637,7 @@ class MixLinear_GEMM(nn.Module):
                 raise RuntimeError(f"MixLinear_GEMM: x has {inputs.shape[1]} columns, the layer {self.in_features} input features")
             if inputs.stride(1) != 1 and M:
                 raise RuntimeError("mixq_amd.mixlib: x must be 2-D with a contiguous last dimension")
-            if not inputs.is_cuda and hasattr(_backend, "ForwardPlan"):
-                raise RuntimeError("mixq_amd.mixlib: expected a GPU (HIP) tensor; there is no CPU fallback")
+            _backend.dev_check(inputs)                       # (a CPU tensor: the product has no CPU path)
             key = self._frozen_key(cache, inputs, M)
             if self._plan_key != key and key in self._plans:
                 self._plan, self._plan_key = self._plans[key], key       # (a batch size seen before, nothing else changed)
@@ -681,12 +682,7 @@ class MixLinear_GEMM(nn.Module):
                 flag.zero_()
             fmt = self.x_fmt(M)
             ind_buf, n_dev = self._ind_dev()
-            if hasattr(_backend, "PackOperand"):
-                cache.q_xcache, xo = _backend.QuantFused(inputs, ind_buf, cache.x_scale, self.bit, self._sigma_f, flag=flag,
-                                                         n_dev=n_dev, fmt=fmt)
-            else:                                            # host stand-in used by the CPU tests (no packed layouts)
-                cache.q_xcache, xo = _backend.QuantFused(inputs, self.ind if n else None, cache.x_scale, self.bit, self._sigma_f,
-                                                         flag=flag)
+            cache.q_xcache, xo = _backend.QuantFused(inputs, ind_buf, cache.x_scale, self.bit, self._sigma_f, flag=flag, n_dev=n_dev, fmt=fmt)
             if n:
                 cache.activation_outliers = xo[:, :n]
             cache.n_dev = n_dev
@@ -747,7 +743,7 @@ class MixLinear_GEMM(nn.Module):
         target = None
         if amax_for is not None and self.bit == 8 and amax_for.in_features == self.out_features:
             wpk = self._packed_weight()
-            if wpk is not None and hasattr(_backend, "amax_supported") and \
+            if wpk is not None and \
                     _backend.amax_supported(M, self.out_features, self.in_features, _fmt_of(cache.q_xcache), _fmt_of(wpk)):
                 target = amax_for.amax_target(M, x.device)
         extra = {} if target is None else {"row_amax": target[0], "col_mask": target[1]}

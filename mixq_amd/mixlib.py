@@ -12,6 +12,9 @@ DetectOutlierCols, DequantWeightCols, FusedLinear), used by mixq_amd.linear.MixL
 """
 from __future__ import annotations
 
+from contextlib import contextmanager
+from dataclasses import dataclass, replace
+
 import torch
 
 from . import _capi
@@ -19,12 +22,16 @@ from ._capi import (ACT_NONE, ACT_SILU, ACT_SILU_MUL, ACT_SILU_PAIR, FMT_PLAIN, 
                     XW_F6X128)
 
 
-def _dev_check(*ts):
+def dev_check(*ts):
+    """Every tensor handed to a kernel lives on the GPU: the product has no CPU path."""
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise RuntimeError("mixq_amd.mixlib: expected a GPU (HIP) tensor; there is no CPU fallback")
+
+
+_dev_check = dev_check
 
 
 def _ptr(t):
@@ -81,11 +88,10 @@ def _layout_bits(x_fmt, w_fmt):
 # ------------------------------------------------------------------------------------------------------------
 # ---- opt-in: packed operands behind the UNCHANGED reference operator -------------------------------------------------
 # The reference's forward treats `cache.q_xcache` and `self.q_weight` as opaque handles between mixlib calls (linear.py:190-283).
-# With set_packed_operands(True), FindRowScale hands back an [M, KB] view of a buffer that really holds the P16X64 image (the
+# With configure(packed_operands=True), FindRowScale hands back an [M, KB] view of a buffer that really holds the P16X64 image (the
 # tag rides on the returned tensor object) and the GEMM entry points use a fragment-order copy of every plain weight they are
 # given (cached per tensor: +1x the weight bytes) - the kernels of the native operator, behind the reference's own code.
 # Off by default: a caller that slices, copies or inspects q_x would lose the tag or read tile-major bytes.
-_packed_operands = False
 _wpacked = {}          # (data_ptr, version, shape) -> (weight, fragment-order copy); the entry pins the weight: see eetq._packed
 
 
@@ -101,22 +107,79 @@ def _check_torch_for_handles():
     if not _warned_torch and not torch.__version__.startswith(_TESTED_TORCH):
         import warnings
         _warned_torch = True
-        warnings.warn(f"mixq_amd.mixlib: the deferred-tensor switches (set_lazy_gemm / set_packed_operands / set_fused_outliers / "
-                      f"set_fused_prepass) were tested with torch {_TESTED_TORCH}.x; this is torch {torch.__version__}", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"mixq_amd.mixlib: the deferred-tensor switches (mixlib.configure: lazy_gemm / packed_operands / fused_outliers / "
+                      f"fused_prepass) were tested with torch {_TESTED_TORCH}.x; this is torch {torch.__version__}", RuntimeWarning, stacklevel=3)
 
 
-def set_packed_operands(enabled):
-    if enabled:
+@dataclass(frozen=True)
+class ShimConfig:
+    """How this module serves the reference's UNCHANGED call sequence - ONE object, handed over once by the
+    maintainer who binds the module (`mixlib.configure(...)` next to `sys.modules["mixlib"] = mixq_amd.mixlib`), instead of round 5's
+    four independent module switches.  Every field keeps every result the reference's own Python observes; the caveat of each is why it
+    is a choice:
+
+      lazy_gemm        `gemm` returns a deferred int32 product (PendingGemmI32) so that the reference's `gemm` + `dequantizeInt8[Silu]` pair
+                       (its arch == 9 route, which gfx950 takes: linear.py:232-241) runs as ONE fused launch; any other use of the handle
+                       computes the exact int32 product first.  ON by default: the only consumer that could see uncomputed storage is a
+                       foreign C++ extension taking the at::Tensor, and the reference has none on this path.
+      packed_operands  FindRowScale hands back q_x as an [M, KB] view of a tile-major (P16x64) buffer, weights are re-tiled once into
+                       fragment order (+1x the weight bytes, cached per storage).  Off by default: a caller that slices or copies q_x
+                       loses the tag.
+      fused_outliers   the `torch.mm(activation_outliers, weight_cache.T)` of linear.py:236,248 becomes the fp16 MFMA tail of the GEMM.
+                       Off by default because ONE rounding changes (the literal route rounds the product to fp16 first: <= 2 fp16 ulp).
+      fused_prepass    (needs fused_outliers) ExtractOutliersAndSetToZeros + FindRowScale on the same tensor run as the one-pass kernel.
+                       Off by default: code that READS x between the two calls would still see the outlier columns unzeroed.
+    All three opt-ins on = the native operator's speed behind the reference's own code (profiles/r05_arch9_route.txt)."""
+    lazy_gemm: bool = True
+    packed_operands: bool = False
+    fused_outliers: bool = False
+    fused_prepass: bool = False
+
+    @classmethod
+    def fastest(cls):
+        return cls(lazy_gemm=True, packed_operands=True, fused_outliers=True, fused_prepass=True)
+
+    @classmethod
+    def literal(cls):
+        """Every reference call = the kernel of that name, nothing deferred (the debugging route)."""
+        return cls(lazy_gemm=False)
+
+
+_cfg = ShimConfig()
+
+
+def configure(config=None, **fields):
+    """Install the shim's configuration (a ShimConfig, and / or single fields by name) and return the previous one:
+        mixlib.configure(mixlib.ShimConfig.fastest())        # once, where the module is bound
+        prev = mixlib.configure(fused_outliers=True); ...; mixlib.configure(prev)
+    A deferred extraction still pending under the old configuration runs first; caches that only serve a switched-off route are dropped."""
+    global _cfg
+    new = replace(config if config is not None else _cfg, **fields)
+    if new.fused_prepass and not new.fused_outliers:
+        raise ValueError("mixlib.configure: fused_prepass needs fused_outliers (the outlier tensor must be one of the shim's)")
+    if new.packed_operands or new.fused_outliers or new.fused_prepass or (new.lazy_gemm and not ShimConfig().lazy_gemm):
         _check_torch_for_handles()
-    global _packed_operands
-    prev, _packed_operands = _packed_operands, bool(enabled)
-    if not enabled:
+    _flush_pending_extract()
+    prev, _cfg = _cfg, new
+    if not new.packed_operands:
         _wpacked.clear()
+    if not new.fused_outliers:
+        _wo_padded.clear()
     return prev
 
 
+@contextmanager
+def configured(config=None, **fields):
+    """`with mixlib.configured(fused_outliers=True): ...` - a scoped configure (tests, tools)."""
+    prev = configure(config, **fields)
+    try:
+        yield _cfg
+    finally:
+        configure(prev)
+
+
 def _weight_for_gemm(q_w, bit):
-    if not _packed_operands or fmt_of(q_w) != FMT_PLAIN or q_w.dim() != 2 or q_w.shape[1] % 64 or not q_w.is_contiguous():
+    if not _cfg.packed_operands or fmt_of(q_w) != FMT_PLAIN or q_w.dim() != 2 or q_w.shape[1] % 64 or not q_w.is_contiguous():
         return q_w
     key = (q_w.data_ptr(), q_w._version, tuple(q_w.shape))
     e = _wpacked.get(key)
@@ -148,14 +211,14 @@ def FindRowScale(x, x_scale, M, K, bit=8):
         if same:                                             # extract + zero + scale + quantise in ONE pass (the native operator's kernel)
             _pending_extract = None
             pend.__dict__.pop("_mixq_pending", None)
-            packed = _packed_operands and M > 0 and KB % 64 == 0
+            packed = _cfg.packed_operands and M > 0 and KB % 64 == 0
             q = torch.empty((packed_rows(M) if packed else M, KB), dtype=dt, device=x.device)
             with torch._C.DisableTorchFunctionSubclass():
                 _capi.call("mixq_quant_fused", xp, ind_p.data_ptr(), ind_p.numel(), None, x_scale.data_ptr(), q.data_ptr(), pend.data_ptr(),
                            None, M, K, ldx, ldo_p, bit, 6.0, FMT_P16X64 if packed else FMT_PLAIN, _stream())
             return set_fmt(q[:M], FMT_P16X64) if packed else q
         _flush_pending_extract()
-    if _packed_operands and M > 0 and KB % 64 == 0:
+    if _cfg.packed_operands and M > 0 and KB % 64 == 0:
         buf = torch.empty((packed_rows(M), KB), dtype=dt, device=x.device)
         _capi.call("mixq_find_row_scale", xp, x_scale.data_ptr(), buf.data_ptr(), M, K, ldx, bit, FMT_P16X64, _stream())
         return set_fmt(buf[:M], FMT_P16X64)              # same storage, same base pointer: an opaque handle of the reference's shape
@@ -167,24 +230,13 @@ def FindRowScale(x, x_scale, M, K, bit=8):
 # ---- opt-in: the outlier product fused into the GEMM behind the UNCHANGED reference operator ------------------------------
 # The reference computes `outliers_fp16 = torch.mm(cache.activation_outliers, self.weight_cache.T)` (linear.py:236,248) - an [M,N] fp16
 # tensor written by one kernel and read back as the addend of the next - where the native operator runs the same product as the fp16
-# MFMA tail of the int8 GEMM.  With set_fused_outliers(True) ExtractOutliersAndSetToZeros returns its (real) [M,n] tensor as an
+# MFMA tail of the int8 GEMM.  With configure(fused_outliers=True) ExtractOutliersAndSetToZeros returns its (real) [M,n] tensor as an
 # OutlierActivations; torch.mm / matmul / @ of THAT tensor with a transposed fp16 [N,n] matrix yields a PendingOutlierProduct: an [M,N]
 # fp16 tensor whose values are only computed if something other than a mixlib GEMM entry point looks at them.  The GEMM entry points
 # take the two factors as their outlier operands instead.  Off by default because it changes one rounding: the literal route rounds
 # the product to fp16 before it is added (torch.mm), the fused tail adds it in fp32 like the native operator (include/mixq_hip.h,
 # convention 2; <= 2 fp16 ulp apart).
-_fused_outliers = False
 _wo_padded = {}        # (data_ptr, version, shape, stride) -> (weight_cache view, copy with a 16-column-padded pitch); pins its source
-
-
-def set_fused_outliers(enabled):
-    if enabled:
-        _check_torch_for_handles()
-    global _fused_outliers
-    prev, _fused_outliers = _fused_outliers, bool(enabled)
-    if not enabled:
-        _wo_padded.clear()
-    return prev
 
 
 def _pad16(n):
@@ -193,23 +245,13 @@ def _pad16(n):
 
 # ---- opt-in: extract + quantise as ONE pass behind the reference's two calls ----------------------------------------------
 # The reference calls ExtractOutliersAndSetToZeros(ind, x) and then FindRowScale(x, ...) on the same tensor (linear.py:189-193):
-# two kernels, two passes over X, two launch floors.  With set_fused_prepass(True) (needs set_fused_outliers(True): the outlier
+# two kernels, two passes over X, two launch floors.  With configure(fused_prepass=True) (needs configure(fused_outliers=True): the outlier
 # tensor must be one of ours) the first call only allocates its result and remembers (ind, x); FindRowScale on that same x then runs
 # the native operator's fused kernel, which gathers, zeroes, scales and quantises in one pass.  Anything else that touches the outlier
 # tensor first - or a FindRowScale / ExtractOutliersAndSetToZeros on another tensor - runs the deferred extraction at once, in order.
 # What it cannot see: code that READS x between the two calls would still find the outlier columns unzeroed.  Off by default.
-_fused_prepass = False
 _pending_extract = None        # the OutlierActivations whose extraction is still deferred (a STRONG reference: the in-place zeroing of
                                # x is a side effect the caller is owed even if it drops the returned tensor before FindRowScale runs)
-
-
-def set_fused_prepass(enabled):
-    if enabled:
-        _check_torch_for_handles()
-    global _fused_prepass
-    _flush_pending_extract()
-    prev, _fused_prepass = _fused_prepass, bool(enabled)
-    return prev
 
 
 def _flush_pending_extract():
@@ -221,11 +263,11 @@ def _flush_pending_extract():
 
 
 class OutlierActivations(torch.Tensor):
-    """x_out [M,n] as returned by ExtractOutliersAndSetToZeros under set_fused_outliers(True): a view of 16-column-padded storage
+    """x_out [M,n] as returned by ExtractOutliersAndSetToZeros under configure(fused_outliers=True): a view of 16-column-padded storage
     (what the GEMM's tail reads) that recognises the reference's torch.mm with weight_cache.T."""
 
     def _run_extract(self):
-        """The deferred extraction of set_fused_prepass (a no-op when there is none)."""
+        """The deferred extraction of ShimConfig.fused_prepass (a no-op when there is none)."""
         pend = self.__dict__.pop("_mixq_pending", None)
         if pend is not None:
             ind, x, ldo = pend
@@ -243,7 +285,7 @@ class OutlierActivations(torch.Tensor):
                     if isinstance(b, OutlierActivations) and "_mixq_pending" in b.__dict__:
                         _flush_pending_extract()
                         b._run_extract()
-        if _fused_outliers and not kwargs and len(args) == 2 and func in (torch.mm, torch.matmul, T.mm, T.matmul, T.__matmul__):
+        if _cfg.fused_outliers and not kwargs and len(args) == 2 and func in (torch.mm, torch.matmul, T.mm, T.matmul, T.__matmul__):
             a, b = args
             if (isinstance(a, OutlierActivations) and isinstance(b, torch.Tensor) and not isinstance(b, OutlierActivations)
                     and a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0] and a.shape[1] > 0
@@ -254,7 +296,7 @@ class OutlierActivations(torch.Tensor):
 
 
 class PendingOutlierProduct(torch.Tensor):
-    """torch.mm(activation_outliers, weight_cache.T), deferred: see set_fused_outliers."""
+    """torch.mm(activation_outliers, weight_cache.T), deferred: see ShimConfig.fused_outliers."""
 
     @staticmethod
     def __new__(cls, xo, wo_t):
@@ -339,10 +381,10 @@ def ExtractOutliersAndSetToZeros(ind, x):
     M, K = x.shape
     n = ind.numel()
     _flush_pending_extract()                                 # (an earlier deferred extraction runs first: program order)
-    if _fused_outliers and n:
+    if _cfg.fused_outliers and n:
         buf = torch.empty((M, _pad16(n)), dtype=torch.float16, device=x.device)          # (columns >= n: never read as values)
         out = buf[:, :n].as_subclass(OutlierActivations)
-        if _fused_prepass and x.dim() == 2:
+        if _cfg.fused_prepass and x.dim() == 2:
             out._mixq_pending = (ind, x, buf.shape[1])
             _pending_extract = out
             return out
@@ -367,7 +409,7 @@ def _outlier_operands(addend):
 def _fused_dequant(q_x, q_w, x_scale, scale_col, addend, M, N, K, bit, act):
     _dev_check(q_x, q_w, x_scale, scale_col)
     if fmt_of(q_x) != FMT_PLAIN:
-        q_w = _weight_for_gemm(q_w, bit)                 # (packed activations need packed weights: set_packed_operands)
+        q_w = _weight_for_gemm(q_w, bit)                 # (packed activations need packed weights: ShimConfig.packed_operands)
         if fmt_of(q_w) == FMT_PLAIN:
             raise RuntimeError("mixq_amd.mixlib: packed q_x with a plain weight that cannot be packed (K % 64)")
     y = torch.empty((M, N), dtype=torch.float16, device=q_x.device)
@@ -451,7 +493,7 @@ class PendingGemmI32(torch.Tensor):
         self._mixq_done = True
         with torch._C.DisableTorchFunctionSubclass():
             q_x, q_w, M, N, K = self._mixq_args
-            if fmt_of(q_x) != FMT_PLAIN:                     # set_packed_operands: the raw kernel wants the plain matrix back
+            if fmt_of(q_x) != FMT_PLAIN:                     # ShimConfig.packed_operands: the raw kernel wants the plain matrix back
                 q_x = UnpackOperand(q_x.as_strided((packed_rows(M), K), (K, 1), q_x.storage_offset()), M, fmt_of(q_x))
             _capi.call("mixq_gemm_i8", q_x.data_ptr(), q_w.data_ptr(), self.data_ptr(), N, M, N, K, _stream())
         self._mixq_args = None
@@ -483,23 +525,8 @@ class PendingGemmI32(torch.Tensor):
             return func(*args, **kwargs)
 
 
-_lazy_gemm = False
-
-
-def set_lazy_gemm(enabled):
-    """False (default): `gemm` computes its int32 result at once (the literal unfused pair).  True: deferred, see PendingGemmI32 - an
-    opt-in like the switches above, because a consumer that bypasses __torch_function__ (a C++ extension taking at::Tensor) would
-    read the not-yet-computed storage.  set_packed_operands(True) / set_fused_outliers(True) imply it: their handles only make sense
-    when `gemm` + `dequantizeInt8` run as one kernel."""
-    if enabled:
-        _check_torch_for_handles()
-    global _lazy_gemm
-    prev, _lazy_gemm = _lazy_gemm, bool(enabled)
-    return prev
-
-
 def _lazy():
-    return _lazy_gemm or _packed_operands or _fused_outliers
+    return _cfg.lazy_gemm or _cfg.packed_operands or _cfg.fused_outliers
 
 
 def gemm(q_x, q_w, M, N, K):
@@ -626,6 +653,14 @@ def kept_map_words(K):
     return (((K + 31) // 32 + 1 + 3) // 4) * 4 + ((K + 7) // 8) * 4
 
 
+def _check_kept_map(col_mask, K, who):
+    """A kept outlier map handed to a kernel: 4-byte words, contiguous, 16-byte aligned, and LONG ENOUGH for the layout the kernels read (round
+    4's map stopped behind the count word; the kernels read the per-column AND-masks up to 2 K bytes further on - ADVICE r05)."""
+    if col_mask.element_size() != 4 or col_mask.numel() < kept_map_words(K) or not col_mask.is_contiguous() or col_mask.data_ptr() % 16:
+        raise RuntimeError(f"{who}: col_mask must be the 16-byte aligned kept outlier map of K = {K} columns - {kept_map_words(K)} int32 words "
+                           f"(bit words, count word, pad, K 16-bit AND-masks; linear.kept_outlier_map), got {col_mask.numel()} x {col_mask.element_size()} bytes")
+
+
 def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, packed=False, fmt=None, col_mask=None):
     """(i)+(ii) in one pass over X: extract/zero the known outlier columns `ind`, per-row scale into x_scale[0:M],
     quantise, and raise the device-side misprediction flag.  Returns (q_x, x_out_view[M,n]).  With fmt = FMT_P16X64 /
@@ -654,9 +689,8 @@ def QuantFused(x, ind, x_scale, bit, sigma, x_out=None, flag=None, n_dev=None, p
     else:
         op, ldo, ip = None, 0, None
     if col_mask is not None and n:
-        if col_mask.element_size() != 4 or col_mask.numel() < kept_map_words(K) or not col_mask.is_contiguous():
-            raise RuntimeError("QuantFused: col_mask must be the kept outlier map of K columns (bit words, count word, pad, K 16-bit AND-masks)")
-        _capi.call("mixq_quant_fused_masked", xp, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K,
+        _check_kept_map(col_mask, K, "QuantFused")
+        _capi.call("mixq_quant_fused_masked", xp, ip, n, _ptr(n_dev), col_mask.data_ptr(), col_mask.numel(), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K,
                    ldx, ldo, bit, float(sigma), fmt, _stream())
     else:
         _capi.call("mixq_quant_fused", xp, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), op, _ptr(flag), M, K, ldx,
@@ -799,8 +833,7 @@ class ForwardPlan:
         # kept_mask: the layer's kept outlier map of `ind` (include/mixq_hip.h: bits, count, AND-masks): the quantise pass then needs one memory round trip
         if kept_mask is not None:
             _dev_check(kept_mask)
-            if kept_mask.element_size() != 4 or kept_mask.numel() < (K + 31) // 32 + 1 or not kept_mask.is_contiguous():
-                raise RuntimeError("ForwardPlan: kept_mask must be contiguous 4-byte words covering all K columns + the count word behind them")
+            _check_kept_map(kept_mask, K, "ForwardPlan")
         self.kept_mask = kept_mask if n_cap else None
         self.keep = (ind_buf, n_dev, x_scale, q_w, scale_col, w_out, bias, kept_mask)
         self.M, self.N, self.K, self.ldx, self.n, self.qfmt, self.device = M, N, K, ldx, n, qfmt, x_scale.device
@@ -814,6 +847,9 @@ class ForwardPlan:
         row_amax (int32 [>= M] on the device): the rows' masked maxima left by the GEMM that produced x (FusedLinear(row_amax=...));
         the quantise pass is then the one-pass known-maximum kernel, which also clears the buffer."""
         dev = self.device
+        if col_mask is not None and col_mask is not self.kept_mask:
+            _dev_check(col_mask)
+            _check_kept_map(col_mask, self.K, "ForwardPlan.run")
         # the block carries x by address: the same checks on every call as the two-call route's QuantFused
         if x.device != dev:
             raise RuntimeError(f"ForwardPlan: x lives on {x.device}, the plan was built for {dev}")
@@ -829,7 +865,8 @@ class ForwardPlan:
         # ONE structure per plan and a foreign call that releases the GIL: two threads (or two streams driven from two threads) running
         # the same frozen layer must not interleave "fill" and "launch" - the C side reads the block before it returns
         with self.lock:
-            a.row_amax, a.col_mask = _ptr(row_amax), _ptr(col_mask if col_mask is not None else self.kept_mask)
+            cm = col_mask if col_mask is not None else self.kept_mask
+            a.row_amax, a.col_mask, a.col_mask_words = _ptr(row_amax), _ptr(cm), (0 if cm is None else cm.numel())
             if xo is not None:
                 a.x_out = xo.data_ptr()
             a.x, a.q_x, a.y = x.data_ptr(), q.data_ptr(), y.data_ptr()
@@ -876,9 +913,8 @@ def RMSNormQuantFused(x, weight, out, eps, ind, x_scale, bit, sigma=6.0, flag=No
     else:
         x_out, xop, ldxo, ip = None, None, 0, None
     if col_mask is not None and n:
-        if col_mask.element_size() != 4 or col_mask.numel() < kept_map_words(K) or not col_mask.is_contiguous():
-            raise RuntimeError("RMSNormQuantFused: col_mask must be the kept outlier map of K columns (bit words, count word, pad, K 16-bit AND-masks)")
-        _capi.call("mixq_rmsnorm_quant_fused_masked", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), col_mask.data_ptr(), x_scale.data_ptr(),
+        _check_kept_map(col_mask, K, "RMSNormQuantFused")
+        _capi.call("mixq_rmsnorm_quant_fused_masked", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), col_mask.data_ptr(), col_mask.numel(), x_scale.data_ptr(),
                    q.data_ptr(), xop, _ptr(flag), M, K, ldx, ldo, ldxo, float(eps), bit, float(sigma), fmt, _stream())
     else:
         _capi.call("mixq_rmsnorm_quant_fused", xp, weight.data_ptr(), op, ip, n, _ptr(n_dev), x_scale.data_ptr(), q.data_ptr(), xop,

@@ -130,7 +130,7 @@ def test_g8_block_trace_step_by_step(golden, oracle_backend, name):
     so gate_proj's take-over from cache.new_ind (linear.py:298-315) IS exercised."""
     import g8_replay
     g = golden(name)
-    worst = g8_replay.replay_walk(g, "cpu", lambda cache, M, KB: cache.q_xcache.numpy().view(np.uint8))
+    worst = g8_replay.replay_walk(g, "cpu", lambda cache, M, KB: backend_oracle._plain(cache.q_xcache, M).view(np.uint8))
     assert worst <= 4e-3
     if int(g["bit"]) == 8:
         assert g["c0_up_ind"].tolist() == [7, 100] and g["c1_gate_ind"].tolist() == [7, 100, 201] and g["c1_new_ind"].tolist() == [201]

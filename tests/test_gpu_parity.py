@@ -1347,7 +1347,7 @@ def test_wreg_kernel_under_graph_replay_and_cold_buffers():
 
 @pytest.mark.parametrize("route", ["arch9", "fused"])
 def test_fused_outliers_behind_the_reference_call_sequence(route):
-    """set_fused_outliers(True): the reference's own sequence - ExtractOutliersAndSetToZeros, FindRowScale, torch.mm(activation_outliers,
+    """mixlib.configure(fused_outliers=True): the reference's own sequence - ExtractOutliersAndSetToZeros, FindRowScale, torch.mm(activation_outliers,
     weight_cache.T), then gemm + dequantizeInt8 (linear.py:234-241) or int8FusedDequantize (:248-256) - runs the outlier product as the
     fp16 tail of the int8 GEMM.  Same bits as the native operator's kernel on the same operands; within 2 fp16 ulp of the literal
     route (which rounds the product to fp16 first); every other use of the deferred product still sees torch.mm's values."""
@@ -1371,7 +1371,7 @@ def test_fused_outliers_behind_the_reference_call_sequence(route):
 
     y_lit, xo_lit, mm_lit, qx = run()
     assert type(mm_lit) is torch.Tensor
-    prev = mixlib.set_fused_outliers(True)
+    prev = mixlib.configure(fused_outliers=True)
     try:
         y_f, xo_f, mm_f, _ = run()
         assert isinstance(xo_f, mixlib.OutlierActivations) and isinstance(mm_f, mixlib.PendingOutlierProduct)
@@ -1393,11 +1393,11 @@ def test_fused_outliers_behind_the_reference_call_sequence(route):
         y3 = mixlib.int8FusedDequantize(qx3, q_weight, x_scale, scale_col, mm3, M, N, K)
         assert torch.equal(y3, mixlib.int8FusedDequantize(qx3, q_weight, x_scale, scale_col, mm_lit, M, N, K))
     finally:
-        mixlib.set_fused_outliers(prev)
+        mixlib.configure(prev)
 
 
 def test_fused_prepass_behind_the_reference_call_sequence():
-    """set_fused_prepass(True) (with set_fused_outliers): ExtractOutliersAndSetToZeros is deferred and FindRowScale on the same tensor
+    """mixlib.configure(fused_outliers=True, fused_prepass=True): ExtractOutliersAndSetToZeros is deferred and FindRowScale on the same tensor
     runs the one-pass extract + zero + scale + quantise kernel.  Same q_x, x_scale, x_out and zeroed x as the two separate calls; a
     deferred extraction that FindRowScale never picks up runs as soon as its result is touched, or before the next prepass call."""
     M, K = 70, 1024
@@ -1410,7 +1410,7 @@ def test_fused_prepass_behind_the_reference_call_sequence():
     xa = x0.clone().to(DEV)
     xo_a = mixlib.ExtractOutliersAndSetToZeros(ind, xa)
     q_a = mixlib.FindRowScale(xa, xs_a, M, K, 8)
-    po, pp = mixlib.set_fused_outliers(True), mixlib.set_fused_prepass(True)
+    po = mixlib.configure(fused_outliers=True, fused_prepass=True)
     try:
         xb = x0.clone().to(DEV)
         xo_b = mixlib.ExtractOutliersAndSetToZeros(ind, xb)
@@ -1435,7 +1435,7 @@ def test_fused_prepass_behind_the_reference_call_sequence():
         assert torch.equal(xd, xa) and torch.equal(xo_d.as_subclass(torch.Tensor), xo_a)
         assert not torch.equal(q_e, q_a)                                                   # xe still had its outliers
     finally:
-        mixlib.set_fused_prepass(pp); mixlib.set_fused_outliers(po)
+        mixlib.configure(po)
 
 
 def test_gemm_shim_refuses_operands_that_do_not_match_m_n_k():
@@ -1445,14 +1445,14 @@ def test_gemm_shim_refuses_operands_that_do_not_match_m_n_k():
     qx = torch.zeros((M, K // 2), dtype=torch.uint8, device="cuda")
     qw = torch.zeros((N, K // 2), dtype=torch.uint8, device="cuda")
     for lazy in (True, False):
-        prev = mixlib.set_lazy_gemm(lazy)
+        prev = mixlib.configure(lazy_gemm=lazy)
         try:
             with pytest.raises(RuntimeError, match="nibble-packed"):
                 mixlib.gemm(qx, qw, M, N, K)
             with pytest.raises(RuntimeError, match="one-byte"):
                 mixlib.gemm(torch.zeros((M, K), dtype=torch.int32, device="cuda"), torch.zeros((N, K), dtype=torch.int8, device="cuda"), M, N, K)
         finally:
-            mixlib.set_lazy_gemm(prev)
+            mixlib.configure(prev)
 
 
 @pytest.mark.parametrize("lazy", [True, False])
@@ -1464,7 +1464,7 @@ def test_reference_arch9_route_at_the_metric_shape(lazy):
     sampled rows; the two forms agree bit for bit."""
     assert torch.cuda.get_device_capability()[0] == 9, "INTEGRATION.md states that gfx950 reports major 9"
     M, K, N = 512, 4096, 11008
-    prev = mixlib.set_lazy_gemm(lazy)
+    prev = mixlib.configure(lazy_gemm=lazy)
     try:
         torch.manual_seed(0)
         W = (torch.randn(N, K) / 64).half()
@@ -1500,7 +1500,7 @@ def test_reference_arch9_route_at_the_metric_shape(lazy):
         assert np.array_equal(n(y32[rows]), O.gemm_i8(qx, qw_h))
         test_reference_arch9_route_at_the_metric_shape.results[lazy] = (y1.clone(), y0.clone(), ys.clone())
     finally:
-        mixlib.set_lazy_gemm(prev)
+        mixlib.configure(prev)
     r = test_reference_arch9_route_at_the_metric_shape.results
     if len(r) == 2:
         for a, b in zip(r[True], r[False]):
@@ -1629,7 +1629,7 @@ def _i4_call(qxp, qwp, sx4, sw4, M, N, K):
 
 
 def test_packed_operands_behind_the_reference_call_sequence():
-    """mixlib.set_packed_operands(True): the reference's own sequence (linear.py:187-193, :234-283) with q_xcache an opaque
+    """mixlib.configure(packed_operands=True): the reference's own sequence (linear.py:187-193, :234-283) with q_xcache an opaque
     P16X64 handle of the reference's shape and the plain weight re-tiled (once) into fragment order - the native kernels behind
     unchanged reference code.  Results equal the plain-operand run bit for bit; a consumer that really reads the integers
     (PendingGemmI32 materialised) still gets the exact product."""
@@ -1650,12 +1650,12 @@ def test_packed_operands_behind_the_reference_call_sequence():
         y32 = mixlib.gemm(cache.q_xcache, q_weight, M, N, K)
         return y_a, y_b, n(y32), cache.q_xcache
     plain = ref_sequence()
-    prev = mixlib.set_packed_operands(True)
+    prev = mixlib.configure(packed_operands=True)
     try:
         fast = ref_sequence()
         assert fmt_of(fast[3]) == 1 and fmt_of(plain[3]) == 0
     finally:
-        mixlib.set_packed_operands(prev)
+        mixlib.configure(prev)
     assert torch.equal(plain[0], fast[0]) and torch.equal(plain[1], fast[1]) and torch.equal(plain[0], plain[1])
     assert np.array_equal(plain[2], fast[2]) and np.array_equal(fast[2], O.gemm_i8(n(plain[3]), c["qw"]))
 

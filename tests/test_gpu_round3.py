@@ -270,7 +270,7 @@ def test_known_maximum_quantiser_writes_the_same_bytes(M, K, ncols, bit, fmt):
     ldo = (ncols + 15) // 16 * 16
     xob = torch.empty((M, ldo), dtype=torch.float16, device=DEV) if ncols else None
     _capi.call("mixq_quant_known_amax", xb.data_ptr(), None if ind is None else ind.data_ptr(), ncols, None, amax.data_ptr(),
-               None if mask is None else mask.data_ptr(), sb.data_ptr(), qb.data_ptr(), None if xob is None else xob.data_ptr(), None,
+               None if mask is None else mask.data_ptr(), 0 if mask is None else mask.numel(), sb.data_ptr(), qb.data_ptr(), None if xob is None else xob.data_ptr(), None,
                M, K, K, ldo, bit, 6.0, fmt, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(sa, sb) and torch.equal(xa, xb) and (n(amax) == 0).all()

@@ -114,3 +114,15 @@ def test_g8_natives_through_the_mixlib_shim(golden):
         assert np.abs(n(y).astype(np.float32) - g[f"c{i}_y"].reshape(M, K).astype(np.float32)).max() <= 4e-3
         assert g[f"c{i}_down_ind"].size == 0
         prev_ind = ind_now
+
+
+@pytest.mark.parametrize("bit", [8, 4])
+def test_operator_state_sequence_on_gpu(bit):
+    """The GPU twin of tests/test_operator_stateful.py: one fixed sequence (search, a new outlier column, freeze, joint gate / up route, a
+    layer called on its own, state_dict round trip, deepcopy, the joint route off and on, new weights, .half(), a 3-row batch) on the HIP
+    backend - the block with every caching feature on returns the bytes of the twin that keeps nothing between forwards, step by step."""
+    import test_operator_stateful as S
+
+    class Gpu(S.BlockMachine if bit == 8 else S.BlockMachine4):
+        DEV, BACKEND = DEV, None
+    S.fixed_sequence(Gpu())

@@ -64,6 +64,8 @@ int main() {
     ind.up(hind); ndev.up({n});
     const std::vector<uint32_t> hmap = kept_map(hind, n, K);
     Dev<uint32_t> map(hmap.size()); map.up(hmap);
+    const int map_words = static_cast<int>(hmap.size());
+    CHECK(map_words == mixq_kept_map_words(K));
 
     // ---- quantise passes: plain / packed, empty, rejected -------------------------------------------------------------------------------
     x.up(hx);
@@ -80,7 +82,7 @@ int main() {
     // the in-kernel mask route against the kept-map route, device count below the capacity of `ind`
     x.up(hx); x2.up(hx);
     CHECK(mixq_quant_fused(x.p, ind.p, cap, ndev.p, xs.p, q.p, xo.p, flag.p, M, K, K, cap, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_OK);
-    CHECK(mixq_quant_fused_masked(x2.p, ind.p, cap, ndev.p, map.p, xs2.p, q2.p, xo2.p, flag.p, M, K, K, cap, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_OK);
+    CHECK(mixq_quant_fused_masked(x2.p, ind.p, cap, ndev.p, map.p, map_words, xs2.p, q2.p, xo2.p, flag.p, M, K, K, cap, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_OK);
     HIPOK(hipDeviceSynchronize());
     CHECK(x.down() == x2.down() && xs.down() == xs2.down() && xo.down() == xo2.down());
     {   // (the packed images are block-major and their pad rows are never written: compare the M rows of the plain matrices)
@@ -90,7 +92,8 @@ int main() {
         HIPOK(hipDeviceSynchronize());
         CHECK(pa.down() == pb.down());
     }
-    CHECK(mixq_quant_fused_masked(x2.p, ind.p, cap, ndev.p, nullptr, xs2.p, q2.p, xo2.p, flag.p, M, K, K, cap, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_EINVAL);
+    CHECK(mixq_quant_fused_masked(x2.p, ind.p, cap, ndev.p, map.p, (K + 31) / 32 + 1, xs2.p, q2.p, xo2.p, flag.p, M, K, K, cap, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_EINVAL);   // (round 4's layout: bits + count only)
+    CHECK(mixq_quant_fused_masked(x2.p, ind.p, cap, ndev.p, nullptr, 0, xs2.p, q2.p, xo2.p, flag.p, M, K, K, cap, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_EINVAL);
     CHECK(mixq_quant_fused(x.p, ind.p, n, nullptr, xs.p, q.p, nullptr, flag.p, M, K, K, cap, 8, 6.f, MIXQ_FMT_PLAIN, nullptr) == MIXQ_EINVAL);   // n > 0 needs x_out
     CHECK(mixq_quant_fused(x.p, ind.p, n, nullptr, xs.p, q.p, xo.p, flag.p, M, K, K, 3, 8, 6.f, MIXQ_FMT_PLAIN, nullptr) == MIXQ_EINVAL);        // ldo < n
     CHECK(mixq_quant_fused(x.p, nullptr, 0, nullptr, xs.p, q.p, nullptr, nullptr, M, K, K, 0, 4, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_OK);
@@ -155,7 +158,7 @@ int main() {
         HIPOK(hipDeviceSynchronize());
         CHECK(y2.down() == y.down());
     }
-    a.col_mask = map.p;                                                        // the frozen layer's kept outlier map
+    a.col_mask = map.p; a.col_mask_words = map_words;                          // the frozen layer's kept outlier map
     x.up(hx);
     CHECK(mixq_linear_forward(&a, nullptr) == MIXQ_OK);
     HIPOK(hipDeviceSynchronize());
@@ -181,7 +184,7 @@ int main() {
     CHECK(mixq_rmsnorm(x.p, g.p, out.p, M, K, K, K, 1e-5f, nullptr) == MIXQ_OK);
     CHECK(mixq_rmsnorm(x.p, g.p, out.p, M, K, K, K - 8, 1e-5f, nullptr) == MIXQ_ESHAPE);
     CHECK(mixq_rmsnorm_quant_fused(x.p, g.p, out.p, ind.p, cap, ndev.p, xs.p, q.p, xo.p, flag.p, M, K, K, K, cap, 1e-5f, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_OK);
-    CHECK(mixq_rmsnorm_quant_fused_masked(x.p, g.p, x2.p, ind.p, cap, ndev.p, map.p, xs2.p, q2.p, xo2.p, flag.p, M, K, K, K, cap, 1e-5f, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_OK);
+    CHECK(mixq_rmsnorm_quant_fused_masked(x.p, g.p, x2.p, ind.p, cap, ndev.p, map.p, map_words, xs2.p, q2.p, xo2.p, flag.p, M, K, K, K, cap, 1e-5f, 8, 6.f, MIXQ_FMT_P16X64, nullptr) == MIXQ_OK);
     HIPOK(hipDeviceSynchronize());
     CHECK(out.down() == x2.down() && xs.down() == xs2.down() && xo.down() == xo2.down());
     CHECK(mixq_rmsnorm_quant_fused(x.p, g.p, out.p, ind.p, n, nullptr, xs.p, q.p, nullptr, flag.p, M, K, K, K, cap, 1e-5f, 8, 6.f, MIXQ_FMT_PLAIN, nullptr) == MIXQ_EINVAL);

@@ -44,23 +44,16 @@ def native():
     return layer(x, None, True)
 flops = 2.0 * M * N * K
 for name, lazy, packed, fo, fn in [("arch==9 route, deferred product (default)", True, False, False, seq_arch9),
-                                   ("arch==9 route, literal pair", False, False, False, seq_arch9),
+                                   ("arch==9 route, literal pair (ShimConfig.literal())", False, False, False, seq_arch9),
                                    ("fused branch (arch != 9): int8FusedDequantize, plain operands", True, False, False, seq_fused_branch),
-                                   ("arch==9 route, deferred product + set_packed_operands(True)", True, True, False, seq_arch9),
-                                   ("fused branch + set_packed_operands(True)", True, True, False, seq_fused_branch),
-                                   ("arch==9 route + set_fused_outliers(True)", True, False, True, seq_arch9),
-                                   ("arch==9 route + set_packed_operands(True) + set_fused_outliers(True)", True, True, True, seq_arch9),
-                                   ("fused branch + set_packed_operands(True) + set_fused_outliers(True)", True, True, True, seq_fused_branch),
+                                   ("arch==9 route, deferred product + packed_operands", True, True, False, seq_arch9),
+                                   ("fused branch + packed_operands", True, True, False, seq_fused_branch),
+                                   ("arch==9 route + fused_outliers", True, False, True, seq_arch9),
+                                   ("arch==9 route + packed_operands + fused_outliers", True, True, True, seq_arch9),
+                                   ("fused branch + packed_operands + fused_outliers", True, True, True, seq_fused_branch),
                                    ("arch==9 route + all three switches (packed operands, fused outliers, fused prepass)", True, True, 2, seq_arch9),
                                    ("fused branch + all three switches", True, True, 2, seq_fused_branch),
                                    ("native operator (packed operands, fused quantise + GEMM)", True, False, False, native)]:
-    prev = mixlib.set_lazy_gemm(lazy)
-    prevp = mixlib.set_packed_operands(packed)
-    prevo = mixlib.set_fused_outliers(bool(fo))
-    prevq = mixlib.set_fused_prepass(fo == 2)
-    us = time_graph(fn, 50, 10)
-    mixlib.set_fused_prepass(prevq)
-    mixlib.set_fused_outliers(prevo)
-    mixlib.set_packed_operands(prevp)
-    mixlib.set_lazy_gemm(prev)
+    with mixlib.configured(mixlib.ShimConfig(lazy_gemm=lazy, packed_operands=packed, fused_outliers=bool(fo), fused_prepass=fo == 2)):
+        us = time_graph(fn, 50, 10)
     print(f"{name:88s} {us:8.2f} us / forward  {flops / us / 1e6:7.1f} TFLOPS ({100 * flops / us / 1e6 / 5033:4.1f} % of peak)", flush=True)
