@@ -194,6 +194,20 @@ def gather_counters(elapsed_s, flops, world, device, per_rank=False):
     return out + ([float(v) for v in allv[:, 0]],) if per_rank else out
 
 
+def describe_group(world, device, backend_arg):
+    """What the process group itself reports - the backend, the number of ranks it sees, every rank's device - so that the `--gpus N` line
+    answers "did RCCL see N ranks, one per GPU" by itself.  One all_gather_object of a short string per rank."""
+    name = torch.cuda.get_device_name(device) + f" (cuda:{device.index})" if device.type == "cuda" else "cpu"
+    if world == 1 and not _group_up():
+        return {"backend": None, "world_size": 1, "devices": [name], "collectives": "none (single process)"}
+    import torch.distributed as dist
+    names = [None] * dist.get_world_size()
+    dist.all_gather_object(names, name)
+    return {"backend": dist.get_backend() + (" (RCCL on ROCm)" if dist.get_backend() == "nccl" else ""), "backend_requested": backend_arg,
+            "world_size": dist.get_world_size(), "devices": names,
+            "collectives": "barrier on both sides of the timed region, one all_gather of {elapsed, FLOPs} behind it; none on the data path"}
+
+
 def shard_rows(total_rows, world, rank):
     """Row range of `rank` when a fixed global batch is split (strong scaling; token rows are independent)."""
     base, rem = divmod(total_rows, world)
@@ -206,13 +220,15 @@ def rank_rows(total_rows, world, rank, scaling):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def outlier_columns():
+def outlier_columns(Kc=None):
+    Kc = K if Kc is None else Kc
     g = torch.Generator().manual_seed(1)
-    return torch.randperm(K, generator=g)[: round(OUTLIER_FRAC * K)]
+    return torch.randperm(Kc, generator=g)[: round(OUTLIER_FRAC * Kc)]
 
 
-def build_layer(device, rows, seed=0, bit=8, cache=None):
+def build_layer(device, rows, seed=0, bit=8, cache=None, shape=None):
     from mixq_amd import MixLibCache, MixLinear_GEMM
+    K, N = shape if shape is not None else (globals()["K"], globals()["N"])
     torch.manual_seed(seed)
     lin = torch.nn.Linear(K, N, bias=False).half()            # nn.Linear default init, as examples/benchbitsand.py:519
     if cache is None:
@@ -223,16 +239,17 @@ def build_layer(device, rows, seed=0, bit=8, cache=None):
         # W4A4O16 (linear.py:123-143): the 128 input channels with the largest calibration scale stay fp16; the synthetic
         # calibration marks the batch's outlier columns (and fills up to 128 with the next channels)
         scales = torch.ones(K) + torch.arange(K) * 1e-6
-        cols = outlier_columns()
+        cols = outlier_columns(K)
         scales[cols] = 20.0 + torch.arange(cols.numel()) * 1e-3
         layer = MixLinear_GEMM.from_linear(lin, 4, cache=cache, layer_scales=scales, dev=device, name="up_proj")
     return lin, cache, layer
 
 
-def make_batches(count, rows, device, rank):
-    cols = outlier_columns()
+def make_batches(count, rows, device, rank, Kc=None):
+    Kc = K if Kc is None else Kc
+    cols = outlier_columns(Kc)
     gx = torch.Generator().manual_seed(100 + rank)
-    base = torch.randn(rows, K, generator=gx).half()
+    base = torch.randn(rows, Kc, generator=gx).half()
     base[:, cols] *= 20
     base = base.to(device)
     budget = 6 << 30                                                      # bytes of pristine inputs kept resident
@@ -265,6 +282,67 @@ def cpu_baseline(rows):
     return {"value": round(results[best][0], 4), "unit": "TFLOPS", "cores": best, "kind": "reference",
             "sample": f"torch.nn.Linear({K},{N}).half() on CPU, M={rows}, {results[best][1]} forwards after 2 warm-ups at {best} threads "
                       f"(sweep over threads: " + ", ".join(f"{c}: {results[c][0]:.3f}" for c in cands) + f" TFLOPS; {logical} logical CPUs)"}
+
+
+# BASELINE.json configs 2-4 at M = 512, timed by the default run AFTER the headline's timed region: the driver's one command
+# then carries a driver-timed figure for every configuration, not only config 1's shape
+SECONDARY_CONFIGS = [
+    ("cfg2_w4a4_4096x11008", "BASELINE config 2: Llama-2-7b up_proj W4A4O16 (128 static fp16 columns), batch 512", 4, 4096, 11008),
+    ("cfg3_w8a8_8192x28672", "BASELINE config 3: Llama-2-70b up_proj W8A8O16, batch 512 per GPU, 1 % outlier columns", 8, 8192, 28672),
+    ("cfg4_w8a8_4096x14336", "BASELINE config 4: Llama-3-8B up_proj W8A8O16, batch 512, 1 % outlier columns, prediction on (frozen after 2 forwards)", 8, 4096, 14336),
+]
+
+
+def measure_config(device, side, rows, bit, Kc, Nc, steps=20, replays=15):
+    """One BASELINE configuration under THE protocol of this file (conditioned_replay): the full forward (quantise + GEMM, a hipGraph of `steps`
+    steps on pristine inputs, median of `replays` back-to-back replays) and the GEMM + fused epilogue alone.  Returns the dict that goes into
+    `secondary_configs`."""
+    from mixq_amd import _capi, mixlib
+    _, cache, layer = build_layer(device, rows, seed=7, bit=bit, shape=(Kc, Nc))
+    _, base, pristine = make_batches(steps, rows, device, 0, Kc)
+    nbuf = pristine.shape[0]
+    for _ in range(3):
+        layer(base.clone(), None, True)
+    torch.cuda.synchronize()
+    assert layer.add_outliers is False
+    n_ind = int(layer.ind.numel())
+    restore = lambda: pristine.copy_(base.unsqueeze(0).expand_as(pristine))
+    with torch.cuda.stream(side):
+        for i in range(3):
+            layer(pristine[i % nbuf], None, True)
+        torch.cuda.synchronize()
+        restore()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(steps):
+                layer(pristine[i % nbuf], None, True)
+        torch.cuda.synchronize()
+        step_ms, _, _ = conditioned_replay(g, side, restore=restore, replays=replays)
+        restore()
+        ind_buf, n_dev = layer._ind_dev()
+        q_x, x_out = mixlib.QuantFused(base.clone(), ind_buf, cache.x_scale, bit, SIGMA, n_dev=n_dev, fmt=layer.x_fmt())
+        cache.q_xcache, cache.activation_outliers, cache.n_dev = q_x, (x_out[:, :n_ind] if n_ind else None), n_dev
+        for _ in range(3):
+            layer._gemm(cache, rows, 0)
+        torch.cuda.synchronize()
+        gg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gg, stream=side):
+            for _ in range(steps):
+                layer._gemm(cache, rows, 0)
+        torch.cuda.synchronize()
+        gemm_ms, _, _ = conditioned_replay(gg, side, replays=replays)
+    flops = 2.0 * rows * Nc * Kc
+    us, gus = step_ms * 1e3 / steps, gemm_ms * 1e3 / steps
+    f6 = layer.x_fmt() == 4
+    peak = PEAK_INT8_TOPS * (2 if f6 else 1)
+    cfg = _capi.gemm_config_names()[_capi.load().mixq_gemm_pick_config_fmt(rows, Nc, Kc, bit, mixlib.fmt_of(layer._wpk))]
+    out = {"bit": bit, "M": rows, "K": Kc, "N": Nc, "outlier_columns": n_ind, "ms_per_step": round(us * 1e-3, 5), "tflops": round(flops / us / 1e6, 1),
+           "pct_of_int8_mfma_peak": round(100.0 * flops / us / 1e6 / PEAK_INT8_TOPS, 2),
+           "gemm": {"kernel": ("FP6-pipe MFMA GEMM" if f6 else "int8 MFMA GEMM") + f" + fused epilogue ({cfg})", "us_per_launch": round(gus, 3),
+                    "achieved_tflops": round(flops / gus / 1e6, 1), "peak": peak, "frac": round(flops / gus / 1e6 / peak, 4)}}
+    del g, gg, layer, pristine
+    torch.cuda.empty_cache()
+    return out
 
 
 def hbm_traffic_from_profile(tag="", cfgname=None):
@@ -302,8 +380,9 @@ def dry_run(args):
     flops = 2.0 * (hi - lo) * N * K * args.steps
     barrier(world, dev)
     mx, tot, per = gather_counters(elapsed, flops, world, dev, per_rank=True)
+    dist_info = describe_group(world, dev, args.backend)
     if rank == 0:
-        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "value": round(tot / mx / 1e12, 3), "unit": "TFLOPS",
+        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "distributed": dist_info, "value": round(tot / mx / 1e12, 3), "unit": "TFLOPS",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
                           "rows_per_rank": hi - lo, "per_rank_ms": [round(v * 1e3, 4) for v in per],
                           "config": {"workload": "launch-path rehearsal", "M": M, "K": K, "N": N}}), flush=True)
@@ -450,6 +529,7 @@ def main(argv=None):
         eager_ms = cold_ms = None
         cold_note = None
         mlp_ms = {}
+        secondary = {}
         if not args.no_secondary and rank == 0:                 # (rank 0 only: the other ranks wait for it in the counter gather)
             # (a) the reference's own protocol, examples/benchbitsand.py:534-550: NO graph, 10 warm-up + 100 timed back-to-back
             # `layer(x)` calls from Python between two events - what a plain Hugging Face loop pays per layer, host cost included
@@ -531,12 +611,21 @@ def main(argv=None):
                 del block, up_l, gate_l, down_l, bx
             except Exception as exc:                                # (a secondary figure must not take the bench line down)
                 print(f"bench.py: MLP-block secondary timing skipped: {exc!r}", file=sys.stderr)
+            # (d) BASELINE configs 2-4 at their own shapes, same protocol (only from the metric's own invocation: a --shape / --bit / --batch run
+            # is somebody measuring ONE configuration)
+            if not args.shape and not args.batch and bit == 8 and world == 1:
+                for tag, what, sbit, sk, sn in SECONDARY_CONFIGS:
+                    try:
+                        secondary[tag] = dict(measure_config(device, side, rows, sbit, sk, sn), what=what)
+                    except Exception as exc:
+                        print(f"bench.py: secondary config {tag} skipped: {exc!r}", file=sys.stderr)
 
     flops_step = 2.0 * rows * N * K
     max_elapsed, total_flops, per_rank = gather_counters(elapsed, flops_step * steps, world, device, per_rank=True)
     max_host, _ = gather_counters(host_elapsed, 0.0, world, device)
     value = total_flops / max_elapsed / 1e12
     ms_per_step = max_elapsed * 1e3 / steps
+    dist_info = describe_group(world, device, args.backend)
     achieved = flops_step / (gemm_us * 1e-6) / 1e12
 
     if rank == 0:
@@ -568,6 +657,7 @@ def main(argv=None):
                        "replays": None if replay_ms is None else len(replay_ms),
                        "replay_ms_min": None if replay_ms is None else round(min(replay_ms), 5),
                        "replay_ms_median": None if replay_ms is None else round(median(replay_ms), 5),
+                       "replay_ms_mean": None if replay_ms is None else round(sum(replay_ms) / len(replay_ms), 5),
                        "replay_ms_max": None if replay_ms is None else round(max(replay_ms), 5),
                        "single_replay_ms_per_step": None if single_ms is None else round(single_ms / steps, 5),
                        "single_replay_protocol": "ONE replay between two events from a synchronised stream (rounds 1-4's figure; carries the graph-launch latency)",
@@ -583,6 +673,13 @@ def main(argv=None):
                        "mlp_block_protocol": "fused RMSNorm + quantise -> gate_proj + up_proj (one launch over interleaved rows | two launches) -> down_proj with the row "
                                              "maxima from the producer, same batch and shape (hidden -> intermediate -> hidden), graph of 20 blocks, same clock conditioning"},
             "pct_of_int8_mfma_peak": round(100.0 * value / (PEAK_INT8_TOPS * world), 2),
+            # rounds 1-4 reported ONE replay between two events from an idle stream: the same figure of THIS run, for comparison across rounds
+            "ms_per_step_single_replay": None if single_ms is None else round(single_ms / steps, 5),
+            "tflops_single_replay": None if single_ms is None else round(flops_step * world * steps / (single_ms * 1e-3) / 1e12, 2),
+            "secondary_configs": secondary or None,
+            "secondary_protocol": "after the headline's timed region, rank 0, same conditioned_replay protocol: hipGraph of 20 forwards on pristine inputs, "
+                                  "first replay discarded, ~40 ms of untimed replays, median of 15 back-to-back replays; `gemm` = GEMM + fused epilogue alone",
+            "distributed": dist_info,
             "max_abs_err_vs_dequant_linear": round(max_abs_err, 6),
             # (W4A4 on the FP6 pipe is priced against the FP6 dense peak, 2x the int8 one: MI355X_MICROARCH.md "Peak FP6/FP4 MFMA ~10 PF dense")
             "roofline": {"bound": "mfma", "kernel": ("FP6-pipe MFMA GEMM (int4 as E3M2 codes)" if fmt == 4 else "int8 MFMA GEMM") + " + fused epilogue (" +

@@ -87,6 +87,9 @@ def test_bench_launches_its_own_ranks_dry_run(scaling):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["dry_run"] is True and out["n_gpus"] == 2 and out["scaling"] == scaling
+    # the line says what the process group itself saw: backend, world size, one device per rank
+    d = out["distributed"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["devices"] == ["cpu", "cpu"] and "all_gather" in d["collectives"]
     assert out["per_rank_ms"] == [1.0, 1.1]                              # max over ranks is what the value is computed with
     rows = 256 if scaling == "strong" else 512
     assert out["rows_per_rank"] == rows
