@@ -391,25 +391,26 @@ class MixLinear_GEMM(nn.Module):
             return [id(t) for t in list(self._buffers.values()) + own]
         before = idents()
         out = super()._apply(fn, *args, **kwargs)
-        if fn(d.wpk) is d.wpk if d.wpk is not None else True:
-            wc, ind = self.__dict__.get("weight_cache"), self.__dict__.get("ind")
-            if (not isinstance(wc, Tensor) or fn(wc) is wc) and (not isinstance(ind, Tensor) or fn(ind) is ind) and idents() == before:
-                # an _apply that changes nothing (model.half() on an fp16 layer): the derived buffers - among them the row-maximum
-                # hand-over buffer and the retired images a captured graph still writes to and reads - stay as they are
-                return out
-        if d.wpk is not None:
-            moved = fn(d.wpk)
-            if moved is not d.wpk:
-                _backend.set_fmt(moved, _fmt_of(d.wpk))
-                d.wpk = moved
+        # fn is applied ONCE per tensor (a real move copies: the 45 MB image must not be copied to find out whether anything moves - ADVICE r05)
+        wc, ind = self.__dict__.get("weight_cache"), self.__dict__.get("ind")
+        moved_wpk = fn(d.wpk) if d.wpk is not None else None
+        moved_wc = fn(wc) if isinstance(wc, Tensor) else wc
+        moved_ind = fn(ind) if isinstance(ind, Tensor) else ind
+        if moved_wpk is d.wpk and moved_wc is wc and moved_ind is ind and idents() == before:
+            # an _apply that changes nothing (model.half() on an fp16 layer): the derived buffers - among them the row-maximum
+            # hand-over buffer and the retired images a captured graph still writes to and reads - stay as they are
+            return out
+        if d.wpk is not None and moved_wpk is not d.wpk:
+            _backend.set_fmt(moved_wpk, _fmt_of(d.wpk))
+            d.wpk = moved_wpk
         # everything else derived is rebuilt where the module now lives: the image is re-packed from q_weight when that buffer still
         # exists, the small-batch image when such a batch arrives, and the kept argument blocks - which pin the OLD device's tensors and
         # which a graph captured before the move may still replay (tests/test_gpu_round4.py) - are dropped
         d.invalidate(device=True)
-        if isinstance(self.__dict__.get("weight_cache"), Tensor):
-            self.weight_cache = fn(self.weight_cache)                    # 8-bit layers keep it as a plain attribute (linear.py:42)
-        if isinstance(self.__dict__.get("ind"), Tensor):
-            self.ind = fn(self.ind)
+        if isinstance(wc, Tensor):
+            self.weight_cache = moved_wc                                 # 8-bit layers keep it as a plain attribute (linear.py:42)
+        if isinstance(ind, Tensor):
+            self.ind = moved_ind
         self._wstore = None
         return out
 

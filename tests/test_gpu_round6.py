@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import g8_replay  # noqa: E402
-from mixq_amd import MixqConfig, _capi, mixlib  # noqa: E402
+from mixq_amd import MixLibCache, MixqConfig, _capi, mixlib  # noqa: E402
 from mixq_amd.mixlib import fmt_of  # noqa: E402
 from test_pack_properties import packed_unpack  # noqa: E402
 
@@ -70,7 +70,7 @@ def test_g8_natives_through_the_mixlib_shim(golden):
     g = golden("g8_mlp_block_w8.npz")
     I, K = g["up_weight"].shape
     x_scale = torch.zeros((64, 1), dtype=torch.float16, device=DEV)
-    zeros = torch.zeros((1, 1), dtype=torch.float16, device=DEV).expand(64, 4096)
+    zeros = MixLibCache(64, device=DEV).zeros                                      # (cache.zeros as the addend, linear.py:241,272: recognised by its tag)
     norm_w = t(g["norm_weight"])
     qw = {k: t(g[k + "_q_weight"]) for k in ("up", "gate", "down")}
     sw = {k: t(g[k + "_scale_col"]) for k in ("up", "gate", "down")}
