@@ -351,6 +351,12 @@ int mixq_gemm_set_trace(unsigned long long* buf);
  * used to rotate the K walk between neighbouring N tiles (rounds 1-2; it never changed a timing and cost two scalar counters per wave):
  * removed in round 4, ignored. */
 int mixq_gemm_set_krot(int krot);
+/* Experiment (round 6, measured negative - NOTEBOOK.md, profiles/r06_cold_prefetch_ab.txt): names the weight image (`bytes` long, 128-byte aligned)
+ * that the launch AFTER the next weights-in-registers GEMM of this host thread will stream; that next launch's loader waves then touch one
+ * dword per 128-byte line of it while its own k loop runs, so that the image is in the 256 MB memory-side cache when its GEMM starts
+ * (a model's layers: mixquant/modules/fused/mlp.py:57-70, benchflops.py:112-128).  Forms: environment MIXQ_PF_MODE = 1 scalar-cache loads,
+ * 2 vector loads, 6 vector loads with the nt hint; results never depend on it.  One launch per hint; NULL / 0 clears it. */
+int mixq_gemm_hint_next_weights(const void* w, long long bytes);
 #endif
 /* Diagnostics: exhaustive self-test of the division-free quantiser used by the quantise kernels (q = rint(x / s) for all
  * finite fp16 x and all finite fp16 s > 0, ~2e9 pairs, ~1 s): adds the number of disagreements with the IEEE-division form

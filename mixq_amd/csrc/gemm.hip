@@ -1088,6 +1088,14 @@ bool mixq_ws_get(void** ws, size_t* bytes, size_t* flag_bytes) {
     *ws = d->ws; *bytes = d->bytes; *flag_bytes = MIXQ_WS_FLAG_BYTES;
     return true;
 }
+#ifdef MIXQ_TUNING
+extern "C" int mixq_gemm_hint_next_weights(const void* w, long long bytes)    // (experiment, tuning library only: include/mixq_hip.h)
+{
+    if (bytes < 0 || (bytes > 0 && !w) || (reinterpret_cast<size_t>(w) & 127)) return MIXQ_EINVAL;
+    mixq_wr_hint_next(w, bytes);
+    return MIXQ_OK;
+}
+#endif
 // (the product library hands no tile through memory: the registration is accepted so that callers of the C ABI need not care which build they link)
 extern "C" int mixq_gemm_set_workspace(void* ws, long long bytes)
 {

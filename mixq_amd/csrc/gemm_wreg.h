@@ -13,6 +13,10 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
                    const uint16_t* addend, int lda, const uint16_t* bias, uint16_t* y, int ldy, int M, int N, int KB, int act,
                    unsigned long long* trace, hipStream_t st, uint32_t* row_amax = nullptr, const uint32_t* amax_mask = nullptr,
                    int n_begin = 0, int n_cols = -1);     // the launch covers the weight rows [n_begin, n_begin + n_cols) (default: all from n_begin)
+#ifdef MIXQ_TUNING
+// (experiment) the weight image of the launch after the next one: the next launch's loader waves touch it (one launch, this host thread)
+void mixq_wr_hint_next(const void* w, long long bytes);
+#endif
 // N split for a partial last round of tiles: true when running tiling c over the first *n1 weight rows and tiling *c2 over the rest is priced
 // cheaper than one launch of c (gemm_wreg.hip)
 bool mixq_wr_split(int bit, int M, int N, int KB, int c, int* n1, int* c2);

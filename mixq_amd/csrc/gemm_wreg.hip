@@ -28,6 +28,7 @@
 #include "gemm_wreg.h"
 #include "gemm_sk.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -58,6 +59,12 @@ struct WrArgs {
     // pairwise split-K (ABL = 50): one int32 slot of BM x BN per tile and one flag word per tile (zero between launches)
     uint8_t* ks_slots;
     unsigned int* ks_flags;
+#ifdef MIXQ_TUNING
+    // cross-layer prefetch experiment (round 6, mixq_gemm_hint_next_weights; measured negative, see the loader): the NEXT launch's weight image
+    const uint8_t* pf;
+    unsigned int pf_lines;                            // 128-byte lines of it
+    int pf_mode;                                      // bit 0: scalar-cache touches, bit 1: vector touches (one lane per line), bit 2: ... with the nt hint
+#endif
 };
 
 constexpr int WR_CW = 4;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // form's activation window holds all MB tuples, bit 1 the loaders sleep 64 cycles behind every DMA piece, bit 2 the loaders sleep 192 cycles
     // in front of a stage's pieces, bit 3 loaders at priority 0, bit 4 consumers at priority 3, bit 5 the in-k-step timeline (as ABL 36),
     // bit 6 ... stamped by consumer wave 2 (a SIMD no loader wave shares) instead of wave 0
-    constexpr int FL = (ABL >= 100 && ABL < 356) ? ABL - 100 : 0;                 // (bit 7: the FP6 form's LDS image of rounds 3-5, see OLDSWZ)
+    constexpr int FL = (ABL >= 100 && ABL < 1124) ? ABL - 100 : 0;                 // (bit 7: the FP6 form's LDS image of rounds 3-5, see OLDSWZ)
     constexpr int ABLK = ABL == 90 ? 0 : (RNDOPS ? 19 - ABL : (ABL >= 100 ? 0 : ABL));
     constexpr bool TL = ABL == 36 || (FL & 32);
     constexpr int TLW = (FL & 64) ? 2 : 0;
@@ -406,10 +413,77 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             (void)i; (void)ktv;
 #endif
         };
+#ifdef MIXQ_TUNING
+        // Cross-layer prefetch - built, measured, NOT shipped (tuning library only; profiles/r06_cold_prefetch_ab.txt,
+        // r06_sprefetch_ubench.txt).  A model's layers stream their weights from HBM (the 256 MB memory-side cache holds the last ~5 layers'
+        // images), which costs the metric launch +3 ... 4.6 us.  The idea: this launch's idle loader waves touch one dword per 128-byte line
+        // of the NEXT launch's image so that it sits in the memory-side cache when its GEMM starts.  Two forms:
+        //  (1) through the SCALAR cache - s_load_dword, a path to the L2 that bypasses the L1 and this wave's in-order vmcnt queue; up to PFB
+        //      batches of four lines per k-step while fewer than 12 of the wave's 15 possible requests are in flight (IB_STS.LGKM_CNT), junk
+        //      destination s98 / s99.  The L2 does fetch whole lines that way (FETCH_SIZE of a touch pass = that of a full read) but the
+        //      memory-side cache does not KEEP them: a dependent-load chase over the image takes 0.70 us per load behind such a pass, as on a
+        //      cold image (0.71), against 0.46 behind plain vector loads - the same holds for vector loads with the nt hint.  Forward with
+        //      344 MB of images in rotation: 33.5 -> 34.3 ... 34.8 us; with 172 MB (all resident): 29.6 -> 33.0 us.
+        //  (2) plain vector loads, 64 lines per instruction every few k-steps: the lines are kept (the next launch does run from the cache),
+        //      but every far request holds one of the CU's L1 miss entries for an HBM round trip - the window the k loop's own requests turn
+        //      over in (NOTEBOOK.md round 4) - and the two effects cancel: 33.8 -> 33.5 ... 33.7 us cold, 30.8 -> 31.4 us when all images are
+        //      resident; with the nt hint (not kept, HBM read twice) 33.7 -> 38.0 us.
+        // No path from a CU fills the memory-side cache without paying for it in the CU's own request window; the product library carries none.
+        constexpr int PFB = 4;
+        const uint8_t* pfp = nullptr;
+        int pfn = 0;                                                             // batches of four lines left
+        if constexpr (!KS) {
+            if (a.pf && (a.pf_mode & 1)) {
+                const unsigned per = (a.pf_lines / (static_cast<unsigned>(gridDim.x) * LOADERS)) & ~3u;
+                pfp = a.pf + static_cast<size_t>(blockIdx.x * LOADERS + lw) * per * 128;
+                pfn = static_cast<int>(per >> 2);
+            }
+        }
+        // (mode 2, experiment: ONE vector load of one dword per line - 64 lines per instruction - every PFV k-steps.  It sits in this wave's in-order
+        // vmcnt queue: the stage wait below only gets stricter by it, and passes unhindered as long as the far load returns within NEWER k-steps)
+        int pfv = 0;                                                             // vector instructions left
+        int pfv_every = 1, pfv_cnt = 0;
+        const uint8_t* pfvp = nullptr;
+        int pfsink = 0;
+        if constexpr (!KS) {
+            if (a.pf && (a.pf_mode & 2)) {
+                const unsigned per = (a.pf_lines / (static_cast<unsigned>(gridDim.x) * LOADERS)) & ~63u;      // lines per wave, whole instructions
+                pfvp = a.pf + static_cast<size_t>(blockIdx.x * LOADERS + lw) * per * 128 + static_cast<size_t>(lane) * 128;
+                pfv = static_cast<int>(per >> 6);
+                const int span = nk - LOOK - 6;
+                pfv_every = pfv > 0 && span > pfv ? span / pfv : 1;
+                if (!(a.pf_mode & 1)) pfn = 0;
+            }
+        }
+        auto prefetch_tick = [&]() MIXQ_INL {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (pfv > 0 && ++pfv_cnt >= pfv_every) {
+                pfv_cnt = 0;
+                if (a.pf_mode & 4) asm volatile("global_load_dword %0, %1, off nt" : "+v"(pfsink) : "v"(pfvp) : "memory"); else asm volatile("global_load_dword %0, %1, off" : "+v"(pfsink) : "v"(pfvp) : "memory");
+                pfvp += 64 * 128;
+                --pfv;
+            }
+#pragma unroll 1
+            for (int b = 0; b < PFB; ++b) {
+                unsigned inflight;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_IB_STS, 8, 4)" : "=s"(inflight));
+                if (inflight > 11u || pfn <= 0) break;
+                const uint8_t* p_ = pfp;
+                asm volatile("s_load_dword s98, %0, 0x0\n\ts_load_dword s98, %0, 0x80\n\ts_load_dword s98, %0, 0x100\n\ts_load_dword s98, %0, 0x180"
+                             :: "s"(p_) : "s98", "s99", "memory");
+                pfp += 512;
+                --pfn;
+            }
+#endif
+        };
+#endif
         for (; kt + LOOK < nk; ++kt) {
             lstamp(0, kt);
             if constexpr (FL & 4) __builtin_amdgcn_s_sleep(3);                    // probe: the consumers' first MFMA group behind the barrier runs without the loaders' burst
             stage(nxt);
+#ifdef MIXQ_TUNING
+            if constexpr (!KS) { if ((pfn > 0 || pfv > 0) && kt + LOOK + 4 < nk) prefetch_tick(); }
+#endif
             lstamp(1, kt);
             if constexpr (ABLK != 5) wr_wait_vmcnt<LOADS * NEWER>();              // stage kt+1 landed
             lstamp(2, kt);
@@ -471,6 +545,9 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
         }
         wr_wait_vmcnt<0>();                                                      // (nk = 1: no drain iteration waited for the tail blocks)
+#ifdef MIXQ_TUNING
+        if constexpr (!KS) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pfsink) :: "s98", "s99", "memory");   // (the prefetch's junk returns: all in before anything else may use the registers)
+#endif
         if constexpr (TOUCH) asm volatile("" :: "v"(tsink));
 #ifdef MIXQ_TUNING
         if constexpr (TL) {
@@ -569,40 +646,42 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         };
         if constexpr (SELF) zero_acc();                                          // (the others: behind their first operand requests)
 
-        // weight stream: wave-uniform block bases (scalar registers), one lane offset
-        const uint8_t* wb[WNB];
-#pragma unroll
-        for (int i = 0; i < WNB; ++i) {
-            int rb = (nw0 >> 4) + i; rb = rb < a.wblocks ? rb : a.wblocks - 1;      // blocks past N: computed and dropped
-            wb[i] = a.qw + static_cast<size_t>(rb) * BLK;
-        }
-        const size_t wks = static_cast<size_t>(a.wblocks) * BLK;
-        if constexpr (KS) {
-#pragma unroll
-            for (int i = 0; i < WNB; ++i) wb[i] += static_cast<size_t>(kbeg) * wks;
-        }
-        size_t woff = 0;                                 // byte offset of the k-step the next weight loads read
+        // weight stream (round 6): ONE buffer resource over the image, this wave's first block and lane in ONE offset register, the fragment's
+        // block as the instruction's immediate offset, the k-step's byte offset as its scalar offset - no address arithmetic per load and two
+        // scalar instructions per k-step.  (Rounds 2-5: a 64-bit base per fragment, s_add_u32 + s_addc_u32 in front of every global_load and a
+        // five-instruction conditional advance - 11 scalar instructions per k-step of a loop that turned out to be bound by what the consumer
+        // waves ISSUE between their MFMAs: profiles/r06_xwait_bisect.txt, 14 no-op-grade instructions per k-step cost 5 % of the launch.)
+        // Blocks past N (computed and dropped) read whatever follows - the next k-step's first blocks, zeros past the image's end (range check).
+        const unsigned wks = static_cast<unsigned>(a.wblocks) * BLK;               // bytes of one k-step of the image (images stay below 2 GB)
+        const i32x4 wrs = {static_cast<int>(reinterpret_cast<size_t>(a.qw)), static_cast<int>((reinterpret_cast<size_t>(a.qw) >> 32) & 0xffff),
+                           static_cast<int>(wks * static_cast<unsigned>(nk_all)), 0x00020000};
+        const int wvo = (nw0 >> 4) * BLK + lane * 16;
+        const int wvo8 = (nw0 >> 4) * BLK + 1024 + lane * 8;                       // (F6: the 8-byte pieces of a 1.5 KiB block, behind its sixty-four 16-byte pieces)
+        const int wvoB = wvo + 2 * BLK, wvo8B = wvo8 + 2 * BLK;                   // (immediates reach 4095: the FP6 form's fourth block goes through these)
+        auto wv16 = [&](int i) MIXQ_INL { return i * BLK < 4096 ? wvo : wvoB; };
+        auto wv8 = [&](int i) MIXQ_INL { return i * BLK < 4096 ? wvo8 : wvo8B; };
+        auto wimm = [&](int i) MIXQ_INL -> int { return i * BLK < 4096 ? i * BLK : (i - 2) * BLK; };
+        unsigned woff = static_cast<unsigned>(kbeg) * wks;                         // byte offset of the k-step the next weight loads read
+        const unsigned wlast = static_cast<unsigned>(kbeg + nk - 1) * wks;
         i32x6 wr6[F6R ? D + 1 : 1][F6R ? WNB : 1];                               // F6R: the weight ring as operand tuples (D + 1 slots, as wq below)
         // WRAP forms request on EVERY k-step; once the tile's last k-step has been requested the surplus requests REPEAT it (valid, never
         // consumed, and the lines are L1 / L2-hot: round 3 wrapped around to the tile's first k-steps instead - 3 MB of long-evicted weight
         // blocks re-fetched per launch, counter traffic 1.42x the algorithmic bytes, and a drain behind the loop that waited for them)
-        int wleft = nk;                                  // k-steps not requested yet
         auto wadvance = [&](int cond) MIXQ_INL {                    // once per requested k-step (cond: wave-uniform 0 / 1; F6R requests always)
-            if constexpr (WRAP) { if (--wleft > 0) woff += wks; }
+            if constexpr (WRAP) { (void)cond; const unsigned n = woff + wks; woff = n < wlast ? n : wlast; }
             else if (cond) woff += wks;
         };
         auto wload6 = [&](auto d_c, int i) MIXQ_INL {               // F6R: fragment i of the k-step at woff -> tuple i of ring slot d
             constexpr int d = decltype(d_c)::value;
             if constexpr (F6R && ABLK != 1 && ABLK != 3) {
-                const uint8_t* src = wb[i] + woff;
-                const int l16 = lane * 16, l8 = lane * 8;
+                const i32x4 rs_ = wrs; const unsigned so_ = woff; const int im_ = wimm(i);   // (named outside the statement: implicit capture does not look into asm operands)
+                const int l16 = wv16(i), l8 = wv8(i);
                 i32x4 lo; i32x2 hi;
-                asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:1024"
-                             : "=v"(lo), "=v"(hi) : "v"(l16), "v"(l8), "s"(src) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen offset:%6\n\tbuffer_load_dwordx2 %1, %3, %4, %5 offen offset:%6"
+                             : "=&v"(lo), "=&v"(hi) : "v"(l16), "v"(l8), "s"(rs_), "s"(so_), "i"(im_) : "memory");
                 wr6[d][i] = i32x6{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
             }
         };
-        const int lane16 = lane * 16, lane8 = lane * 8;
         // activation fragment (row lm, k-chunk lq) inside a P16X64 block: conflict-free by the layout's swizzle (common.h);
         // F6: the fragment's 16-byte and 8-byte pieces in the LDS image of an R6X128 block (see the loader)
         const int xoff8 = lm * 96 + 64 + ((lq ^ ((lm >> 3) << 1)) << 3);
@@ -621,7 +700,6 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         constexpr int XR = F6 ? ((ABLK == 38 || (FL & 1)) ? MB : (ABLK == 39 ? 2 : (MB < MIXQ_XR ? MB : MIXQ_XR))) : 1;   // (ABLK 38 / 39, tuning build: window of MB / of 2 tuples)
         i32x6 xf6[XR];
         static_assert(!F6 || MB % XR == 0, "window slots must be compile-time");
-        i32x4 xc[2];                                     // (probe ABLK 30: copies of the last two fragments)
 #pragma unroll
         for (int d = 0; d < NSLOT; ++d)
 #pragma unroll
@@ -639,6 +717,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     asm volatile("" : "+v"(wq[d][i]));
                 }
             }
+        if constexpr (!F6) {                               // (the fragment registers are read-write operands of the read statements: defined, no instruction)
+#pragma unroll
+            for (int j = 0; j < MB; ++j) asm volatile("" : "=v"(xf[j]));
+        }
         if constexpr (ABLK != 0) {                         // ablation builds: never-loaded operands get defined, opaque values
 #pragma unroll
             for (int j = 0; j < MB; ++j) {
@@ -682,40 +764,40 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             constexpr int d = decltype(d_c)::value;
             if constexpr (F6R) { (void)cond; wload6(d_c, i); }
             else if constexpr (WRAP) {                     // (int8 form with unconditional, wrapping requests: compile-time waits in the tail)
-                const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];
-                const int l16 = lane16;
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(l16), "s"(src) : "memory");
+                const i32x4 rs_ = wrs; const unsigned so_ = woff; const int im_ = wimm(i);   // (named outside the statement: implicit capture does not look into asm operands)
+                const int l16 = wv16(i);
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(dst) : "v"(l16), "s"(rs_), "s"(so_), "i"(im_) : "memory");
             }
             else if constexpr (ABLK != 1 && ABLK != 3) {
                 const int cs = __builtin_amdgcn_readfirstlane(cond);             // provably wave-uniform for the "s" constraint
-                const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];                     // (named outside the statement: implicit capture does not look into asm operands)
-                const int l16 = lane16;
+                const i32x4 rs_ = wrs; const unsigned so_ = woff; const int im_ = wimm(i);   // (named outside the statement: implicit capture does not look into asm operands)
+                const int l16 = wv16(i);
                 if constexpr (F6) {
                     i32x2& dst2 = wq2[d][i];
-                    const int l8 = lane8;
-                    asm volatile("s_cmp_eq_u32 %5, 0\n\ts_cbranch_scc1 1f\n\tglobal_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:1024\n1:"
-                                 : "+v"(dst), "+v"(dst2) : "v"(l16), "v"(l8), "s"(src), "s"(cs) : "memory", "scc");
+                    const int l8 = wv8(i);
+                    asm volatile("s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 1f\n\tbuffer_load_dwordx4 %0, %2, %4, %5 offen offset:%7\n\tbuffer_load_dwordx2 %1, %3, %4, %5 offen offset:%7\n1:"
+                                 : "+v"(dst), "+v"(dst2) : "v"(l16), "v"(l8), "s"(rs_), "s"(so_), "s"(cs), "i"(im_) : "memory", "scc");
                 } else
-                asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\tglobal_load_dwordx4 %0, %1, %2\n1:"
-                             : "+v"(dst) : "v"(l16), "s"(src), "s"(cs) : "memory", "scc");
+                asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 1f\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%5\n1:"
+                             : "+v"(dst) : "v"(l16), "s"(rs_), "s"(so_), "s"(cs), "i"(im_) : "memory", "scc");
             }
         };
         auto wload1_always = [&](auto d_c, int i) MIXQ_INL {
             constexpr int d = decltype(d_c)::value;
             if constexpr (F6R) wload6(d_c, i);
             else if constexpr (ABLK != 1 && ABLK != 3) {
-                const uint8_t* src = wb[i] + woff;
                 i32x4& dst = wq[d][i];
-                const int l16 = lane16;
+                const i32x4 rs_ = wrs; const unsigned so_ = woff; const int im_ = wimm(i);   // (named outside the statement: implicit capture does not look into asm operands)
+                const int l16 = wv16(i);
                 if constexpr (F6) {
                     i32x2& dst2 = wq2[d][i];
-                    const int l8 = lane8;
-                    asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %4 offset:1024"
-                                 : "+v"(dst), "+v"(dst2) : "v"(l16), "v"(l8), "s"(src) : "memory");
+                    const int l8 = wv8(i);
+                    asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen offset:%6\n\tbuffer_load_dwordx2 %1, %3, %4, %5 offen offset:%6"
+                                 : "+v"(dst), "+v"(dst2) : "v"(l16), "v"(l8), "s"(rs_), "s"(so_), "i"(im_) : "memory");
                 } else
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(l16), "s"(src) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(dst) : "v"(l16), "s"(rs_), "s"(so_), "i"(im_) : "memory");
             }
         };
         // wait until at most CNT loads issued after slot d's are outstanding (vmcnt retires in order); naming the slot's registers
@@ -779,17 +861,113 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // (round 6) The activation fragment reads are inline asm with hand-counted waits, like the weight loads.  Left to the compiler, every
+        // wait for a fragment came out as `s_waitcnt lgkmcnt(0)`: at the k-step boundary of the int8 loop (the re-read of fragment MB - 1,
+        // issued a few cycles earlier, was an exposed LDS round trip per k-step) and in front of groups 0 and XR of the FP6 loop (176 and 148
+        // cycles for those two groups against ~80 for the others, profiles/r06_w4a4_kstep_timeline_old_lds_image.txt).  The LDS counter
+        // retires in order, so group j waits for "at most xyounger(j) DS operations behind my fragment's": the reads issued since.
+        // The destinations are READ-WRITE operands (the register stays the fragment's own); xdrain() behind the loops names them all.
+        const unsigned xbase32 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) uint8_t*)lds)) + static_cast<unsigned>(xoff);
+        const unsigned xbase32_8 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) uint8_t*)lds)) + static_cast<unsigned>(xoff8);
         auto xread = [&](int slot, int j) MIXQ_INL {
-            if (ABLK == 14 && (j & 1)) { if constexpr (!F6) { xf[j] = xf[j - 1]; asm volatile("" : "+v"(xf[j])); } return; }   // timing probe (tuning build): HALF of the activation fragment reads - odd fragments are register copies of their even neighbours (real data for the MFMAs; results are garbage)
             if constexpr (F6 && (ABLK == 2 || ABLK == 3 || ABLK == 32)) {
                 // (ablation: no LDS reads)
             } else if constexpr (F6) {
-                const i32x4 p4 = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * BLK + xoff);
-                const i32x2 p2 = *reinterpret_cast<const i32x2*>(lds + slot * STAGE_BYTES + j * BLK + xoff8);
+#if defined(__HIP_DEVICE_COMPILE__)
+                const unsigned a16 = xbase32 + static_cast<unsigned>(slot * STAGE_BYTES), a8 = xbase32_8 + static_cast<unsigned>(slot * STAGE_BYTES);
+                i32x4 p4; i32x2 p2;
+                // (EARLY-CLOBBER outputs: two instructions in one statement - without it the allocator put the first read's destination over the second read's
+                // address register, the one it considered dead behind the statement (wr32x64: wrong tiles whenever the second read was held back behind a full LDS queue))
+                asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4" : "=&v"(p4), "=&v"(p2) : "v"(a16), "v"(a8), "i"(j * BLK) : "memory");
                 xf6[j % XR] = i32x6{p4[0], p4[1], p4[2], p4[3], p2[0], p2[1]};
+#endif
             } else
-            if constexpr (ABLK != 2 && ABLK != 3)
-                xf[j] = *reinterpret_cast<const i32x4*>(lds + slot * STAGE_BYTES + j * 1024 + xoff);
+            if constexpr (ABLK != 2 && ABLK != 3) {
+                const unsigned a16 = xbase32 + static_cast<unsigned>(slot * STAGE_BYTES);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(xf[j]) : "v"(a16), "i"(j * 1024) : "memory");
+            }
+        };
+        // One wait serves XWG consecutive groups: a wait (and the wait state the compiler puts behind a statement that "writes" an MFMA operand)
+        // in front of EVERY group cost the int8 loop 5 % of the launch - the consumer waves are bound by what they issue between their MFMAs
+        // (profiles/r06_xwait_bisect.txt) - and one drain per k-step costs the int8 loop nothing measurable.  The FP6 forms' window of XR tuples
+        // needs a wait every XR groups at least; theirs is counted, so the youngest read it waits for is XR - XWG groups old.
+        constexpr int XWG_SEL = (FL >> 8) & 3;                                    // (tuning build: 1, 2, 3 -> a wait every 1, 2, 4 groups)
+        constexpr int XWG_DEF = F6 ? (XR < 2 ? XR : 2) : MB;
+        constexpr int XWG0 = ABLK == 73 ? 4 : (ABLK == 74 ? 2 : (ABLK == 75 ? 1 : (XWG_SEL == 1 ? 1 : (XWG_SEL == 2 ? 2 : (XWG_SEL == 3 ? 4 : XWG_DEF)))));
+        constexpr int XWG = XWG0 > (F6 ? XR : MB) ? (F6 ? XR : MB) : XWG0;
+        static_assert((F6 ? XR : MB) % XWG == 0, "a wait serves whole groups of the fragment window");
+        // DS operations issued behind the read that filled group jt's fragment and in front of group j0 <= jt, in a k-step that re-reads from the
+        // next stage (REFILL) or not (the tile's last k-step).  int8 forms: fragment j is re-read behind group j (one operation).  FP6 forms: group
+        // g requests fragment g + XR - of this stage while g + XR < MB, of the next one (REFILL only) beyond - two operations each.
+        auto xyounger = [&](int j0, int jt, bool refill) MIXQ_INL -> int {
+            int n = 0;
+            for (int g = jt - (F6 ? XR : MB) + 1; g < j0; ++g) n += (g < 0 || (F6 && g + XR < MB) || refill) ? 1 : 0;
+            return F6 ? 2 * n : n;
+        };
+        // the fragments of groups j .. j + XWG - 1 have landed (a statement in front of group j when j is a multiple of XWG; nothing otherwise)
+        auto xwait = [&](int j, bool refill) MIXQ_INL {
+            if constexpr (F6 && (ABLK == 2 || ABLK == 3 || ABLK == 32)) { (void)j; (void)refill; }
+            else if (j % XWG == 0) {
+                const int jt = j + XWG - 1;
+                if constexpr (F6) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if constexpr (XWG == 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf6[j % XR]) : "i"(xyounger(j, jt, refill)));
+                    if constexpr (XWG == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xf6[j % XR]), "+v"(xf6[(j + 1) % XR]) : "i"(xyounger(j, jt, refill)));
+                    if constexpr (XWG == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xf6[j % XR]), "+v"(xf6[(j + 1) % XR]), "+v"(xf6[(j + 2) % XR]), "+v"(xf6[(j + 3) % XR]) : "i"(xyounger(j, jt, refill)));
+#endif
+                } else if constexpr (ABLK != 2 && ABLK != 3) {
+                    if constexpr (XWG == 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[j]) : "i"(xyounger(j, jt, refill)));
+                    if constexpr (XWG == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xf[j]), "+v"(xf[j + 1]) : "i"(xyounger(j, jt, refill)));
+                    if constexpr (XWG == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xf[j]), "+v"(xf[j + 1]), "+v"(xf[j + 2]), "+v"(xf[j + 3]) : "i"(xyounger(j, jt, refill)));
+                    if constexpr (XWG == 8) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(xf[j]), "+v"(xf[j + 1]), "+v"(xf[j + 2]), "+v"(xf[j + 3]), "+v"(xf[j + 4]), "+v"(xf[j + 5]), "+v"(xf[j + 6]), "+v"(xf[j + 7]) : "i"(xyounger(j, jt, refill)));
+                    if constexpr (XWG == 16) {
+                        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(xf[j]), "+v"(xf[j + 1]), "+v"(xf[j + 2]), "+v"(xf[j + 3]), "+v"(xf[j + 4]), "+v"(xf[j + 5]), "+v"(xf[j + 6]), "+v"(xf[j + 7]) : "i"(xyounger(j, jt, refill)));
+                        asm volatile("" : "+v"(xf[j + 8]), "+v"(xf[j + 9]), "+v"(xf[j + 10]), "+v"(xf[j + 11]), "+v"(xf[j + 12]), "+v"(xf[j + 13]), "+v"(xf[j + 14]), "+v"(xf[j + 15]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // (tail k-steps: `refill` is a run-time value, the counts are not.  The choice sits INSIDE one statement: a branch around two wait
+        // statements made the compiler merge the fragment's register through copies, one of them in front of its wait - tools/check_wreg_asm.py)
+        auto xwait_rt = [&](int j, bool refill) MIXQ_INL {
+            const int rf = __builtin_amdgcn_readfirstlane(refill ? 1 : 0);
+#define MIXQ_XWAIT_RT "s_cmp_eq_u32 %[rf], 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt lgkmcnt(%[a])\n\ts_branch 2f\n1:\n\ts_waitcnt lgkmcnt(%[b])\n2:"
+#define MIXQ_XWAIT_IN [rf] "s"(rf), [a] "i"(xyounger(j, jt, true)), [b] "i"(xyounger(j, jt, false))
+            if constexpr (F6 && (ABLK == 2 || ABLK == 3 || ABLK == 32)) { (void)j; (void)rf; }
+            else if (j % XWG == 0) {
+                const int jt = j + XWG - 1;
+                if constexpr (F6) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if constexpr (XWG == 1) asm volatile(MIXQ_XWAIT_RT : "+v"(xf6[j % XR]) : MIXQ_XWAIT_IN : "scc");
+                    if constexpr (XWG == 2) asm volatile(MIXQ_XWAIT_RT : "+v"(xf6[j % XR]), "+v"(xf6[(j + 1) % XR]) : MIXQ_XWAIT_IN : "scc");
+                    if constexpr (XWG == 4) asm volatile(MIXQ_XWAIT_RT : "+v"(xf6[j % XR]), "+v"(xf6[(j + 1) % XR]), "+v"(xf6[(j + 2) % XR]), "+v"(xf6[(j + 3) % XR]) : MIXQ_XWAIT_IN : "scc");
+#endif
+                } else if constexpr (ABLK != 2 && ABLK != 3) {
+                    if constexpr (XWG == 1) asm volatile(MIXQ_XWAIT_RT : "+v"(xf[j]) : MIXQ_XWAIT_IN : "scc");
+                    if constexpr (XWG == 2) asm volatile(MIXQ_XWAIT_RT : "+v"(xf[j]), "+v"(xf[j + 1]) : MIXQ_XWAIT_IN : "scc");
+                    if constexpr (XWG == 4) asm volatile(MIXQ_XWAIT_RT : "+v"(xf[j]), "+v"(xf[j + 1]), "+v"(xf[j + 2]), "+v"(xf[j + 3]) : MIXQ_XWAIT_IN : "scc");
+                    if constexpr (XWG == 8) asm volatile(MIXQ_XWAIT_RT : "+v"(xf[j]), "+v"(xf[j + 1]), "+v"(xf[j + 2]), "+v"(xf[j + 3]), "+v"(xf[j + 4]), "+v"(xf[j + 5]), "+v"(xf[j + 6]), "+v"(xf[j + 7]) : MIXQ_XWAIT_IN : "scc");
+                    if constexpr (XWG == 16) {
+                        asm volatile(MIXQ_XWAIT_RT : "+v"(xf[j]), "+v"(xf[j + 1]), "+v"(xf[j + 2]), "+v"(xf[j + 3]), "+v"(xf[j + 4]), "+v"(xf[j + 5]), "+v"(xf[j + 6]), "+v"(xf[j + 7]) : MIXQ_XWAIT_IN : "scc");
+                        asm volatile("" : "+v"(xf[j + 8]), "+v"(xf[j + 9]), "+v"(xf[j + 10]), "+v"(xf[j + 11]), "+v"(xf[j + 12]), "+v"(xf[j + 13]), "+v"(xf[j + 14]), "+v"(xf[j + 15]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef MIXQ_XWAIT_RT
+#undef MIXQ_XWAIT_IN
+        };
+        auto xdrain = [&]() MIXQ_INL {
+            if constexpr (F6) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int j = 0; j < XR; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf6[j]));
+#endif
+            } else {
+#pragma unroll
+                for (int j = 0; j < MB; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[j]));
+            }
         };
         uint32_t nib = 0xf0f0f0f0u;
         if constexpr (I4) asm volatile("s_mov_b32 %0, 0xf0f0f0f0" : "=s"(nib));
@@ -837,6 +1015,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #endif
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
+                    if constexpr (FULL) xwait(j, true); else xwait_rt(j, refill);
                     MIXQ_F6_MMA(acc[j][0], wr6[C][0], xf6[j % XR]);
                     __builtin_amdgcn_sched_barrier(0);
                     loads_behind(j);
@@ -878,6 +1057,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #endif
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
+                    if constexpr (FULL) xwait(j, true); else xwait_rt(j, refill);
                     MIXQ_F6_MMA(acc[j][0], w6[0], xf6[j % XR]);
                     __builtin_amdgcn_sched_barrier(0);
                     loads_behind(j);
@@ -893,29 +1073,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             } else if constexpr (!I4) {
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
-                    if constexpr (ABLK == 30 && MB >= 4 && WNB >= 3) {
-                        // probe: the k-step boundary drains ALL fragment reads (the compiler's lgkmcnt(0)), so the last re-read,
-                        // issued a few cycles before it, is an exposed LDS round trip per k-step.  The last two groups therefore run on
-                        // COPIES of their fragments taken at the top of the step, and those two fragments are re-read early (behind the
-                        // second MFMA of groups 0 and 1): the youngest read at the boundary is then six MFMAs old.
-                        if (j == 0) { xc[0] = xf[MB - 2]; xc[1] = xf[MB - 1]; asm volatile("" : "+v"(xc[0]), "+v"(xc[1])); }
-                        const i32x4 xb = j >= MB - 2 ? xc[j - (MB - 2)] : xf[j];
-                        acc[j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][0], xb, acc[j][0], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        loads_behind(j);
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc[j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][1], xb, acc[j][1], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (refill && j < 2) xread(rslot, MB - 2 + j);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 2; i < WNB; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][i], xb, acc[j][i], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (refill && j < MB - 2) xread(rslot, j);
-                        __builtin_amdgcn_sched_barrier(0);
-                        continue;
-                    }
+                    if constexpr (FULL) xwait(j, true); else xwait_rt(j, refill);
                     constexpr bool NEW_ORDER = ABLK != 31;                        // (31, tuning build: round 2's order)
                     if constexpr (NEW_ORDER) {
                         // At most ONE memory instruction per MFMA gap: a wave issues in order and a 16-cycle MFMA leaves ~12 cycles in
@@ -952,6 +1110,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 for (int i = 0; i < WNB; ++i) { wl[i] = lo4(wq[C][i]); wh[i] = hi4(wq[C][i]); }
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
+                    if constexpr (FULL) xwait(j, true); else xwait_rt(j, refill);
                     const i32x4 xl = lo4(xf[j]), xh = hi4(xf[j]);
 #pragma unroll
                     for (int i = 0; i < WNB; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wl[i], xl, acc[j][i], 0, 0, 0);
@@ -1029,6 +1188,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 __builtin_amdgcn_s_barrier();                                    // everybody's: stage kt+1 readable, stage kt-2's slot free
 #pragma unroll
                 for (int j = 0; j < MB; ++j) {
+                    xwait(j, true);                                               // (this form re-reads on every k-step: the wrapped-around stages)
 #pragma unroll
                     for (int i = 0; i < WNB; ++i)
                         acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wq[C][i], xf[j], acc[j][i], 0, 0, 0);
@@ -1044,7 +1204,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 }
                 wadvance(1);
                 xadvance();
-                slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
+                slot1 = (NSTAGE & (NSTAGE - 1)) == 0 ? ((slot1 + 1) & (NSTAGE - 1)) : ((slot1 + 1 == NSTAGE) ? 0 : slot1 + 1);
                 nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
                 ++kt;
             };
@@ -1054,7 +1214,8 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 wr_static_for<0, NSLOT>([&](auto c_c) MIXQ_INL { if (k0 + decltype(c_c)::value < nk) one(c_c); });
             }
             wr_wait_vmcnt<0>();                                                  // the wrapped-around requests of the last k-steps: nothing may
-            load_scales();                                                       // land in a register the epilogue re-uses
+            xdrain();                                                            // land in a register the epilogue re-uses
+            load_scales();
             stamp(2);
         } else {
         // ---- prologue ------------------------------------------------------------------------------------------------
@@ -1102,7 +1263,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 if (more && ABLK != 6) __builtin_amdgcn_s_barrier();
                 step(c_c, full_c, more, kt + D < nk ? 1 : 0, slot1);
             }
-            slot1 = (slot1 + 1 == NSTAGE) ? 0 : slot1 + 1;
+            slot1 = (NSTAGE & (NSTAGE - 1)) == 0 ? ((slot1 + 1) & (NSTAGE - 1)) : ((slot1 + 1 == NSTAGE) ? 0 : slot1 + 1);
             ++kt;
         };
         auto group = [&](auto full_c) MIXQ_INL { wr_static_for<0, NSLOT>([&](auto c_c) MIXQ_INL { one(c_c, full_c); }); };
@@ -1117,6 +1278,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // moment they are issued - free for anything - while the loads are still in flight.  The drain therefore NAMES every ring slot
         // (read-write operands of the wait statements): the ring stays allocated until nothing can land in it any more.
         if constexpr (WRAP) wr_static_for<0, NSLOT>([&](auto d_c) MIXQ_INL { wwait(d_c, std::integral_constant<int, 0>{}); });
+        xdrain();                                                                // (every issued fragment read has been consumed; this names the registers once more)
         if constexpr (F6) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // asm MFMA -> accumulator reads: wait states the compiler cannot count
 #ifdef MIXQ_TUNING
         if constexpr (TL) {
@@ -1826,6 +1988,7 @@ const WrConfig g_wr[] = {
 #define MIXQ_F6R_FL(NAME, BITS) { "wr128x192_f6r_" NAME, 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 100 + (BITS)>, 8 }
     MIXQ_F6R_FL("oldswz", 128), MIXQ_F6R_FL("pace", 2), MIXQ_F6R_FL("delay", 4), MIXQ_F6R_FL("xr8_pace", 1 + 2), MIXQ_F6R_FL("xr8_delay", 1 + 4), MIXQ_F6R_FL("lprio0", 8),
     MIXQ_F6R_FL("cprio3", 16), MIXQ_F6R_FL("xr8_lprio0", 1 + 8), MIXQ_F6R_FL("pace_lprio0", 2 + 8), MIXQ_F6R_FL("xr8_pace_lprio0", 1 + 2 + 8),
+    MIXQ_F6R_FL("xw1", 256), MIXQ_F6R_FL("xw2", 512), MIXQ_F6R_FL("xw4", 768), MIXQ_F6R_FL("t_xw1", 32 + 256), MIXQ_F6R_FL("t_xw4", 32 + 768),
     MIXQ_F6R_FL("t_wave2", 32 + 64), MIXQ_F6R_FL("t_xr8", 32 + 1), MIXQ_F6R_FL("t_pace", 32 + 2), MIXQ_F6R_FL("t_xr8_pace", 32 + 1 + 2),
     MIXQ_WR(8, 3, 16, 4, 2, 36, "128x192_t36_kstep_timeline"), MIXQ_WR(8, 3, 16, 4, 2, 100 + 32 + 64, "128x192_t_wave2"),   // the int8 loop's in-k-step timeline
     { "wr128x192_f6r_xr8", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 3, 2, 38>, 8 },
@@ -1841,6 +2004,7 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 66, "128x192_p66_epi2_no_scaling"),
     { "wr128x192_p70_touch", 8, 3, 16, 2, gemm_wreg_kernel<8, 3, 16, 4, 0, 2, 70>, nullptr, nullptr, 0 },   // probe: the loaders pull the panel's weight lines into L2 ahead of the consumers
     MIXQ_WR(8, 3, 16, 4, 2, 67, "128x192_p67_epi2_loaders_copy_3_of_4"),
+    MIXQ_WR(8, 3, 16, 4, 2, 73, "128x192_p73_xwait_every4"), MIXQ_WR(8, 3, 16, 4, 2, 74, "128x192_p74_xwait_every2"), MIXQ_WR(8, 3, 16, 4, 2, 75, "128x192_p75_xwait_every1"),
     MIXQ_WR(8, 3, 16, 4, 2, 60, "128x192_p60_epi1"),   // cfg 0 with the first form of the epilogue (round 3's): the A/B partner of EPI2
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
     MIXQ_WR(8, 3, 16, 4, 2, 2, "128x192_abl2_noX"),    // cfg 0 without X traffic
@@ -1848,7 +2012,6 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 16, "128x192_abl16_mfma_rnd"),    // abl3 / abl2 / abl1 with pseudo-random bytes in the never-loaded operands
     MIXQ_WR(8, 3, 16, 4, 2, 17, "128x192_abl17_noX_rnd"),
     MIXQ_WR(8, 3, 16, 4, 2, 18, "128x192_abl18_noW_rnd"),
-    MIXQ_WR(8, 3, 16, 4, 2, 14, "128x192_abl14_halfXreads"),   // cfg 0 with every other activation fragment never re-read from LDS: what halving the fragment reads would buy
     MIXQ_WR(8, 3, 16, 4, 2, 7, "128x192_abl7_nostore"),// cfg 0 without the stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 8, "128x192_abl8_plainst"),// cfg 0 with ordinary (not nt) stores of Y
     MIXQ_WR(8, 3, 16, 4, 2, 9, "128x192_abl9_empty"),  // returns at entry: the launch floor of this grid and LDS footprint
@@ -1861,7 +2024,6 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 28, "128x192_p28_prio"),
     MIXQ_WR(8, 3, 16, 4, 2, 41, "128x192_p41_wrapload"),
     MIXQ_WR(8, 3, 16, 4, 2, 31, "128x192_p31_r2order"),   // round 2's order: re-read and weight load in the same gap
-    MIXQ_WR(8, 3, 16, 4, 2, 30, "128x192_p30_earlyreread"),
     MIXQ_WR(8, 3, 16, 5, 2, 0, "128x192_s16_d5_l2"),
     MIXQ_WR8(8, 3, 16, 6, 2, "128x192_s16_d6_l2"),        // (deeper weight rings for the cold-weights protocol: tools/trace_gemm.py --cold 8)
     MIXQ_WR8(8, 3, 12, 6, 2, "128x192_s12_d6_l2"),
@@ -2010,6 +2172,14 @@ bool mixq_wr_split(int bit, int M, int N, int KB, int c, int* n1, int* c2)
     return true;
 }
 
+#ifdef MIXQ_TUNING
+// mixq_gemm_hint_next_weights (experiment): the image the launch AFTER the next one will stream, for the next launch's loader waves to touch
+// (see the loader).  Per host thread, consumed by the next weights-in-registers launch from it.
+static thread_local const uint8_t* t_next_w = nullptr;
+static thread_local long long t_next_bytes = 0;
+void mixq_wr_hint_next(const void* w, long long bytes) { t_next_w = static_cast<const uint8_t*>(w); t_next_bytes = w && bytes > 0 ? bytes : 0; if (!t_next_bytes) t_next_w = nullptr; }
+#endif
+
 // bit: 8, 4 (nibble-packed operands) or 6 (int4 as FP6 codes, MIXQ_FMT_F6X128 operands; KB is K / 2 as for bit 4)
 int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint16_t* x_scale, const uint16_t* scale_col,
                    const uint16_t* x_out, int ldxo, const uint16_t* w_out, int ldwo, int n_out, const int32_t* n_out_dev,
@@ -2045,6 +2215,13 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
     }
     a.trace = trace;
     a.row_amax = row_amax; a.amax_mask = amax_mask;
+#ifdef MIXQ_TUNING
+    if (t_next_w && g.loaders && c != WR_KSPLIT) {
+        static const int mode = [] { const char* e = getenv("MIXQ_PF_MODE"); return e ? atoi(e) : 2; }();
+        a.pf = t_next_w; a.pf_lines = static_cast<unsigned int>(t_next_bytes >> 7); a.pf_mode = mode;
+    }
+    t_next_w = nullptr; t_next_bytes = 0;                                    // (a hint serves ONE launch)
+#endif
     void (*k)(const WrArgs) = pair ? (bit == 8 ? g.k8p : g.k6p) : (bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4));
     if (!k) return MIXQ_EINVAL;
     int units = a.tiles_m * a.tiles_n;

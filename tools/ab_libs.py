@@ -20,6 +20,7 @@ ap.add_argument("--shapes", default="512x11008x4096")
 ap.add_argument("--nouts", default="41")
 ap.add_argument("--rounds", type=int, default=30)
 ap.add_argument("--launches", type=int, default=20)
+ap.add_argument("--bit", type=int, default=8, help="4: mixq_gemm_i4_fused on FP6-coded operands (the W4A4 form of the weights-in-registers kernels)")
 args = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _capi.load()
@@ -29,6 +30,8 @@ for item in args.libs.split(","):
     h = C.CDLL(os.path.join(root, path))
     h.mixq_gemm_i8_fused.argtypes = _capi.SIGNATURES["mixq_gemm_i8_fused"]
     h.mixq_gemm_i8_fused.restype = C.c_int
+    h.mixq_gemm_i4_fused.argtypes = _capi.SIGNATURES["mixq_gemm_i4_fused"]
+    h.mixq_gemm_i4_fused.restype = C.c_int
     libs.append((nm, h))
 dev = "cuda"
 side = torch.cuda.Stream()
@@ -42,6 +45,11 @@ for shp in args.shapes.split(","):
         sx = (torch.rand(M, 1, generator=g) * 0.01 + 0.001).half().to(dev)
         sw = (torch.rand(1, N, generator=g) * 0.01 + 0.001).half().to(dev)
         xp, wp = mixlib.PackOperand(qx, 1), mixlib.PackOperand(qw, 2)
+        if args.bit == 4:
+            from mixq_amd.linear import pack_to_i4
+            wp = mixlib.PackOperand(pack_to_i4(torch.randint(-8, 8, (N, K), generator=g, dtype=torch.int8)).to(dev), 3)
+            xp = mixlib.PackOperand(pack_to_i4(torch.randint(-7, 8, (M, K), generator=g, dtype=torch.int8)).to(dev), 4)
+        lay = (_capi.X_PACKED | _capi.W_F16X64) if args.bit == 8 else _capi.XW_F6X128
         pad = (max(nout, 1) + 15) // 16 * 16
         xo = torch.randn((M, pad), device=dev).half()
         wo = torch.randn((N, pad), device=dev).half()
@@ -51,9 +59,10 @@ for shp in args.shapes.split(","):
             for nm, h in libs:
                 out = torch.zeros((M, N), dtype=torch.float16, device=dev)
                 outs[nm] = out
-                run = lambda h=h, out=out: h.mixq_gemm_i8_fused(xp.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(),
-                                                               xo.data_ptr() if nout else None, pad, wo.data_ptr() if nout else None, pad, nout, None, None, 0,
-                                                               None, out.data_ptr(), N, M, N, K, 0, _capi.X_PACKED | _capi.W_F16X64, st)
+                fn = h.mixq_gemm_i8_fused if args.bit == 8 else h.mixq_gemm_i4_fused
+                run = lambda fn=fn, out=out: fn(xp.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(),
+                                                xo.data_ptr() if nout else None, pad, wo.data_ptr() if nout else None, pad, nout, None, None, 0,
+                                                None, out.data_ptr(), N, M, N, K, 0, lay, st)
                 for _ in range(3):
                     assert run() == 0
                 torch.cuda.synchronize()

@@ -14,6 +14,10 @@ TARGETS = [
 ]
 
 
+# the weight ring's loads: global_load_* until round 5, buffer_load_* (scalar k-step offset, immediate block offset) since round 6; gemm_w8a16.hip keeps global loads
+RING_LOADS = ("global_load_dwordx4", "global_load_dwordx2", "buffer_load_dwordx4", "buffer_load_dwordx2")
+
+
 def regs(tok):
     m = re.match(r"v\[(\d+):(\d+)\]", tok)
     if m:
@@ -47,7 +51,7 @@ def check(fname, kname, tag_re, tag_fmt, abl_idx):
             t = ln.strip()
             if t.startswith(";;#ASMSTART"): in_asm = True
             elif t.startswith(";;#ASMEND"): in_asm = False
-            elif in_asm and t.startswith(("global_load_dwordx4", "global_load_dwordx2")):   # (dwordx2: the 8-byte pieces of the FP6 form's fragments)
+            elif in_asm and t.startswith(RING_LOADS):   # (dwordx2: the 8-byte pieces of the FP6 form's fragments)
                 loaded |= regs(t.split()[1].rstrip(","))
         # the k loop and its tail: from the first hand-placed wait to the last one
         first = last = None
@@ -56,7 +60,7 @@ def check(fname, kname, tag_re, tag_fmt, abl_idx):
             t = ln.strip()
             if t.startswith(";;#ASMSTART"): in_asm = True
             elif t.startswith(";;#ASMEND"): in_asm = False
-            elif in_asm and t.startswith(("global_load_dwordx4", "global_load_dwordx2")): seen_load = True
+            elif in_asm and t.startswith(RING_LOADS): seen_load = True
             elif in_asm and t.startswith("s_waitcnt vmcnt") and seen_load:       # (the loader wave's own waits come before any ring load)
                 if first is None: first = i            # (the prologue gives every slot a defined value BEFORE its first load: harmless copies)
                 if any("sched_barrier" in x for x in lines[i:i + 4]): last = i    # a ring wait (the trace drain at the very end is not)
@@ -82,18 +86,21 @@ def check(fname, kname, tag_re, tag_fmt, abl_idx):
                 if any(regs(x) & loaded for x in toks): hits.append((i, t))
             elif op.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr_write")):
                 if any(regs(x) & loaded for x in toks[1:]): hits.append((i, t))          # a SOURCE in the ring
-        # activation fragments (asm ds_read_b128 + hand-counted lgkmcnt): LDS returns in order, so simulate the queue of outstanding
+        # activation fragments (asm ds_read_b128 / ds_read_b64 + hand-counted lgkmcnt; gemm_wreg.hip since round 6, gemm_w8a16.hip before): LDS returns in order, so simulate the queue of outstanding
         # destination registers through the kernel text and flag any compiler copy / spill that READS a register still in it
-        pending, in_asm, lds_hits = [], False, []
+        pending, in_asm, lds_hits, prev_op = [], False, [], ""
         for i, ln in enumerate(lines):
             t = ln.strip()
             if t.startswith(";;#ASMSTART"): in_asm = True; continue
             if t.startswith(";;#ASMEND"): in_asm = False; continue
+            if re.match(r"^\.LBB\d+_\d+:", t) and prev_op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                pending = []                                   # a block nothing falls into: the queue of the text above it is not its state
             if not t or t.startswith((";", ".")): continue
             op = t.split()[0]
+            if not in_asm: prev_op = op
             toks = [x.strip(",") for x in t.split()[1:]]
             if in_asm:
-                if op == "ds_read_b128": pending.append(regs(toks[0]))
+                if op in ("ds_read_b128", "ds_read_b64"): pending.append(regs(toks[0]))   # (the FP6 forms read a fragment as 16 + 8 bytes: two queue entries)
                 elif op == "s_waitcnt":
                     m2 = re.search(r"lgkmcnt\((\d+)\)", t)
                     if m2: pending = pending[len(pending) - int(m2.group(1)):] if int(m2.group(1)) else []

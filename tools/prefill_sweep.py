@@ -21,6 +21,8 @@ ap.add_argument("--bit", type=int, default=8, help="4: W4A4 with both operands a
 args = ap.parse_args()
 dev = "cuda"
 lib = _capi.load()
+if os.environ.get("MIXQ_TUNING_LIB") == "1":
+    _capi.ensure_workspace(dev)                # (the pairwise split-K form, tuning library, hands partial tiles through it)
 names = _capi.gemm_config_names()
 print(_capi.device_info())
 cfgs = [int(c) if c.lstrip("-").isdigit() else names.index(c) for c in args.cfgs.split(",")]

@@ -3,7 +3,7 @@
 # tuple-ring form interleaved (tuning library), in-k-step timelines of the FP6 and the int8 loop (consumer wave 0 = shares its SIMD with a loader
 # wave, wave 2 = does not), short SQ / LDS / TA counter passes, then the GPU suite and the bench line.  Output: gpurun_out/r06e_* (small files only).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
-C=wr128x192_s16_d4_l2,wr128x192_f6r_abl3_mfma,wr128x192_f6r_abl1_noW,wr128x192_f6r_abl2_noX,wr128x192_f6r_abl32_dma_noreads,wr128x192_f6r_abl33_reads_nodma,wr128x192_f6r_abl6_nobar,wr128x192_f6r_xr8,wr128x192_f6r_xr2,wr128x192_f6r_pace,wr128x192_f6r_delay,wr128x192_f6r_xr8_pace,wr128x192_f6r_xr8_delay,wr128x192_f6r_lprio0,wr128x192_f6r_cprio3,wr128x192_f6r_xr8_lprio0,wr128x192_f6r_pace_lprio0,wr128x192_f6r_xr8_pace_lprio0,wr128x192_f6r_l4,wr128x192_f6r_d3,wr128x192_f6r_d4,wr128x192_f6r_s6,wr128x192_f6r_s10
+C=wr128x192_s16_d4_l2,wr128x192_f6r_abl3_mfma,wr128x192_f6r_abl1_noW,wr128x192_f6r_abl2_noX,wr128x192_f6r_abl32_dma_noreads,wr128x192_f6r_abl33_reads_nodma,wr128x192_f6r_abl6_nobar,wr128x192_f6r_oldswz,wr128x192_f6r_xr8,wr128x192_f6r_xr2,wr128x192_f6r_pace,wr128x192_f6r_delay,wr128x192_f6r_xr8_pace,wr128x192_f6r_xr8_delay,wr128x192_f6r_lprio0,wr128x192_f6r_cprio3,wr128x192_f6r_xr8_lprio0,wr128x192_f6r_pace_lprio0,wr128x192_f6r_xr8_pace_lprio0,wr128x192_f6r_l4,wr128x192_f6r_d3,wr128x192_f6r_d4,wr128x192_f6r_s6,wr128x192_f6r_s10
 MIXQ_TUNING_LIB=1 timeout 400 python3 tools/prefill_sweep.py --bit 4 --tokens 512 --layers 11008x4096 --cfgs $C --rounds 15 2>&1 | grep -v amdgpu.ids > $O/r06e_f6_variants.txt
 tr -s ' ' < $O/r06e_f6_variants.txt | sed 's/ wr/\n  wr/g; s/ auto/\n  auto/g; s/ int_mm/\n  int_mm/' | head -60
 timeout 300 python3 tools/trace_kstep.py --cfg wr128x192_f6r_t36_kstep_timeline,wr128x192_f6r_t_wave2,wr128x192_f6r_t_xr8,wr128x192_f6r_t_pace,wr128x192_f6r_t_xr8_pace 2>&1 | grep -v amdgpu.ids > $O/r06e_kstep_f6.txt; cat $O/r06e_kstep_f6.txt
