@@ -112,6 +112,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     constexpr int FL = (ABL >= 100 && ABL < 1124) ? ABL - 100 : 0;                 // (bit 7: the FP6 form's LDS image of rounds 3-5, see OLDSWZ)
     constexpr int ABLK = ABL == 90 ? 0 : (RNDOPS ? 19 - ABL : (ABL >= 100 ? 0 : ABL));
     constexpr bool TL = ABL == 36 || (FL & 32);
+    constexpr bool WPROBE = ABLK == 76;                                            // (timing probe: the weights through LDS - see the loader's stage())
     constexpr int TLW = (FL & 64) ? 2 : 0;
     constexpr int CW = WR_CW;
     constexpr int NT = (CW + LOADERS) * 64;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
     // (round 6: the tuple-ring form's feed ablations - 1 no weight loads, 2 no X traffic, 3 MFMA only, 6 no k-loop barriers, 32 DMA without fragment
     // reads, 33 fragment reads without DMA - with pseudo-random stand-ins, and 36: the in-k-step timeline of tools/trace_kstep.py)
     static_assert(!F6 || (!SELF && (ABLK == 0 || ABLK == 1 || ABLK == 2 || ABLK == 3 || (F6R && (ABLK == 6 || ABLK == 32 || ABLK == 33 || ABLK == 36 || ABLK == 38 || ABLK == 39 || ABL >= 100)))), "the FP6 form exists for the shipped loop (and its feed ablations) only");
-    static_assert(LOOK >= 1 && LOADS * NEWER < 64, "vmcnt range");
+    static_assert(LOOK >= 1 && (LOADS + (ABLK == 76 ? (BN / 16) / (LOADERS ? LOADERS : 1) : 0)) * NEWER < 64, "vmcnt range");
     static_assert(!SELF || (LOOK == D + 1 && !I4 && ABLK == 0 && (D - 1) * (WNB + LOADS) < 64), "self-loading form: X stage kt+1 and the weights of k-step kt are requested in the same k-step");
     static_assert(!EPI2 || SC_END <= 160 * 1024, "X ring + tail blocks + panel flags + scales must fit the 160 KiB of LDS");
     static_assert(!PAIR || (EPI2 && (Q == 0 || Q == 3)), "the paired gate / up epilogue exists in the panel form of the int8 and the FP6 tuple-ring kernels");
@@ -341,6 +342,20 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             for (int i = 0; i < LOADS; ++i) src[i] += static_cast<size_t>(kbeg) * xks;
         }
         size_t xoff = 0;                                 // byte offset of the k-step the next stage reads
+        // (ABLK 76, timing probe, results are garbage: what would the loop cost with the WEIGHTS staged through LDS by the loader waves - 1 KiB
+        // LDS-DMA pieces of the tile's weight blocks into one 12 KiB region behind the scales, the consumers reading their fragments from there with
+        // ds_read_b128 instead of issuing vector loads themselves.  A vector load costs the issuing consumer wave ~39 cycles of its k-step, a fragment
+        // read ~13: profiles/r05_ablations_random_operands.txt, r06_w8a8_kstep_timeline.txt)
+        constexpr int WPL = WPROBE ? (BN / 16) / LOADERS : 0;
+        const uint8_t* wsrc[WPL > 0 ? WPL : 1];
+        size_t woffL = 0;
+        if constexpr (WPROBE) {
+#pragma unroll
+            for (int i = 0; i < WPL; ++i) {
+                int rb = (n0 >> 4) + lw + i * LOADERS; rb = rb < a.wblocks ? rb : a.wblocks - 1;
+                wsrc[i] = a.qw + static_cast<size_t>(rb) * 1024 + lane * 16;
+            }
+        }
         auto stage = [&](int slot) MIXQ_INL {
             if constexpr (ABLK != 2 && ABLK != 3 && ABLK != 33) {
 #pragma unroll
@@ -349,9 +364,16 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                     if constexpr (ABLK == 22 || ABLK == 23 || (FL & 2)) __builtin_amdgcn_s_sleep(1);     // probe: the loader's pieces spread over the k-step
                     if constexpr (ABLK == 24) __builtin_amdgcn_s_sleep(2);
                 }
+                if constexpr (WPROBE) {
+#pragma unroll
+                    for (int i = 0; i < WPL; ++i) wr_glds16(wsrc[i] + woffL, lds + SC_END + (lw + i * LOADERS) * 1024);
+                    woffL += static_cast<size_t>(a.wblocks) * 1024;
+                    if (woffL >= static_cast<size_t>(a.wblocks) * 1024 * nk_all) woffL = 0;
+                }
             }
             xoff += xks;
         };
+        constexpr int LPS = LOADS + WPL;                 // load instructions per stage and loader wave (the counted waits below)
         // Deep rings start with a RAMP: all 232 workgroups asking for LOOK stages at once (14 x 8 KiB each at the metric tile) puts
         // 26 MB of requests in front of everybody's first stage.  RP stages are requested up front, then two per k-step until the
         // loader is LOOK stages ahead.  (slot of stage RP + 2 i + 1 was last read LOOK + 2 k-steps earlier: free, as in steady state)
@@ -361,13 +383,13 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         if (RP < LOOK && nk >= 2 * LOOK) {
 #pragma unroll
             for (int s = 0; s < RP; ++s) { stage(s); if constexpr (ABLK == 26 || ABLK == 27) { if (s == 0) __builtin_amdgcn_s_sleep(8); } }
-            wr_wait_vmcnt<LOADS * (RP - 1)>();
+            wr_wait_vmcnt<LPS * (RP - 1)>();
             __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
             wr_static_for<0, LOOK - RP>([&](auto i_c) MIXQ_INL {
                 constexpr int i = decltype(i_c)::value;
                 stage((RP + 2 * i) % NSTAGE);
                 stage((RP + 2 * i + 1) % NSTAGE);
-                wr_wait_vmcnt<LOADS * (RP + i)>();                               // stage i + 1 landed: RP + i younger stages may be in flight
+                wr_wait_vmcnt<LPS * (RP + i)>();                               // stage i + 1 landed: RP + i younger stages may be in flight
                 if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
             });
             kt = LOOK - RP;
@@ -376,7 +398,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #pragma unroll
             for (int s = 0; s < LOOK; ++s)
                 if (s < nk) stage(s);
-            if (NEWER < nk) wr_wait_vmcnt<LOADS * NEWER>(); else wr_wait_vmcnt<0>();
+            if (NEWER < nk) wr_wait_vmcnt<LPS * NEWER>(); else wr_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                                        // B0: stage 0 landed
             nxt = LOOK % NSTAGE;
         }
@@ -485,7 +507,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
             if constexpr (!KS) { if ((pfn > 0 || pfv > 0) && kt + LOOK + 4 < nk) prefetch_tick(); }
 #endif
             lstamp(1, kt);
-            if constexpr (ABLK != 5) wr_wait_vmcnt<LOADS * NEWER>();              // stage kt+1 landed
+            if constexpr (ABLK != 5) wr_wait_vmcnt<LPS * NEWER>();              // stage kt+1 landed
             lstamp(2, kt);
             if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
             lstamp(3, kt);
@@ -767,6 +789,10 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                 i32x4& dst = wq[d][i];
                 const i32x4 rs_ = wrs; const unsigned so_ = woff; const int im_ = wimm(i);   // (named outside the statement: implicit capture does not look into asm operands)
                 const int l16 = wv16(i);
+                if constexpr (WPROBE) {                    // (probe: the fragment comes out of the loaders' LDS copy of the tile's weight blocks)
+                    const unsigned wa = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) uint8_t*)lds)) + SC_END + (wave * WNB) * 1024 + lane * 16;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(wa), "i"(i * 1024) : "memory");
+                } else
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(dst) : "v"(l16), "s"(rs_), "s"(so_), "i"(im_) : "memory");
             }
             else if constexpr (ABLK != 1 && ABLK != 3) {
@@ -2004,6 +2030,7 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 66, "128x192_p66_epi2_no_scaling"),
     { "wr128x192_p70_touch", 8, 3, 16, 2, gemm_wreg_kernel<8, 3, 16, 4, 0, 2, 70>, nullptr, nullptr, 0 },   // probe: the loaders pull the panel's weight lines into L2 ahead of the consumers
     MIXQ_WR(8, 3, 16, 4, 2, 67, "128x192_p67_epi2_loaders_copy_3_of_4"),
+    MIXQ_WR(8, 3, 8, 4, 2, 0, "128x192_s8_d4_l2"), MIXQ_WR(8, 3, 8, 4, 2, 76, "128x192_s8_p76_weights_through_lds"),
     MIXQ_WR(8, 3, 16, 4, 2, 73, "128x192_p73_xwait_every4"), MIXQ_WR(8, 3, 16, 4, 2, 74, "128x192_p74_xwait_every2"), MIXQ_WR(8, 3, 16, 4, 2, 75, "128x192_p75_xwait_every1"),
     MIXQ_WR(8, 3, 16, 4, 2, 60, "128x192_p60_epi1"),   // cfg 0 with the first form of the epilogue (round 3's): the A/B partner of EPI2
     MIXQ_WR(8, 3, 16, 4, 2, 1, "128x192_abl1_noW"),    // cfg 0 without the weight loads
@@ -2235,7 +2262,11 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
         units *= 2;
     }                                                  // (the prefill tiles have no nibble form, few tilings an FP6 form)
     const size_t ring = (bit == 6 ? static_cast<size_t>(g.nstage6) * g.mb * 1536 + 4 * g.mb * 1024 : static_cast<size_t>(g.nstage + (g.loaders ? 2 : 0)) * g.mb * 1024) + 64 /* panel flags */ + static_cast<size_t>(bm) * 4 + static_cast<size_t>(bn) * 8 /* scales */, stg = ((static_cast<size_t>(bm) * (bn * 2 + 16) + 15) & ~static_cast<size_t>(15)) + 16 * bm * 4;   // ring + the tail's X_out blocks | staging tile + row-maximum slots
+#ifdef MIXQ_TUNING
+    const size_t shm0 = ring > stg ? ring : stg, shm = shm0 + static_cast<size_t>(bn) * 64 <= 160 * 1024 ? shm0 + static_cast<size_t>(bn) * 64 : shm0;   // (room for probe 76's weight blocks where it fits)
+#else
     const size_t shm = ring > stg ? ring : stg;
+#endif
     if (int rc = mixq_ensure_dynamic_lds(reinterpret_cast<const void*>(k), shm)) return rc;
     hipLaunchKernelGGL(k, dim3(units), dim3((WR_CW + g.loaders) * 64), shm, st, a);
     return mixq_launch_status();
