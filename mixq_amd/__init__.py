@@ -10,9 +10,9 @@ from .cache import MixLibCache, MLPCache
 from .linear import MixLinear_GEMM, MixQLinear, pack_to_i4, two_compl, unpack_int8_to_int4
 from . import mixlib
 from .mixlib import ShimConfig
-from .fused import FasterTransformerRMSNorm, MixLlamaMLP
+from .fused import FasterTransformerRMSNorm, MixFalconMLP, MixGPTJMLP, MixLlamaMLP
 from . import checkpoint
 
 __all__ = ["MixqConfig", "MixLinear_GEMM", "MixQLinear", "MixLibCache", "MLPCache", "pack_to_i4", "two_compl", "unpack_int8_to_int4",
-           "mixlib", "ShimConfig", "FasterTransformerRMSNorm", "MixLlamaMLP", "checkpoint"]
+           "mixlib", "ShimConfig", "FasterTransformerRMSNorm", "MixLlamaMLP", "MixFalconMLP", "MixGPTJMLP", "checkpoint"]
 __version__ = "0.1.0"

@@ -268,3 +268,43 @@ class MixLlamaMLP(nn.Module):
         extra = {"amax_for": self.down_proj_} if self.config.fuse_down_amax else {}
         gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache, mul=up_output, **extra)
         return self.down_proj_(gate_output, None, True)
+
+
+class MixFalconMLP(nn.Module):
+    """mixquant/modules/fused/mlp.py:8-32 (models/falcon.py:53): dense_h_to_4h -> exact GELU -> dense_4h_to_h with the unfused pre-pass.  The
+    two Linears are this package's operator (quantise + GEMM kernels); the GELU between them is the reference's own torch module."""
+
+    def __init__(self, dense_h_to_4h, dense_4h_to_h, MixGemmCache=None):
+        super().__init__()
+        self.dense_h_to_4h = dense_h_to_4h
+        self.dense_4h_to_h = dense_4h_to_h
+        self.act = nn.GELU()
+        self.MixGemmCache = MixGemmCache
+
+    def forward(self, x):
+        x = self.act(self.dense_h_to_4h(x, self.MixGemmCache))
+        return self.dense_4h_to_h(x, self.MixGemmCache, True)
+
+
+class MixGPTJMLP(nn.Module):
+    """mixquant/modules/fused/mlp.py:75-93 (models/gptj.py:56): fc_in -> config.activation_function -> fc_out -> dropout, the layers called
+    with an MLPCache (Cache.py:42-48).  Deviation: the reference always builds a bare MLPCache and ignores its MixGemmCache argument - enough
+    for weight-only layers (fc_out under the GPT-J policy, utils/module.py:4-12), but a mixed-precision fc_in reads `sigma`, `zeros`, ... that an
+    MLPCache does not have; here the model's MixLibCache is used when one is given."""
+
+    def __init__(self, module, config, MixGemmCache=None):
+        super().__init__()
+        from transformers.activations import ACT2FN
+        from .cache import MLPCache
+        self.fc_in = module.fc_in
+        self.fc_out = module.fc_out
+        self.act = ACT2FN[config.activation_function]
+        self.dropout = nn.Dropout(config.resid_pdrop)
+        dev = next((b.device for b in self.fc_in.buffers()), torch.device("cpu"))
+        self.MLPCache = MixGemmCache if MixGemmCache is not None else MLPCache(device=dev)
+
+    def forward(self, hidden_states):
+        hidden_states = self.fc_in(hidden_states, self.MLPCache)
+        hidden_states = self.act(hidden_states)
+        hidden_states = self.fc_out(hidden_states, self.MLPCache)
+        return self.dropout(hidden_states)

@@ -9,7 +9,7 @@ import torch
 import backend_oracle
 import mixq_amd.fused as F
 import mixq_amd.linear as L
-from mixq_amd import FasterTransformerRMSNorm, MixLibCache, MixLinear_GEMM, MixLlamaMLP
+from mixq_amd import FasterTransformerRMSNorm, MixFalconMLP, MixGPTJMLP, MixLibCache, MixLinear_GEMM, MixLlamaMLP
 from oracle import oracle as O
 
 
@@ -142,3 +142,45 @@ def test_g8_block_trace_through_forward(golden, oracle_backend, name):
     import g8_replay
     worst = g8_replay.replay_forward(golden(name), "cpu")
     assert worst <= 1e-2
+
+
+def test_falcon_and_gptj_mlp_wrappers_match_their_composition(oracle_backend):
+    """mixquant/modules/fused/mlp.py:8-32, :75-93: the wrappers ARE the sequence of operator calls the reference writes out - same calls, same
+    flags (dense_4h_to_h with the unfused pre-pass), same activation modules - so their outputs equal the layers called by hand, bit for bit."""
+    torch.manual_seed(5)
+    K, I, M = 128, 256, 8
+    a, b = torch.nn.Linear(K, I).half(), torch.nn.Linear(I, K).half()
+    cache = MixLibCache(16, device="cpu")
+    mk = lambda l, **kw: MixLinear_GEMM.from_linear(l, 8, cache=cache, dev="cpu", **kw)
+    x = torch.randn(M, K).half()
+    # (as in the reference's models, the first Linear's quantised input is left in the cache by the fused norm in front of it: fused/norm.py:21-33)
+    def normed(first):
+        norm = FasterTransformerRMSNorm(torch.ones(K), cache=cache)
+        norm.next_layer = first
+        return norm(x.clone())
+    h_to_4h, h4_to_h = mk(a), mk(b)
+    y = MixFalconMLP(h_to_4h, h4_to_h, cache)(normed(h_to_4h))
+    h_to_4h2, h4_to_h2 = mk(a), mk(b)
+    ref = h4_to_h2(torch.nn.GELU()(h_to_4h2(normed(h_to_4h2), cache)), cache, True)
+    assert torch.equal(y, ref) and tuple(y.shape) == (M, K)
+    xn = norm_ref(x)
+    dense = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xn, a.weight.float(), a.bias.float())), b.weight.float(), b.bias.float())
+    assert (y.float() - dense).abs().max() < 0.05 * dense.abs().max() + 0.05
+
+    class Cfg:
+        activation_function, resid_pdrop = "gelu_new", 0.0
+
+    class Mod(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc_in, self.fc_out = mk(a), mk(b, weight_only=True, name="fc_out")     # the GPT-J policy: fc_out weight-only (utils/module.py:4-12)
+
+    m = Mod()
+    g = MixGPTJMLP(m, Cfg(), cache).eval()
+    y2 = g(normed(m.fc_in))
+    from transformers.activations import ACT2FN
+    m2 = Mod()
+    ref2 = m2.fc_out(ACT2FN["gelu_new"](m2.fc_in(normed(m2.fc_in), cache)), cache)
+    assert torch.equal(y2, ref2) and tuple(y2.shape) == (M, K)
+    from mixq_amd import MLPCache
+    assert isinstance(MixGPTJMLP(m, Cfg()).MLPCache, MLPCache)            # (no model cache given: the reference's bare MLPCache)

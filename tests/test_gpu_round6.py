@@ -126,3 +126,53 @@ def test_operator_state_sequence_on_gpu(bit):
     class Gpu(S.BlockMachine if bit == 8 else S.BlockMachine4):
         DEV, BACKEND = DEV, None
     S.fixed_sequence(Gpu())
+
+
+def test_falcon_and_gptj_mlp_wrappers_on_gpu():
+    """mixquant/modules/fused/mlp.py:8-32, :75-93 on the HIP backend: the wrappers equal the operator calls written out by hand bit for bit, and the
+    dense fp32 block within the W8A8 quantisation error (the parity gate of the Linears themselves is tests/test_gpu_parity.py's)."""
+    from mixq_amd import FasterTransformerRMSNorm, MixFalconMLP, MixGPTJMLP, MixLinear_GEMM
+    from transformers.activations import ACT2FN
+    torch.manual_seed(11)
+    K, I, M = 512, 2048, 96
+    a, b = torch.nn.Linear(K, I).half(), torch.nn.Linear(I, K).half()
+    cache = MixLibCache(128, device=DEV)
+    mk = lambda l, **kw: MixLinear_GEMM.from_linear(l, 8, cache=cache, dev=DEV, **kw)
+    x = torch.randn(M, K).half().to(DEV)
+    x[:, [5, 77]] *= 30
+
+    def normed(first):
+        norm = FasterTransformerRMSNorm(torch.ones(K, dtype=torch.float16, device=DEV), cache=cache)
+        norm.next_layer = first
+        return norm(x.clone())
+
+    for _ in range(3):                                      # call 0 finds the outlier columns, later calls run the frozen (one-call) forwards
+        l1, l2 = (mk(a), mk(b)) if _ == 0 else (l1, l2)
+        y = MixFalconMLP(l1, l2, cache)(normed(l1))
+    r1, r2 = mk(a), mk(b)
+    for _ in range(3):
+        ref = r2(torch.nn.GELU()(r1(normed(r1), cache)), cache, True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    xf = x.float().cpu()
+    xn = xf / torch.sqrt((xf ** 2).mean(dim=-1, keepdim=True) + 1e-6)
+    dense = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xn, a.weight.float(), a.bias.float())), b.weight.float(), b.bias.float())
+    assert (y.float().cpu() - dense).abs().max() < 0.05 * dense.abs().max() + 0.05
+
+    class Cfg:
+        activation_function, resid_pdrop = "gelu_new", 0.0
+
+    class Mod(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc_in, self.fc_out = mk(a), mk(b, weight_only=True, name="fc_out")
+
+    m, m2 = Mod(), Mod()
+    g = MixGPTJMLP(m, Cfg(), cache).eval()
+    for _ in range(3):
+        y2 = g(normed(m.fc_in))
+        ref2 = m2.fc_out(ACT2FN["gelu_new"](m2.fc_in(normed(m2.fc_in), cache)), cache)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, ref2)
+    dense2 = torch.nn.functional.linear(ACT2FN["gelu_new"](torch.nn.functional.linear(xn, a.weight.float(), a.bias.float())), b.weight.float(), b.bias.float())
+    assert (y2.float().cpu() - dense2).abs().max() < 0.05 * dense2.abs().max() + 0.05
