@@ -524,47 +524,82 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // behind the ring - instead of being fetched from L2 by each wave (4 x 8 KiB per tail k-step: as much traffic as two
         // k-steps of the main loop, 0.6 us of a 27 us launch at 41 outlier columns).  Requested HERE, when the last X stage has been
         // issued and LOOK k-steps of the main loop are still to run, so it has landed long before the consumers reach the epilogue.
-        if constexpr (EPI2) {
-            // the scales into LDS (see SX_OFF): behind the last X stage's requests, every wait from here on is vmcnt(0)
-            if (lw == 0) {
+        // (round 6) ... and AFTER the first drain k-step's barrier, with COUNTED waits in the drain: rounds 4-5 issued the scales and the tail blocks right
+        // behind the last stage and drained with vmcnt(0) - the first drain wait then sat on the stage requested a moment ago AND on the tail's far
+        // loads (X_out has just been written by the quantise kernel, on other XCDs), the loader reached that k-step's barrier late and the whole
+        // workgroup with it: the k loop grew with the outlier count (int8 18.4 / 18.8 / 19.2 us at 0 / 41 / 128 columns, FP6 13.2 / 13.8 / 14.2 us at
+        // 0 / 64 / 128; profiles/r06_tail_drain.txt).  The counts must be compile-time, so both loader waves request the scales (the same bytes to
+        // the same LDS words), the bias slot is always loaded (scale_col again when there is no bias: never read) and a launch with outlier operands
+        // requests all TQ tail k-steps (chunks past the padded width read column 0; the fix-up below zeroes what is not a column).
+        constexpr int SCL = EPI2 ? (BM + 63) / 64 + 2 * ((BN + 63) / 64) : 0;      // scale requests per loader wave
+        constexpr int TLQ = TQ * TLOADS;                                         // tail requests per loader wave
+        constexpr bool CDRAIN = LOOK >= 3 && LPS * (LOOK - 3) + SCL + TLQ < 64 && LPS * (LOOK - 2) < 64;   // (an upper bound of every count below)
+        const bool has_tail = a.xo && a.wo;
+        auto issue_scales = [&]() MIXQ_INL {
+            if constexpr (EPI2) {
+                // the scales into LDS (see SX_OFF)
                 const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.sx) + m0, 0, (a.M - m0) * 2, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.sw) + n0, 0, (a.N - n0) * 2, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.bias ? a.bias : a.sw) + n0, 0, (a.N - n0) * 2, 0x00020000);
 #pragma unroll
                 for (int q = 0; q < (BM + 63) / 64; ++q)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(lds + SX_OFF + q * 256), 2, (q * 64 + lane) * 2, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < (BN + 63) / 64; ++q)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(lds + SW_OFF + q * 256), 2, (q * 64 + lane) * 2, 0, 0, 0);
-                if (a.bias) {
-                    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.bias) + n0, 0, (a.N - n0) * 2, 0x00020000);
 #pragma unroll
-                    for (int q = 0; q < (BN + 63) / 64; ++q)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)(lds + BI_OFF + q * 256), 2, (q * 64 + lane) * 2, 0, 0, 0);
-                }
+                for (int q = 0; q < (BN + 63) / 64; ++q)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)(lds + BI_OFF + q * 256), 2, (q * 64 + lane) * 2, 0, 0, 0);
             }
-        }
-        if (a.xo && a.wo) {
+        };
+        int kpad_l = 0;
+        if (has_tail) {
             int n_out_l = a.n_out;
             if (a.n_out_dev) { const int nd = *a.n_out_dev; n_out_l = nd < n_out_l ? nd : n_out_l; }
-            const int kpad_l = (n_out_l + 15) & ~15;
-            const int tsteps = (n_out_l + 31) >> 5;
+            kpad_l = (n_out_l + 15) & ~15;
+        }
+        auto issue_tail = [&](int kk) MIXQ_INL {                                   // (has_tail: X_out blocks of tail k-step kk, TLOADS pieces per loader wave)
 #pragma unroll
-            for (int kk = 0; kk < TQ; ++kk) {
-                if (kk < tsteps) {
+            for (int i = 0; i < TLOADS; ++i) {
+                const int p = lw + i * LOADERS;
+                int xr = m0 + p * 16 + (lane & 15); xr = xr < a.M ? xr : a.M - 1;
+                int col = kk * 32 + (lane >> 4) * 8; col = col < kpad_l ? col : 0;        // chunks past the padded width: any valid address (zeroed by the fix-up)
+                wr_glds16(reinterpret_cast<const uint8_t*>(a.xo + static_cast<size_t>(xr) * a.ldxo + col),
+                          lds + TAILX + (kk * MB + p) * 1024);
+            }
+        };
+        // ONE tail k-step per drain k-step (its TLOADS pieces take the loader a few hundred cycles of the ~600 it idles per k-step; all at once they
+        // made it late for the next barrier), the scales with the first
+        bool counted = false;
+        if constexpr (CDRAIN && ABLK != 6 && ABLK != 5) {
+            if (nk > LOOK) {                              // (the main loop has run: stage kt + 1 .. nk - 1 are the LOOK - 1 stages in flight)
+                counted = true;
+                wr_static_for<0, LOOK - 1>([&](auto d_c) MIXQ_INL {
+                    constexpr int d = decltype(d_c)::value, issued = d < TQ ? d : TQ;     // tail k-steps requested in front of this wait
+                    // stage kt + 1 landed: LOOK - 2 - d younger stages, the scales (d >= 1) and `issued` tail k-steps may be in flight
+                    if (has_tail) wr_wait_vmcnt<LPS * (LOOK - 2 - d) + (d ? SCL : 0) + TLOADS * issued>();
+                    else wr_wait_vmcnt<LPS * (LOOK - 2 - d) + (d ? SCL : 0)>();
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (d == 0) issue_scales();
+                    if (has_tail) {
 #pragma unroll
-                    for (int i = 0; i < TLOADS; ++i) {
-                        const int p = lw + i * LOADERS;
-                        int xr = m0 + p * 16 + (lane & 15); xr = xr < a.M ? xr : a.M - 1;
-                        int col = kk * 32 + (lane >> 4) * 8; col = col < kpad_l ? col : 0;        // chunks past the padded width: any valid address (masked later)
-                        wr_glds16(reinterpret_cast<const uint8_t*>(a.xo + static_cast<size_t>(xr) * a.ldxo + col),
-                                  lds + TAILX + (kk * MB + p) * 1024);
+                        for (int kk = 0; kk < TQ; ++kk)
+                            if (kk == d || (d == LOOK - 2 && kk > d)) issue_tail(kk);
                     }
-                }
+                });
+                kt = nk - 1;
             }
         }
-        for (; kt + 1 < nk; ++kt) {
-            wr_wait_vmcnt<0>();
-            if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
+        if (!counted) {                                   // (fewer k-steps than the ring is deep, probes: everything at once, drained with vmcnt(0))
+            issue_scales();
+            if (has_tail) {
+#pragma unroll
+                for (int kk = 0; kk < TQ; ++kk) issue_tail(kk);
+            }
+            for (; kt + 1 < nk; ++kt) {
+                wr_wait_vmcnt<0>();
+                if constexpr (ABLK != 6) __builtin_amdgcn_s_barrier();
+            }
         }
         wr_wait_vmcnt<0>();                                                      // (nk = 1: no drain iteration waited for the tail blocks)
 #ifdef MIXQ_TUNING
