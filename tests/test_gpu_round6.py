@@ -176,3 +176,47 @@ def test_falcon_and_gptj_mlp_wrappers_on_gpu():
     assert torch.equal(y2, ref2)
     dense2 = torch.nn.functional.linear(ACT2FN["gelu_new"](torch.nn.functional.linear(xn, a.weight.float(), a.bias.float())), b.weight.float(), b.bias.float())
     assert (y2.float().cpu() - dense2).abs().max() < 0.05 * dense2.abs().max() + 0.05
+
+
+@pytest.mark.parametrize("bit", [8, 4])
+def test_outlier_count_edges_through_the_counted_drain(bit):
+    """Round 6: the loader waves request the epilogue's scales and ALL TQ tail k-steps of X_out during the drain of the ring, with compile-time
+    request counts (gemm_wreg.hip, `CDRAIN`): chunks past the live columns read column 0 and are zeroed by the LDS fix-up, both loader waves load the
+    scales, the bias slot is always loaded.  Every outlier count around the 16- / 32-column boundaries, with the count in the argument and in device memory
+    (capacity larger than the count: poison beyond it), K long enough for the counted path, ragged M / N - every weights-in-registers tiling against the
+    oracle and bit-identical to each other."""
+    from test_gpu_parity import _fused_case, _run_fused, _wr_configs, ulp_tol
+    from oracle import oracle as O
+    from mixq_amd._capi import FMT_F6X128, FMT_R6X128
+    lib, names = _capi.load(), _capi.gemm_config_names()
+    M, N, K = 130, 328, 2048                                 # 32 int8 k-steps (ring 14 deep), 16 FP6 k-steps (ring 6 deep)
+    try:
+        for n_out in ([1, 15, 16, 17, 31, 32, 33, 47, 64, 65, 96, 128, 143] if bit == 8 else [16, 33, 64, 96, 128, 143]):
+            for bias, cap in ((False, 0), (True, 0), (False, ((n_out + 15) // 16 * 16) + 16)):
+                c = _fused_case(M, N, K, bit, seed=7 * n_out + bit, n_out=n_out, bias=bias, addend=False, act=0)
+                ref = O.linear_fused(c["qx"], c["qw"], c["sx"], c["sw"], xo=c["xo"], wo=c["wo"], bias=c["bias"], bit=bit).astype(np.float32)
+                first = None
+                cfgs = _wr_configs() if bit == 8 else [names.index(nm) for nm in ("wr128x192_s16_d4_l2", "wr128x128_s16_d4_l2", "wr64x128_s16_d4_l2", "wr64x192_s16_d4_l2", "wr64x256_s16_d4_l2", "wr32x64_s8_d6_l1")]
+                for cfg in cfgs:
+                    assert lib.mixq_gemm_set_config(cfg) == 0
+                    if bit == 8:
+                        y = _run_fused(c, 2, n_dev_cap=cap)
+                    else:                                    # W4A4 on the FP6 pipe: both operands as FP6 codes
+                        pad = (max(n_out, cap) + 15) // 16 * 16
+                        xo = torch.full((M, pad), float("nan"), dtype=torch.float16, device=DEV); xo[:, :n_out] = t(c["xo"])
+                        wo = torch.full((N, pad), float("nan"), dtype=torch.float16, device=DEV); wo[:, :n_out] = t(c["wo"])
+                        ncap = max(n_out, cap)
+                        n_dev = torch.tensor([n_out], dtype=torch.int32, device=DEV) if cap else None
+                        sx = torch.zeros((M, 1), dtype=torch.float16, device=DEV); sx[:, 0] = t(c["sx"])
+                        y = mixlib.FusedLinear(mixlib.PackOperand(t(c["qx"]), FMT_R6X128), mixlib.PackOperand(t(c["qw"]), FMT_F6X128), sx, t(c["sw"]), xo[:, :ncap], wo[:, :ncap], ncap,
+                                               None if c["bias"] is None else t(c["bias"]), M, N, K, bit=4, n_out_dev=n_dev)
+                    torch.cuda.synchronize()
+                    yn = n(y).astype(np.float32)
+                    assert np.isfinite(yn).all(), (names[cfg], n_out, cap)
+                    assert (np.abs(yn - ref) <= ulp_tol(ref)).all(), (names[cfg], n_out, cap, float(np.abs(yn - ref).max()))
+                    if first is None:
+                        first = y.clone()
+                    else:
+                        assert torch.equal(y, first), (names[cfg], n_out, cap)
+    finally:
+        lib.mixq_gemm_set_config(-1)
