@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 6: hand-counted activation fragment reads (asm ds_read + lgkmcnt(n)) against the previous build's loop (compiler-placed lgkmcnt(0)),
 # two libraries interleaved on one box; then the GPU suite on the new library and the scalar-cache prefetch micro-benchmark.
+# mixq_amd/libmixq_hip.so.r5loop (git-ignored) = the product objects with gemm_wreg.hip of commit 1f38e8a:  git show 1f38e8a:mixq_amd/csrc/gemm_wreg.hip > /tmp/old/gemm_wreg.hip;
+#   hipcc <Makefile FLAGS> -Imixq_amd/csrc -Iinclude -c /tmp/old/gemm_wreg.hip -o /tmp/old/gemm_wreg_old.o;  hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o mixq_amd/libmixq_hip.so.r5loop build/obj/{quant,gemm,norm,gemm_w8a16,gemm_skinny,forward}.o /tmp/old/gemm_wreg_old.o
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
 L="new=mixq_amd/libmixq_hip.so,r5loop=mixq_amd/libmixq_hip.so.r5loop"
 timeout 300 python3 tools/ab_libs.py --libs $L --shapes 512x11008x4096,512x4096x4096,512x4096x11008,512x14336x4096,512x28672x8192,2048x11008x4096,4096x11008x4096 --nouts 41 --rounds 15 2>&1 | grep -v amdgpu.ids > $O/r06f_ab_i8.txt; cat $O/r06f_ab_i8.txt
