@@ -357,6 +357,10 @@ int mixq_gemm_set_krot(int krot);
  * (a model's layers: mixquant/modules/fused/mlp.py:57-70, benchflops.py:112-128).  Forms: environment MIXQ_PF_MODE = 1 scalar-cache loads,
  * 2 vector loads, 6 vector loads with the nt hint; results never depend on it.  One launch per hint; NULL / 0 clears it. */
 int mixq_gemm_hint_next_weights(const void* w, long long bytes);
+/* Timing probe (round 6, tuning configuration wr128x192_p77_one_launch; NOTEBOOK.md "the one-launch form"): until cleared with NULLs, launches of that configuration from this
+ * host thread run a STAND-IN quantise phase in front of the GEMM - x: fp16 rows [M, K], scratch: [M, K] bytes written with write-through stores, counters: 2 x ceil(M / 128)
+ * zeroed 32-bit words (one agent-scope add per row, polled by the loader waves, reset by the last poller).  The GEMM's own operands and results are untouched. */
+int mixq_gemm_set_fuse_probe(const void* x, void* scratch, void* counters, int K);
 #endif
 /* Diagnostics: exhaustive self-test of the division-free quantiser used by the quantise kernels (q = rint(x / s) for all
  * finite fp16 x and all finite fp16 s > 0, ~2e9 pairs, ~1 s): adds the number of disagreements with the IEEE-division form

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mixq_gemm_workspace_bytes": [],
     "mixq_gemm_set_workspace": [_P, C.c_longlong],
     "mixq_gemm_hint_next_weights": [_P, C.c_longlong],
+    "mixq_gemm_set_fuse_probe": [_P, _P, _P, _I],
     "mixq_linear_forward": [_P, _P],
     "mixq_gemm_i8_fused_amax": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "mixq_gemm_amax_supported": [_I, _I, _I, _I],
@@ -115,7 +116,7 @@ class LinearArgs(C.Structure):
 _lib = None
 
 
-TUNING_ONLY = ("mixq_gemm_set_trace", "mixq_gemm_set_krot", "mixq_gemm_hint_next_weights")     # exported by libmixq_hip_tuning.so only (include/mixq_hip.h: #ifdef MIXQ_TUNING)
+TUNING_ONLY = ("mixq_gemm_set_trace", "mixq_gemm_set_krot", "mixq_gemm_hint_next_weights", "mixq_gemm_set_fuse_probe")     # exported by libmixq_hip_tuning.so only (include/mixq_hip.h: #ifdef MIXQ_TUNING)
 
 
 def header_symbols(path: str = HEADER_PATH, tuning: bool = False):

@@ -1089,6 +1089,11 @@ bool mixq_ws_get(void** ws, size_t* bytes, size_t* flag_bytes) {
     return true;
 }
 #ifdef MIXQ_TUNING
+extern "C" int mixq_gemm_set_fuse_probe(const void* x, void* scratch, void* counters, int K)    // (timing probe, tuning library only: include/mixq_hip.h)
+{
+    mixq_wr_fuse_probe(x, scratch, counters, K);
+    return MIXQ_OK;
+}
 extern "C" int mixq_gemm_hint_next_weights(const void* w, long long bytes)    // (experiment, tuning library only: include/mixq_hip.h)
 {
     if (bytes < 0 || (bytes > 0 && !w) || (reinterpret_cast<size_t>(w) & 127)) return MIXQ_EINVAL;

@@ -16,6 +16,8 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
 #ifdef MIXQ_TUNING
 // (experiment) the weight image of the launch after the next one: the next launch's loader waves touch it (one launch, this host thread)
 void mixq_wr_hint_next(const void* w, long long bytes);
+// (timing probe 77) the stand-in quantise phase of the one-launch form: fp16 rows [M, K], scratch [M, K] bytes, 2 x tiles_m zeroed counter words; NULL clears
+void mixq_wr_fuse_probe(const void* x, void* scratch, void* counters, int K);
 #endif
 // N split for a partial last round of tiles: true when running tiling c over the first *n1 weight rows and tiling *c2 over the rest is priced
 // cheaper than one launch of c (gemm_wreg.hip)

@@ -64,6 +64,8 @@ struct WrArgs {
     const uint8_t* pf;
     unsigned int pf_lines;                            // 128-byte lines of it
     int pf_mode;                                      // bit 0: scalar-cache touches, bit 1: vector touches (one lane per line), bit 2: ... with the nt hint
+    // one-launch probe (ABL 77, mixq_gemm_set_fuse_probe): a stand-in quantise phase in front of the GEMM - fp16 rows in, bytes out, a counter per M tile
+    const uint16_t* fx; uint8_t* fq; unsigned int* fcnt; int fK;
 #endif
 };
 
@@ -253,6 +255,59 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
 #endif
     };
     stamp(0);
+#ifdef MIXQ_TUNING
+    // ---- ABL 77, timing probe (NOTEBOOK.md round 6, "the one-launch form"): what would ONE launch for quantise + GEMM cost?  Every workgroup first runs a
+    // stand-in quantise pass over its share of the token rows - the row's fp16 values in (16 bytes per thread and chunk), maximum through DPP + LDS,
+    // scale, eight conversions per chunk, 8 bytes out per chunk with WRITE-THROUGH stores into a scratch image (the GEMM below keeps reading the real q_x:
+    // the launch's results stay correct), drain, ONE agent-scope atomic add per row on the counter of the row's 128-row M tile - then the GEMM as it is,
+    // whose loader waves poll their M tile's counter (bounded: a bug ends in a slow launch, not a hung box) in front of their first activation
+    // stage while the consumer waves are already requesting weights; the last poller of a tile resets its counters.  No outlier handling in the
+    // stand-in (the real pass spends ~0.9 of its 3 us there).
+    if constexpr (ABLK == 77) {
+        if (a.fx) {
+            const int nch = a.fK >> 3;                                             // 16-byte chunks per row
+            if (tid == 0) *reinterpret_cast<volatile uint32_t*>(lds + NSTAGE * STAGE_BYTES - 16) = 0u;      // (the loaders' relay word: LDS is not cleared between launches)
+            // ONE ROW PER WAVE (wave w of workgroup b: row w x workgroups + b): one far round trip for the row, the maximum inside the wave, no LDS, no
+            // workgroup barrier; the first form walked a workgroup's two or three rows one after the other with all six waves (47.7-59 us per forward)
+            const int r = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
+            if (r < a.M && nch <= 64 * 16) {
+                const uint16_t* xr = a.fx + static_cast<size_t>(r) * a.fK;
+                constexpr int CH = 16;                                             // chunks per lane at most (K <= 8192)
+                u32x4 c[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) { c[q] = u32x4{0, 0, 0, 0}; if (q * 64 + lane < nch) c[q] = *reinterpret_cast<const u32x4*>(xr + (q * 64 + lane) * 8); }
+                uint32_t m = 0;
+#pragma unroll
+                for (int q = 0; q < CH; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const uint32_t v = c[q][e] & 0x7fff7fffu; const uint32_t lo = v & 0xffffu, hi = v >> 16; m = m > lo ? m : lo; m = m > hi ? m : hi; }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off); m = m > o ? m : o; }
+                const float amax = h2f(static_cast<uint16_t>(m));
+                const float inv = amax > 0.f ? 127.f / amax : 0.f;
+                const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(a.fq + static_cast<size_t>(r) * a.fK, 0, a.fK, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int ch = q * 64 + lane;
+                    if (ch < nch) {
+                        u32x2 o = {0u, 0u};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int q0 = static_cast<int>(__builtin_rintf(h2f(static_cast<uint16_t>(c[q][e] & 0xffffu)) * inv));
+                            const int q1 = static_cast<int>(__builtin_rintf(h2f(static_cast<uint16_t>(c[q][e] >> 16)) * inv));
+                            const uint32_t pair = (static_cast<uint32_t>(q0) & 0xffu) | ((static_cast<uint32_t>(q1) & 0xffu) << 8);
+                            if (e < 2) o.x |= pair << (16 * e); else o.y |= pair << (16 * (e - 2));
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rq, ch * 8, 0, 16 /* sc1: write-through */);
+                    }
+                }
+                wr_wait_vmcnt<0>();
+                if (lane == 0) __hip_atomic_fetch_add(a.fcnt + r / BM, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                                                      // (the relay word is cleared before a loader can set it)
+        }
+    }
+#endif
     // second set of stamps (tools/trace_gemm.py --panels): the same buffer 16 x 4096 entries further on; `who`: the thread that stamps
     auto stamp2 = [&](int slot, int who) MIXQ_INL {
 #ifdef MIXQ_TUNING
@@ -379,6 +434,32 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         // loader is LOOK stages ahead.  (slot of stage RP + 2 i + 1 was last read LOOK + 2 k-steps earlier: free, as in steady state)
         // (FP6 form at 128-row tiles: 8 stages of 12 KiB - three up front instead of all six: -0.6 .. -1.1 % per launch, same-run A/B of two builds)
         constexpr int RP = (LOOK > 6 && ABLK != 12) ? 4 : (F6 && LOOK > 3 ? 3 : LOOK);
+#ifdef MIXQ_TUNING
+        if constexpr (ABLK == 77) {
+            if (a.fx) {                                   // (probe: the loaders wait for their M tile's rows - the consumers are already requesting weights)
+                const unsigned want = static_cast<unsigned>(a.M - m0 < BM ? a.M - m0 : BM);
+                int spins = 0;
+                // ONE lane of ONE loader wave polls, every ~0.5 us (all 64 lanes of 464 waves on four words: 55-59 us per forward - the words' memory channel
+                // serialises the polls and the producers' adds behind them); the other loader wave watches a word in LDS (SC_END: behind the scales)
+                volatile uint32_t* ldsflag = reinterpret_cast<volatile uint32_t*>(lds + NSTAGE * STAGE_BYTES - 16);     // (the ring's last 16 bytes: stage NSTAGE - 1 lands long after)
+                if (lw == 0) {
+                    if (lane == 0) {
+                        while (__hip_atomic_load(a.fcnt + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < (1 << 14)) __builtin_amdgcn_s_sleep(16);
+                        *ldsflag = 0x600DF00Du;
+                    }
+                } else if (lane == 0) {
+                    while (*ldsflag != 0x600DF00Du && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(2);
+                }
+                if (lw == 0 && lane == 0) {
+                    const unsigned seen = __hip_atomic_fetch_add(a.fcnt + a.tiles_m + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen == static_cast<unsigned>(a.tiles_n) - 1u) {                // the tile's last poller: everybody has passed
+                        __hip_atomic_store(a.fcnt + a.tiles_m + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.fcnt + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+#endif
         int nxt, kt = 0;
         if (RP < LOOK && nk >= 2 * LOOK) {
 #pragma unroll
@@ -2092,6 +2173,7 @@ const WrConfig g_wr[] = {
     // 15 (WR_KSPLIT): two workgroups per tile, half of K each (pairwise split-K).  Correct, tested, and slower than the data-parallel tilings at
     // every shape it was built for (32.6 vs 28.8 us at 11008 -> 4096, profiles/r03_splitk_ab.txt): round 5 moved it out of the product library
     MIXQ_WR(8, 2, 16, 4, 2, 50, "128x128_s16_d4_l2_k2"),
+#ifndef MIXQ_TUNING_ONLY_77                            // (-DMIXQ_TUNING_ONLY_77: a quick build for iterating on probe 77 - the split-K entry, whose index is referenced, and that probe only)
     // ablation forms (results are garbage by design)
     { "wr128x192_f6_abl1_noW", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 1>, 8 },   // the FP6 form's feed ablations
     { "wr128x192_f6_abl2_noX", 8, 3, 16, 2, nullptr, nullptr, gemm_wreg_kernel<8, 3, 8, 2, 2, 2, 2>, 8 },
@@ -2129,6 +2211,9 @@ const WrConfig g_wr[] = {
     MIXQ_WR(8, 3, 16, 4, 2, 66, "128x192_p66_epi2_no_scaling"),
     { "wr128x192_p70_touch", 8, 3, 16, 2, gemm_wreg_kernel<8, 3, 16, 4, 0, 2, 70>, nullptr, nullptr, 0 },   // probe: the loaders pull the panel's weight lines into L2 ahead of the consumers
     MIXQ_WR(8, 3, 16, 4, 2, 67, "128x192_p67_epi2_loaders_copy_3_of_4"),
+#endif
+    MIXQ_WR(8, 3, 16, 4, 2, 77, "128x192_p77_one_launch"),
+#ifndef MIXQ_TUNING_ONLY_77
     { "wr128x256_p78_mfma32x32x32", 8, 4, 16, 2, gemm_wreg_kernel<8, 4, 16, 3, 0, 2, 78>, nullptr, nullptr, 0 }, { "wr128x256_p79_shadow_acc", 8, 4, 16, 2, gemm_wreg_kernel<8, 4, 16, 3, 0, 2, 79>, nullptr, nullptr, 0 },
     MIXQ_WR(8, 3, 8, 4, 2, 0, "128x192_s8_d4_l2"), MIXQ_WR(8, 3, 8, 4, 2, 76, "128x192_s8_p76_weights_through_lds"),
     MIXQ_WR(8, 3, 16, 4, 2, 73, "128x192_p73_xwait_every4"), MIXQ_WR(8, 3, 16, 4, 2, 74, "128x192_p74_xwait_every2"), MIXQ_WR(8, 3, 16, 4, 2, 75, "128x192_p75_xwait_every1"),
@@ -2165,6 +2250,7 @@ const WrConfig g_wr[] = {
     // power cap either way - and its one-register-set tail costs 33 us with 41 outlier columns.  Known fault: memory access
     // violation at M = 8192 and with > 64 outlier columns.  int8 only.
     { "wr256x256_s6_d3_self", 16, 4, 6, 0, gemm_wreg_kernel<16, 4, 6, 3, 0, 0, 0>, nullptr, nullptr, 0 },
+#endif
 #endif
 };
 constexpr int WR_SMALL = 14;
@@ -2300,6 +2386,12 @@ bool mixq_wr_split(int bit, int M, int N, int KB, int c, int* n1, int* c2)
 }
 
 #ifdef MIXQ_TUNING
+// mixq_gemm_set_fuse_probe (timing probe 77): the stand-in quantise phase's input rows, scratch output and counters (2 x tiles_m words, zero), until cleared
+static thread_local const uint16_t* t_fx = nullptr;
+static thread_local uint8_t* t_fq = nullptr;
+static thread_local unsigned int* t_fcnt = nullptr;
+static thread_local int t_fK = 0;
+void mixq_wr_fuse_probe(const void* x, void* scratch, void* counters, int K) { t_fx = static_cast<const uint16_t*>(x); t_fq = static_cast<uint8_t*>(scratch); t_fcnt = static_cast<unsigned int*>(counters); t_fK = K; }
 // mixq_gemm_hint_next_weights (experiment): the image the launch AFTER the next one will stream, for the next launch's loader waves to touch
 // (see the loader).  Per host thread, consumed by the next weights-in-registers launch from it.
 static thread_local const uint8_t* t_next_w = nullptr;
@@ -2348,6 +2440,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
         a.pf = t_next_w; a.pf_lines = static_cast<unsigned int>(t_next_bytes >> 7); a.pf_mode = mode;
     }
     t_next_w = nullptr; t_next_bytes = 0;                                    // (a hint serves ONE launch)
+    if (t_fx && t_fq && t_fcnt && t_fK > 0 && (t_fK & 7) == 0 && n_begin == 0 && n_cols == N) { a.fx = t_fx; a.fq = t_fq; a.fcnt = t_fcnt; a.fK = t_fK; }
 #endif
     void (*k)(const WrArgs) = pair ? (bit == 8 ? g.k8p : g.k6p) : (bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4));
     if (!k) return MIXQ_EINVAL;
