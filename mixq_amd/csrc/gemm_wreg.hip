@@ -66,6 +66,7 @@ struct WrArgs {
     int pf_mode;                                      // bit 0: scalar-cache touches, bit 1: vector touches (one lane per line), bit 2: ... with the nt hint
     // one-launch probe (ABL 77, mixq_gemm_set_fuse_probe): a stand-in quantise phase in front of the GEMM - fp16 rows in, bytes out, a counter per M tile
     const uint16_t* fx; uint8_t* fq; unsigned int* fcnt; int fK;
+    int fflags;                                       // (probe breakdown, env MIXQ_FUSE_FLAGS: 1 no stores, 2 no drain, 4 no atomic add, 8 no poll, 16 ordinary instead of write-through stores)
 #endif
 };
 
@@ -298,11 +299,12 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
                             const uint32_t pair = (static_cast<uint32_t>(q0) & 0xffu) | ((static_cast<uint32_t>(q1) & 0xffu) << 8);
                             if (e < 2) o.x |= pair << (16 * e); else o.y |= pair << (16 * (e - 2));
                         }
-                        __builtin_amdgcn_raw_buffer_store_b64(o, rq, ch * 8, 0, 16 /* sc1: write-through */);
+                        if (!(a.fflags & 1)) { if (a.fflags & 16) __builtin_amdgcn_raw_buffer_store_b64(o, rq, ch * 8, 0, 0); else __builtin_amdgcn_raw_buffer_store_b64(o, rq, ch * 8, 0, 16 /* sc1: write-through */); }
+                        else asm volatile("" :: "v"(o));
                     }
                 }
-                wr_wait_vmcnt<0>();
-                if (lane == 0) __hip_atomic_fetch_add(a.fcnt + r / BM, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(a.fflags & 2)) wr_wait_vmcnt<0>();
+                if (lane == 0 && !(a.fflags & 4)) __hip_atomic_fetch_add(a.fcnt + r / BM, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();                                                      // (the relay word is cleared before a loader can set it)
         }
@@ -436,7 +438,7 @@ __global__ __launch_bounds__((WR_CW + LOADERS) * 64) void gemm_wreg_kernel(const
         constexpr int RP = (LOOK > 6 && ABLK != 12) ? 4 : (F6 && LOOK > 3 ? 3 : LOOK);
 #ifdef MIXQ_TUNING
         if constexpr (ABLK == 77) {
-            if (a.fx) {                                   // (probe: the loaders wait for their M tile's rows - the consumers are already requesting weights)
+            if (a.fx && !(a.fflags & 8)) {                // (probe: the loaders wait for their M tile's rows - the consumers are already requesting weights)
                 const unsigned want = static_cast<unsigned>(a.M - m0 < BM ? a.M - m0 : BM);
                 int spins = 0;
                 // ONE lane of ONE loader wave polls, every ~0.5 us (all 64 lanes of 464 waves on four words: 55-59 us per forward - the words' memory channel
@@ -2440,7 +2442,7 @@ int mixq_wr_launch(int c, int bit, const void* q_x, const void* q_w, const uint1
         a.pf = t_next_w; a.pf_lines = static_cast<unsigned int>(t_next_bytes >> 7); a.pf_mode = mode;
     }
     t_next_w = nullptr; t_next_bytes = 0;                                    // (a hint serves ONE launch)
-    if (t_fx && t_fq && t_fcnt && t_fK > 0 && (t_fK & 7) == 0 && n_begin == 0 && n_cols == N) { a.fx = t_fx; a.fq = t_fq; a.fcnt = t_fcnt; a.fK = t_fK; }
+    if (t_fx && t_fq && t_fcnt && t_fK > 0 && (t_fK & 7) == 0 && n_begin == 0 && n_cols == N) { static const int ff = [] { const char* e = getenv("MIXQ_FUSE_FLAGS"); return e ? atoi(e) : 0; }(); a.fx = t_fx; a.fq = t_fq; a.fcnt = t_fcnt; a.fK = t_fK; a.fflags = ff; }
 #endif
     void (*k)(const WrArgs) = pair ? (bit == 8 ? g.k8p : g.k6p) : (bit == 8 ? g.k8 : (bit == 6 ? g.k6 : g.k4));
     if (!k) return MIXQ_EINVAL;
